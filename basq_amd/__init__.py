@@ -1,0 +1,18 @@
+"""basq_amd -- MI355X-native kernel recombination for BASQ (hot path of ma921/BASQ ``BASQ/_rchq.py``).
+
+Public surface (mirrors the reference's names):
+
+    recombination(pts_rec, pts_nys, num_pts, kernel, device, init_weights=0) -> (idx, w)
+    BASQ(batch_size, device).run_rchq(pts_nys, pts_rec, w_IS, kernel) -> (x, w)
+    KernelQuadrature(...).rchq / .quadrature
+    kernels.StationaryKernel / PosteriorKernel / WsabiKernel / from_gpytorch_model
+
+Importing the package does not touch the GPU; the HIP library is loaded on first use and its
+absence is an error (there is no CPU fallback).
+"""
+from . import kernels, pools                                  # noqa: F401
+from ._basq import BASQ, KernelQuadrature                      # noqa: F401
+from ._engine import EngineTrace                               # noqa: F401
+from ._rchq import recombination, recombination_sharded        # noqa: F401
+
+__all__ = ["recombination", "recombination_sharded", "BASQ", "KernelQuadrature", "EngineTrace", "kernels", "pools"]

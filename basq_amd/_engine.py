@@ -1,0 +1,306 @@
+"""Recombination engine: the host orchestration of the HIP kernels (one process per GPU).
+
+Mirrors ``BASQ/_rchq.py``: ``rc_kernel_svd`` (:34-40) = Nystrom basis + ``Mod_Tchernychova_Lyons``
+(:43-130) whose per-round reduction is ``Tchernychova_Lyons_CAR`` (:133-175).  What runs where:
+
+=======================================  ==========================================================
+step (reference lines)                   here
+=======================================  ==========================================================
+Gram ``kernel(pt, pt)`` (:29)            ``basq_gram_f64`` (+ small rocBLAS GEMMs for GP corrections)
+``torch.svd_lowrank`` (:29)              same algorithm (Halko 4.4/5.1, niter=2): Gaussian test matrix
+                                         from the CPU global generator (parity), GEMMs on the GPU,
+                                         QR / small SVD on host LAPACK (parity: sign conventions)
+hot loop + tail + tot (:79-99)           ``basq_blocksum_f64`` (fused, nothing materialised)
+``U_svd @ X_for_nys`` (:88)              ``basq_project_f64`` (f64 MFMA)
+divide, ones column (:101, :138)         ``basq_finalize_f64``
+full SVD -> null space (:140-143)        host LAPACK ``torch.linalg.svd`` (gesdd): the null-space basis
+                                         is algorithm-specific, any other SVD changes the selection
+                                         (SURVEY finding 3) -- 160 KB D2H + 160 KB H2D per round
+elimination loop (:146-175)              ``basq_car_eliminate_f64``
+re-weight + compaction (:107-130)        ``basq_reweight_compact_f64`` (closed-form destinations)
+=======================================  ==========================================================
+
+Multi-GPU: the candidate pool is sharded in contiguous id ranges; per round every rank
+block-sums and projects its shard, the ``(q+1) x S`` messages are all-gathered and added in rank order,
+rank 0 runs the reduction and broadcasts the (tiny) result; re-weighting/compaction are local.
+"""
+from __future__ import annotations
+
+import time
+from dataclasses import dataclass, field
+
+import torch
+
+from ._lib import ROLE_A, ROLE_B
+from ._partition import RoundGeometry, choose_chunks, local_blocks, next_shard, survivors_before
+
+
+# ----------------------------------------------------------------------------------------------------
+# communicators
+# ----------------------------------------------------------------------------------------------------
+class LocalComm:
+    rank, world = 0, 1
+
+    def all_gather(self, t):
+        return t.unsqueeze(0)
+
+    def broadcast(self, t, src=0):
+        return t
+
+
+class TorchDistComm:
+    """``torch.distributed`` (backend ``nccl`` = RCCL over xGMI on ROCm; ``gloo`` in the CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def all_gather(self, t):
+        out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        self.dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        return out
+
+    def broadcast(self, t, src=0):
+        self.dist.broadcast(t, src=src, group=self.group)
+        return t
+
+
+# ----------------------------------------------------------------------------------------------------
+# trace (tests / profiling)
+# ----------------------------------------------------------------------------------------------------
+@dataclass
+class EngineTrace:
+    rounds: list = field(default_factory=list)      # dicts: R, S, nb, n_tail, kept, tot, XcarT (optional)
+    U: torch.Tensor | None = None
+    timers: dict = field(default_factory=dict)
+    keep_tensors: bool = False
+
+    def add_time(self, key, dt):
+        self.timers[key] = self.timers.get(key, 0.0) + dt
+
+
+def _host_qr_q(ops, X):
+    """Q factor by host LAPACK (geqrf/orgqr), as ``torch.linalg.qr(X).Q`` on a CPU tensor."""
+    return ops.to_device(torch.linalg.qr(X.cpu()).Q)
+
+
+def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None):
+    """``ker_svd_sparsify`` (``BASQ/_rchq.py:28-31``): ``-svd_lowrank(A, q)[0].T`` -> ``[min(q,m), m]``.
+
+    Restates ``torch._lowrank.get_approximate_basis`` / ``_svd_lowrank`` (torch 2.10, niter=2, square A so
+    no transposition): the Gaussian test matrix is drawn exactly where the reference draws it -- one
+    ``torch.randn(m, q)`` from the CPU global generator.
+    """
+    m = A.shape[0]
+    R = torch.randn(m, q_req, dtype=torch.float64)           # CPU generator (reference: A is a CPU tensor)
+    At = A.t()
+    Q = _host_qr_q(ops, ops.matmul(A, ops.to_device(R)))
+    for _ in range(2):
+        Q = _host_qr_q(ops, ops.matmul(At, Q))
+        Q = _host_qr_q(ops, ops.matmul(A, Q))
+    B = ops.matmul(Q.t(), A)                                   # [k, m]
+    Ub, _, _ = torch.linalg.svd(B.cpu(), full_matrices=False)
+    U = ops.matmul(Q, ops.to_device(Ub))                       # [m, k]
+    return (-1 * U.t()).contiguous()                           # :30
+
+
+class RecombinationEngine:
+    def __init__(self, ops, comm=None):
+        self.ops = ops
+        self.comm = comm or LocalComm()
+
+    # ------------------------------------------------------------------------------------------------
+    def run(self, pts_local, gid0: int, n_total: int, pts_nys, num_pts: int, kernel, trace: EngineTrace | None = None):
+        """Recombine.  ``pts_local`` = this rank's contiguous slice ``[gid0, gid0 + len)`` of the pool.
+
+        Returns ``(idx int64[<=num_pts] ascending, w float64)`` on the ops device (identical on every rank).
+        """
+        ops, comm = self.ops, self.comm
+        if kernel.warp == "wsabim":
+            raise NotImplementedError("WSABI-M (0.5 cov^2 term) is not linear in the block sums: not built yet")
+        if n_total >= 2 ** 31:
+            raise ValueError("pool sizes >= 2^31 are not supported")
+        pts_nys = ops.to_device(pts_nys, torch.float64)
+        pts_local = ops.to_device(pts_local, torch.float64)
+        m, d = pts_nys.shape
+        Rl = pts_local.shape[0]
+        base, post, warp = kernel.base, kernel.posterior, kernel.warp
+        spec = base.spec(d)
+        kp = ops.kp(d)
+        t_all = time.perf_counter()
+
+        center = ops.col_mean(pts_nys)
+
+        # ---- Nystrom basis: rank 0 computes, everyone receives (one randn draw, as in the reference) ----
+        t0 = time.perf_counter()
+        if comm.rank == 0:
+            A = kernel.dense(ops, pts_nys, pts_nys, center)
+            U = nystrom_basis(ops, A, num_pts - 1, trace)
+            del A
+            qbuf = torch.tensor([U.shape[0]], dtype=torch.int64, device=U.device)
+        else:
+            qbuf = ops.zeros(1, dtype=torch.int64)
+        if comm.world > 1:
+            comm.broadcast(qbuf)
+            if comm.rank != 0:
+                U = ops.empty(int(qbuf.item()), m)
+            comm.broadcast(U)
+        q = U.shape[0]
+        s = q + 1
+        S = 2 * s                                               # :50
+        if trace is not None:
+            ops.synchronize()
+            trace.add_time("basis", time.perf_counter() - t0)
+            if trace.keep_tensors:
+                trace.U = U.clone()
+
+        # ---- extended operands: posterior correction / warping folded into the contraction -----------
+        nys_rows = [pts_nys]
+        Um = U
+        mu_pt = None
+        if warp != "none":
+            mu_pt = kernel.mean(ops, pts_nys, center)
+            Um = (U * mu_pt.unsqueeze(0)).contiguous()
+        U_cols = [Um]
+        diag_noise, n_obs = 0.0, 0
+        if post is not None:
+            Xo = ops.to_device(post.Xobs, torch.float64)
+            W = ops.to_device(post.W, torch.float64)
+            n_obs = Xo.shape[0]
+            Bmat = base.dense(ops, pts_nys, Xo, center) @ W      # [m, n_obs] (small rocBLAS GEMM)
+            U_cols.append(-(Um @ Bmat))
+            nys_rows.append(Xo)
+            diag_noise = post.noise
+        m_ext = m + n_obs
+        q_ext = q
+        wrow = 0
+        if warp != "none" and diag_noise != 0.0:
+            # an all-zero packed row has kernel value 1 with every candidate: its block sum is the
+            # kernel-weighted set weight needed by the diagonal-noise term of wsabil_kernel
+            zero_row_idx = m_ext
+            m_ext += 1
+            q_ext = q + 1
+            wrow = q + 1
+        nys_cat = torch.cat(nys_rows, 0) if len(nys_rows) > 1 else pts_nys
+        nys_ext = ops.pack(spec, nys_cat, center, ROLE_A, pad_rows_to=64)
+        if nys_ext.shape[0] < ((m_ext + 63) // 64) * 64:
+            nys_ext = torch.cat([nys_ext, ops.zeros(64, kp)], 0)
+        if wrow:
+            nys_ext[zero_row_idx].zero_()
+        U_ext = torch.cat(U_cols, 1) if len(U_cols) > 1 else Um
+        if wrow:
+            sel = ops.zeros(1, m_ext)
+            U_ext = torch.cat([torch.cat([U_ext, ops.zeros(q, 1)], 1), sel], 0)
+            U_ext[q, zero_row_idx] = 1.0 / spec.outputscale
+        U_ext = U_ext.contiguous()
+        diagU = Um if diag_noise != 0.0 else None
+
+        # ---- candidate state --------------------------------------------------------------------------
+        cand = ops.pack(spec, pts_local, center, ROLE_B)
+        mu, gid = ops.init_state(Rl, gid0, n_total)
+        wx = None
+        if warp != "none":
+            wx = kernel.mean(ops, pts_local, center) if Rl > 0 else ops.empty(1)
+        off, R = gid0, n_total
+        if trace is not None:
+            ops.synchronize()
+            trace.add_time("setup", time.perf_counter() - t0)
+
+        # ---- rounds -------------------------------------------------------------------------------------
+        while True:
+            if R <= s:                                           # :60-63 nothing to reduce
+                gids, mus = self._gather_survivors(gid, mu, Rl, R, off, S)
+                keep = mus > 0
+                idx, w = gids[keep], mus[keep]
+                break
+            final = R <= S                                       # :65-74 single reduction of the points
+            S_r = R if final else S
+            geo = RoundGeometry.of(R, S_r)
+            t0 = time.perf_counter()
+            n_chunks = choose_chunks(local_blocks(off, Rl, geo), m_ext, S_r)
+            Xpart, totpart = ops.blocksum(spec, nys_ext, m_ext, cand, mu, wx, Rl, off, geo.n_full, S_r, n_chunks)
+            msg = ops.project(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S_r, spec.outputscale)
+            if trace is not None:
+                ops.synchronize()
+                trace.add_time("blocksum+project", time.perf_counter() - t0)
+                t0 = time.perf_counter()
+            parts = comm.all_gather(msg) if comm.world > 1 else msg.unsqueeze(0)
+            M = S_r
+            res = ops.empty(2 + 2 * s + 2 * M)                   # info | kept | w_star | keep_rank | tot
+            if comm.rank == 0:
+                XcarT, tot = ops.finalize(parts, comm.world, q_ext + 1, q, S_r, diagU, m, min(m, S_r), diag_noise, wrow)
+                t1 = time.perf_counter()
+                Vh = torch.linalg.svd(XcarT.cpu())[2]            # :140 full SVD of [s, M] on host LAPACK
+                PhiT = ops.to_device(Vh[-(M - s):, :])           # :143 (rows = null-space vectors)
+                if trace is not None:
+                    trace.add_time("host_svd", time.perf_counter() - t1)
+                mu_car = tot.clone()
+                keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, mu_car, M, s)
+                res[0:2] = info.to(torch.float64)
+                res[2:2 + s] = kept.to(torch.float64)
+                res[2 + s:2 + 2 * s] = w_star
+                res[2 + 2 * s:2 + 2 * s + M] = keep_rank.to(torch.float64)
+                res[2 + 2 * s + M:] = tot
+            if comm.world > 1:
+                comm.broadcast(res)
+            head = res[:2 + s].cpu()
+            n_keep, status = int(head[0]), int(head[1])
+            if status != 0:
+                raise RuntimeError("Caratheodory elimination: a null vector has no positive entry "
+                                   "(the reference fails here too: argmin of an empty tensor, _rchq.py:152)")
+            kept_list = [int(v) for v in head[2:2 + n_keep]]
+            w_star = res[2 + s:2 + 2 * s].contiguous()
+            keep_rank = res[2 + 2 * s:2 + 2 * s + M].to(torch.int32)
+            tot = res[2 + 2 * s + M:].contiguous()
+            if trace is not None:
+                ops.synchronize()
+                trace.add_time("reduce", time.perf_counter() - t0)
+                rec = dict(R=R, S=S_r, nb=geo.nb, n_tail=geo.n_tail, kept=kept_list)
+                if trace.keep_tensors:
+                    rec["tot"] = tot.cpu()
+                    if comm.rank == 0:
+                        rec["XcarT"] = XcarT.cpu()
+                    rec["w_star"] = w_star[:n_keep].cpu()
+                trace.rounds.append(rec)
+            if final:
+                gids, _ = self._gather_survivors(gid, mu, Rl, R, off, S)
+                kept_t = torch.tensor(kept_list, dtype=torch.int64, device=gids.device)
+                idx, w = gids[kept_t], w_star[:n_keep].clone()   # :69-73
+                break
+            t0 = time.perf_counter()
+            new_off, new_Rl = next_shard(off, Rl, geo, kept_list)
+            cand, mu, gid, wx = ops.reweight_compact(cand, mu, gid, wx, Rl, off, geo.n_full, S_r, kp, keep_rank, w_star,
+                                                     tot, n_keep, new_off, new_Rl)
+            R = survivors_before(R, geo, kept_list)
+            off, Rl = new_off, new_Rl
+            if trace is not None:
+                ops.synchronize()
+                trace.add_time("compact", time.perf_counter() - t0)
+        if trace is not None:
+            ops.synchronize()
+            trace.add_time("total", time.perf_counter() - t_all)
+        return idx, w
+
+    # ------------------------------------------------------------------------------------------------
+    def _gather_survivors(self, gid, mu, Rl, R, off, cap):
+        """All ranks' (gid, mu) of the R <= cap survivors, in global position order, on every rank."""
+        comm, ops = self.comm, self.ops
+        if comm.world == 1:
+            return gid[:Rl], mu[:Rl]
+        buf = ops.zeros(2 * cap + 2)
+        buf[0] = float(off)
+        buf[1] = float(Rl)
+        buf[2:2 + Rl] = gid[:Rl].to(torch.float64)               # ids < 2^31: exact in float64
+        buf[2 + cap:2 + cap + Rl] = mu[:Rl]
+        allb = comm.all_gather(buf).cpu()
+        gids = torch.empty(R, dtype=torch.int64)
+        mus = torch.empty(R, dtype=torch.float64)
+        for r in range(comm.world):
+            o, n = int(allb[r, 0]), int(allb[r, 1])
+            gids[o:o + n] = allb[r, 2:2 + n].to(torch.int64)
+            mus[o:o + n] = allb[r, 2 + cap:2 + cap + n]
+        return ops.to_device(gids), ops.to_device(mus)

@@ -1,0 +1,184 @@
+"""Device operations of the recombination engine: thin, checked wrappers over the C ABI.
+
+Every method takes/returns torch tensors that live on one HIP device; torch is used only
+for memory, streams and (for now) the five tall-skinny GEMMs of the randomised SVD
+(rocBLAS through ``torch.matmul``).  All pairwise-kernel work, the Nystrom contraction,
+the elimination and the compaction run in ``libbasq_hip.so``.
+
+The engine (``_engine.py``) is written against this interface so that the CPU tests can
+drive its host logic (sharding, offsets, collectives) with a stand-in defined under
+``tests/`` -- the product never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import KernelSpecC, ROLE_A, ROLE_B, check
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class HipOps:
+    """Operations on ``device`` (a ``torch.device('cuda', i)``)."""
+
+    name = "hip"
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.BasqHipError("basq_amd runs on an AMD GPU (torch device type 'cuda'); no CPU path exists")
+        if not torch.cuda.is_available():
+            raise _lib.BasqHipError("no HIP device visible to torch")
+        self.lib = _lib.load()
+
+    # -- helpers -----------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _chk(self, t, dtype=torch.float64):
+        if t.device != self.device and not (t.device.type == "cuda" and t.device.index == self.device.index):
+            raise ValueError(f"tensor on {t.device}, expected {self.device}")
+        if t.dtype != dtype or not t.is_contiguous():
+            raise ValueError("expected a contiguous %s tensor" % dtype)
+        return t
+
+    def empty(self, *shape, dtype=torch.float64):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def zeros(self, *shape, dtype=torch.float64):
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def to_device(self, t, dtype=None):
+        return t.to(device=self.device, dtype=dtype or t.dtype).contiguous()
+
+    @staticmethod
+    def spec_c(spec) -> KernelSpecC:
+        return KernelSpecC(_lib.FAMILY[spec.family], int(spec.d), float(spec.lengthscale), float(spec.outputscale))
+
+    def kp(self, d: int) -> int:
+        kp = self.lib.basq_kp(int(d))
+        check(min(kp, 0), "basq_kp")
+        return kp
+
+    # -- kernels -----------------------------------------------------------------------------
+    def col_mean(self, X):
+        self._chk(X)
+        n, d = X.shape
+        mean = self.empty(d)
+        check(self.lib.basq_col_mean_f64(_ptr(X), n, d, _ptr(mean), self._stream()), "basq_col_mean_f64")
+        return mean
+
+    def pack(self, spec, X, center, role, pad_rows_to: int = 1):
+        """-> [rows, kp] with rows = n rounded up to ``pad_rows_to`` (extra rows zero)."""
+        self._chk(X)
+        n, d = X.shape
+        assert d == spec.d
+        kp = self.kp(d)
+        rows = ((n + pad_rows_to - 1) // pad_rows_to) * pad_rows_to
+        out = self.zeros(max(rows, 1), kp) if rows != n else self.empty(max(n, 1), kp)
+        sc = self.spec_c(spec)
+        check(self.lib.basq_pack_points_f64(C.byref(sc), _ptr(X), n, _ptr(center), role, _ptr(out), self._stream()),
+              "basq_pack_points_f64")
+        return out
+
+    def gram(self, spec, packA, na, packB, nb):
+        K = self.empty(na, nb)
+        sc = self.spec_c(spec)
+        check(self.lib.basq_gram_f64(C.byref(sc), _ptr(packA), na, _ptr(packB), nb, _ptr(K), nb, self._stream()),
+              "basq_gram_f64")
+        return K
+
+    def matvec(self, spec, packA, na, packB, nb, v, bias: float):
+        """out[i] = bias + sum_j k(A_i, B_j) v_j.  packA must have rows padded to a multiple of 64."""
+        self._chk(v)
+        out = self.empty(na)
+        sc = self.spec_c(spec)
+        check(self.lib.basq_kernel_matvec_f64(C.byref(sc), _ptr(packA), na, _ptr(packB), nb, _ptr(v), float(bias),
+                                              _ptr(out), self._stream()), "basq_kernel_matvec_f64")
+        return out
+
+    def blocksum(self, spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks):
+        Xpart = self.empty(n_chunks, m, S)
+        totpart = self.empty(n_chunks, S)
+        if Rl == 0:
+            Xpart.zero_()
+            totpart.zero_()
+            return Xpart, totpart
+        sc = self.spec_c(spec)
+        check(self.lib.basq_blocksum_f64(C.byref(sc), _ptr(nys), m, _ptr(cand), _ptr(mu), _ptr(wx), Rl, off, n_full, S,
+                                         n_chunks, _ptr(Xpart), _ptr(totpart), self._stream()), "basq_blocksum_f64")
+        return Xpart, totpart
+
+    def project(self, U, q, m, Xpart, totpart, n_chunks, S, outputscale, ksplit=None):
+        self._chk(U)
+        if ksplit is None:
+            ksplit = max(1, min(64, m // 128))
+        work = self.empty(ksplit, q, S)
+        out = self.empty(q + 1, S)
+        check(self.lib.basq_project_f64(_ptr(U), q, m, _ptr(Xpart), _ptr(totpart), n_chunks, S, float(outputscale),
+                                        ksplit, _ptr(work), _ptr(out), self._stream()), "basq_project_f64")
+        return out
+
+    def finalize(self, parts, n_parts, msg_rows, q, S, diagU=None, ld_diag=0, n_diag=0, diag_noise=0.0, diag_wrow=0):
+        self._chk(parts)
+        XcarT = self.empty(q + 1, S)
+        tot = self.empty(S)
+        check(self.lib.basq_finalize_f64(_ptr(parts), n_parts, msg_rows, q, S, _ptr(diagU), ld_diag, n_diag,
+                                         float(diag_noise), diag_wrow, _ptr(XcarT), _ptr(tot), self._stream()),
+              "basq_finalize_f64")
+        return XcarT, tot
+
+    def car_eliminate(self, PhiT, mu, M, s):
+        """In place on PhiT/mu.  -> (keep_rank[M] i32, kept[s] i32, w_star[s] f64, info[2] i32)."""
+        self._chk(PhiT)
+        self._chk(mu)
+        keep_rank = self.empty(M, dtype=torch.int32)
+        kept = self.empty(max(s, 1), dtype=torch.int32)
+        w_star = self.empty(max(s, 1))
+        info = self.empty(2, dtype=torch.int32)
+        check(self.lib.basq_car_eliminate_f64(_ptr(PhiT), _ptr(mu), M, s, _ptr(keep_rank), _ptr(kept), _ptr(w_star),
+                                              _ptr(info), self._stream()), "basq_car_eliminate_f64")
+        return keep_rank, kept, w_star, info
+
+    def reweight_compact(self, cand, mu, gid, wx, Rl, off, n_full, S, kp, keep_rank, w_star, tot, n_keep, new_off,
+                         new_Rl):
+        cand_o = self.empty(max(new_Rl, 1), kp)
+        mu_o = self.empty(max(new_Rl, 1))
+        gid_o = self.empty(max(new_Rl, 1), dtype=torch.int64)
+        wx_o = self.empty(max(new_Rl, 1)) if wx is not None else None
+        check(self.lib.basq_reweight_compact_f64(_ptr(cand), _ptr(mu), _ptr(gid), _ptr(wx), Rl, off, n_full, S, kp,
+                                                 _ptr(keep_rank), _ptr(w_star), _ptr(tot), n_keep, new_off,
+                                                 _ptr(cand_o), _ptr(mu_o), _ptr(gid_o), _ptr(wx_o), self._stream()),
+              "basq_reweight_compact_f64")
+        return cand_o, mu_o, gid_o, wx_o
+
+    def init_state(self, Rl, gid0, n_total):
+        mu = self.empty(max(Rl, 1))
+        gid = self.empty(max(Rl, 1), dtype=torch.int64)
+        check(self.lib.basq_init_state_f64(_ptr(mu), _ptr(gid), Rl, gid0, n_total, self._stream()),
+              "basq_init_state_f64")
+        return mu, gid
+
+    def gemm(self, A, B, alpha=1.0):
+        """C = alpha * A @ B on the f64 matrix cores (own kernel)."""
+        self._chk(A)
+        self._chk(B)
+        Mr, K = A.shape
+        K2, N = B.shape
+        assert K == K2
+        Cm = self.empty(Mr, N)
+        check(self.lib.basq_gemm_f64(_ptr(A), K, _ptr(B), N, _ptr(Cm), N, Mr, N, K, float(alpha), self._stream()),
+              "basq_gemm_f64")
+        return Cm
+
+    # -- plumbing (library GEMMs of the randomised SVD; rocBLAS via torch) ---------------------
+    def matmul(self, A, B):
+        return torch.matmul(A, B)
+
+    def synchronize(self):
+        torch.cuda.current_stream(self.device).synchronize()

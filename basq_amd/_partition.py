@@ -1,0 +1,82 @@
+"""Closed-form bookkeeping of the divide-and-conquer rounds (host side, pure Python).
+
+The reference keeps the survivors as one ascending index list ``idx_story`` and derives
+everything from positions in it (``BASQ/_rchq.py:76-78,91,107-130``):
+
+* ``S = 2 (q + 1)`` sets; position ``p`` belongs to set ``p % S`` for ``p < nb * S``
+  (``nb = R // S`` full blocks) and to set ``S - 1`` otherwise (the ragged tail);
+* after the reduction keeps the sets ``kept`` (ascending), a survivor at block ``b`` whose
+  set has rank ``k`` among ``kept`` lands at position ``b * n_keep + k``; tail survivors
+  (only if set ``S-1`` was kept) follow at ``nb * n_keep + (p - nb * S)``.
+
+Because the map is closed-form, a rank that holds the contiguous positions
+``[off, off + Rl)`` can compute where its survivors go, and how many it keeps, without any
+collective: that is what makes the pool shard over GPUs with a single small exchange per
+round.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+
+@dataclass(frozen=True)
+class RoundGeometry:
+    R: int          # surviving candidates (all ranks)
+    S: int          # number of sets this round
+    nb: int         # full blocks: R // S
+    n_full: int     # nb * S
+    n_tail: int     # R - n_full
+
+    @staticmethod
+    def of(R: int, S: int) -> "RoundGeometry":
+        nb = R // S
+        return RoundGeometry(R, S, nb, nb * S, R - nb * S)
+
+
+def survivors_before(P: int, geo: RoundGeometry, kept: list) -> int:
+    """Number of survivors among global positions ``[0, P)`` when the sets ``kept`` survive."""
+    n_keep = len(kept)
+    last_kept = n_keep > 0 and kept[-1] == geo.S - 1
+    if P <= geo.n_full:
+        b, s = divmod(P, geo.S)
+        below = sum(1 for k in kept if k < s)
+        return b * n_keep + below
+    return geo.nb * n_keep + ((P - geo.n_full) if last_kept else 0)
+
+
+def next_shard(off: int, Rl: int, geo: RoundGeometry, kept: list):
+    """-> (new_off, new_Rl) for the rank holding positions ``[off, off + Rl)``."""
+    lo = survivors_before(off, geo, kept)
+    hi = survivors_before(off + Rl, geo, kept)
+    return lo, hi - lo
+
+
+def initial_shards(N: int, world: int):
+    """Contiguous, near-equal shards of the candidate ids ``0..N-1``: [(off, Rl)] per rank."""
+    base, extra = divmod(N, world)
+    out, off = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append((off, n))
+        off += n
+    return out
+
+
+def local_blocks(off: int, Rl: int, geo: RoundGeometry) -> int:
+    """How many global blocks intersect this rank's block positions."""
+    lim = min(off + Rl, geo.n_full)
+    if lim <= off:
+        return 0
+    return (lim + geo.S - 1) // geo.S - off // geo.S
+
+
+def choose_chunks(n_local_blocks: int, m: int, S: int, target_waves: int = 4096, min_blocks: int = 8,
+                  max_chunks: int = 64) -> int:
+    """Split the block loop so the launch has ~``target_waves`` waves without starving a chunk.
+
+    One wave covers 64 Nystrom rows x 16 sets; chunks multiply the wave count.
+    """
+    waves = ((m + 63) // 64) * ((S + 15) // 16)
+    want = max(1, -(-target_waves // max(waves, 1)))
+    cap = max(1, n_local_blocks // min_blocks)
+    return max(1, min(want, cap, max_chunks))

@@ -1,0 +1,792 @@
+// basq_hip.hip -- gfx950 (MI355X, CDNA4) kernels behind include/basq_hip.h.
+//
+// Hot path: kernel recombination of ma921/BASQ (BASQ/_rchq.py).  Everything is float64 (SURVEY §8c:
+// the reference's index selection is only well-posed in fp64).  Wave = 64 lanes; the pairwise
+// exponent arguments are produced on the f64 matrix cores (v_mfma_f64_16x16x4_f64) from packed
+// operands, the transcendental epilogue runs on the fp64 VALU, which is the binding unit.
+//
+// MFMA f64 16x16x4 lane maps (cdna_hip_programming.md §3):  lane l, c = l & 15, g = l >> 4
+//     A operand: A[row = c][k = g]      B operand: B[k = g][col = c]
+//     C/D:       D[reg r] = D[row = g + 4 r][col = c]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/basq_hip.h"
+#include "exp_coeffs.inc"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define BASQ_CHECK_LAUNCH()                                   \
+    do {                                                      \
+        if (hipGetLastError() != hipSuccess) return BASQ_ELAUNCH; \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// fp64 exp for arguments <= 0 (every kernel family evaluates exp of a non-positive number).
+// x = n ln2 + r, |r| <= ln2/2; degree-10 polynomial (2.9e-16 rel. before rounding); 2^n applied by an
+// integer add on the exponent field.  Arguments below -708 are clamped (result ~3e-308 instead of 0).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double exp_nonpos(double x) {
+    x = fmax(x, -708.0);
+    const double MAGIC = 0x1.8p52;
+    const double t = __builtin_fma(x, BASQ_LOG2E, MAGIC);
+    const double nf = t - MAGIC;
+    double r = __builtin_fma(nf, -BASQ_LN2_HI, x);
+    r = __builtin_fma(nf, -BASQ_LN2_LO, r);
+    double p = BASQ_EXP_P10;
+    p = __builtin_fma(p, r, BASQ_EXP_P9);
+    p = __builtin_fma(p, r, BASQ_EXP_P8);
+    p = __builtin_fma(p, r, BASQ_EXP_P7);
+    p = __builtin_fma(p, r, BASQ_EXP_P6);
+    p = __builtin_fma(p, r, BASQ_EXP_P5);
+    p = __builtin_fma(p, r, BASQ_EXP_P4);
+    p = __builtin_fma(p, r, BASQ_EXP_P3);
+    p = __builtin_fma(p, r, BASQ_EXP_P2);
+    p = __builtin_fma(p, r, BASQ_EXP_P1);
+    p = __builtin_fma(p, r, BASQ_EXP_P0);
+    const int n = __double2loint(t);               // low word of t holds n (two's complement)
+    const int hi = __double2hiint(p) + (n << 20);  // p * 2^n, p in [0.70, 1.42], n >= -1022
+    return __hiloint2double(hi, __double2loint(p));
+}
+
+// Kernel value (without outputscale) from D = -1/2 |(x-y)/l|^2.
+template <int FAM>
+__device__ __forceinline__ double kernel_from_arg(double D) {
+    if (FAM == BASQ_FAMILY_RBF) {
+        return exp_nonpos(fmin(D, 0.0));           // clamp: squared distance >= 0
+    } else {
+        const double r2 = fmax(-2.0 * D, 1e-30);   // gpytorch: clamp_min(1e-30) before sqrt
+        const double r = sqrt(r2);
+        if (FAM == BASQ_FAMILY_MATERN52) {
+            const double a = 0x1.1e3779b97f4a8p+1 * r;   // sqrt(5) r
+            const double poly = (a + 1.0) + (5.0 / 3.0) * r2;
+            return poly * exp_nonpos(-a);
+        } else {
+            const double a = 0x1.bb67ae8584caap+0 * r;   // sqrt(3) r
+            return (a + 1.0) * exp_nonpos(-a);
+        }
+    }
+}
+
+// Sum over the 16 lanes that share g = lane >> 4 (the 16 columns of an MFMA tile); fixed butterfly
+// order, result in every lane of the group.
+__device__ __forceinline__ double sum16(double v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pack / init / mean
+// ------------------------------------------------------------------------------------------------
+__global__ void col_mean_kernel(const double* __restrict__ X, long long n, int d, double* __restrict__ mean) {
+    // one block; thread (k, lane-in-column) ; fixed-order two-level sum => deterministic
+    __shared__ double part[1024];
+    const int per = blockDim.x / d;                 // threads per column
+    const int k = threadIdx.x % d, t = threadIdx.x / d;
+    double acc = 0.0;
+    if (t < per)
+        for (long long i = t; i < n; i += per) acc += X[i * d + k];
+    part[threadIdx.x] = (t < per) ? acc : 0.0;
+    __syncthreads();
+    if (threadIdx.x < d) {
+        double s = 0.0;
+        for (int u = 0; u < per; ++u) s += part[u * d + threadIdx.x];
+        mean[threadIdx.x] = n > 0 ? s / (double)n : 0.0;
+    }
+}
+
+__global__ void pack_points_kernel(const double* __restrict__ X, long long n, int d, int kp,
+                                   const double* __restrict__ center, double inv_ell, int role,
+                                   double* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double h = 0.0;
+    double* o = out + i * kp;
+    for (int k = 0; k < d; ++k) {
+        const double c = center ? center[k] : 0.0;
+        const double v = (X[i * d + k] - c) * inv_ell;
+        o[k] = v;
+        h = __builtin_fma(v, v, h);
+    }
+    h *= -0.5;
+    o[d] = (role == BASQ_ROLE_A) ? h : 1.0;
+    o[d + 1] = (role == BASQ_ROLE_A) ? 1.0 : h;
+    for (int k = d + 2; k < kp; ++k) o[k] = 0.0;
+}
+
+__global__ void init_state_kernel(double* __restrict__ mu, long long* __restrict__ gid, long long Rl, long long gid0,
+                                  double w0) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Rl) return;
+    mu[i] = w0;
+    gid[i] = gid0 + i;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused block sums (BASQ/_rchq.py:79-99).  One wave owns a 64 x 16 tile of (Nystrom rows x sets):
+// the A fragments of its 64 rows stay in registers for the whole launch; every iteration streams
+// the 16 candidates of one block that fall in the wave's 16 sets (B fragments), issues
+// JT*KK MFMAs for the exponent arguments and evaluates 16 kernel values per lane on the VALU.
+// ------------------------------------------------------------------------------------------------
+struct BlocksumArgs {
+    const double* nys;
+    const double* cand;
+    const double* mu;
+    const double* wx;
+    double* Xpart;
+    double* totpart;
+    long long Rl, off, n_full;
+    long long blk_lo, blk_hi, blk_per_chunk;   // global block-index range touched by this rank
+    int m, S, n_chunks, n_stiles;
+};
+
+template <int KK>
+struct CandFrag {
+    double b[KK];
+    double w;    // kernel weight mu * wx (0 for masked columns)
+    double wm;   // mu (0 for masked columns)
+};
+
+template <int KK>
+__device__ __forceinline__ void load_cand(CandFrag<KK>& f, const BlocksumArgs& A, long long pl, bool ok, int g) {
+    constexpr int KP = KK * 4;
+    const long long row = ok ? pl : 0;
+    const double* src = A.cand + row * KP + g;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) f.b[kk] = src[kk * 4];
+    const double m_ = A.mu[row];
+    const double x_ = A.wx ? A.wx[row] : 1.0;
+    f.wm = ok ? m_ : 0.0;
+    f.w = ok ? m_ * x_ : 0.0;
+}
+
+template <int KK, int FAM, int JT>
+__device__ __forceinline__ void tile_accumulate(const double (&a)[JT][KK], const CandFrag<KK>& f, double (&acc)[JT][4]) {
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        d4 D = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) D = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt][kk], f.b[kk], D, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[jt][r] = __builtin_fma(kernel_from_arg<FAM>(D[r]), f.w, acc[jt][r]);
+    }
+}
+
+template <int KK, int FAM, int JT>
+__global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A) {
+    constexpr int KP = KK * 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    int b = blockIdx.x;
+    const int st = b % A.n_stiles;
+    b /= A.n_stiles;
+    const int chunk = b % A.n_chunks;
+    const int jg = b / A.n_chunks;
+    const int j0 = (jg * 4 + wave) * (16 * JT);
+    if (j0 >= A.m) return;   // wave-uniform; no barriers in this kernel
+    const int s0 = st * 16;
+
+    double a[JT][KK];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) a[jt][kk] = A.nys[(long long)(j0 + jt * 16 + c) * KP + kk * 4 + g];
+
+    double acc[JT][4];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[jt][r] = 0.0;
+    double tot = 0.0;
+
+    const bool col_ok = (s0 + c) < A.S;
+    const long long lim = (A.off + A.Rl < A.n_full) ? (A.off + A.Rl) : A.n_full;   // end of block positions held here
+    long long bA = A.blk_lo + (long long)chunk * A.blk_per_chunk;
+    long long bB = bA + A.blk_per_chunk;
+    if (bB > A.blk_hi) bB = A.blk_hi;
+
+    if (bA < bB) {
+        long long pg = bA * A.S + s0 + c;   // global position of this lane's column in block bA
+        CandFrag<KK> cur, nxt;
+        load_cand<KK>(cur, A, pg - A.off, col_ok && pg >= A.off && pg < lim, g);
+        for (long long i = bA; i < bB; ++i) {
+            pg += A.S;
+            const bool more = (i + 1 < bB);
+            load_cand<KK>(nxt, A, pg - A.off, more && col_ok && pg >= A.off && pg < lim, g);
+            tile_accumulate<KK, FAM, JT>(a, cur, acc);
+            tot += cur.wm;
+            cur = nxt;
+        }
+    }
+
+    // Ragged tail (positions >= n_full all belong to set S-1, BASQ/_rchq.py:91-99): 16 tail candidates
+    // per iteration, one per column; folded into the column that owns set S-1 at the end.
+    const long long t0 = (A.n_full > A.off) ? (A.n_full - A.off) : 0;   // first local tail position
+    if (chunk == A.n_chunks - 1 && st == A.n_stiles - 1 && t0 < A.Rl) {
+        double tacc[JT][4];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tacc[jt][r] = 0.0;
+        double ttot = 0.0;
+        for (long long p = t0; p < A.Rl; p += 16) {
+            CandFrag<KK> f;
+            load_cand<KK>(f, A, p + c, (p + c) < A.Rl, g);
+            tile_accumulate<KK, FAM, JT>(a, f, tacc);
+            ttot += f.wm;
+        }
+        const int c_last = (A.S - 1) - s0;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = sum16(tacc[jt][r]);
+                if (c == c_last) acc[jt][r] += v;
+            }
+        const double tv = sum16(ttot);
+        if (c == c_last) tot += tv;
+    }
+
+    if (col_ok) {
+        double* out = A.Xpart + (long long)chunk * A.m * A.S;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + jt * 16 + g + 4 * r;
+                if (j < A.m) out[(long long)j * A.S + s0 + c] = acc[jt][r];
+            }
+        if (A.totpart && jg == 0 && wave == 0 && g == 0) A.totpart[(long long)chunk * A.S + s0 + c] = tot;
+    }
+}
+
+template <int KK, int FAM>
+static int launch_blocksum(const BlocksumArgs& A, hipStream_t st) {
+    constexpr int JT = 4;
+    const int jgroups = (A.m + 64 * JT - 1) / (64 * JT);   // 4 waves x 64 rows per block
+    const long long nblk = (long long)A.n_stiles * A.n_chunks * jgroups;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return BASQ_EINVAL;
+    hipLaunchKernelGGL((blocksum_kernel<KK, FAM, JT>), dim3((unsigned)nblk), dim3(256), 0, st, A);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+template <int KK>
+static int dispatch_blocksum_fam(int fam, const BlocksumArgs& A, hipStream_t st) {
+    switch (fam) {
+        case BASQ_FAMILY_RBF: return launch_blocksum<KK, BASQ_FAMILY_RBF>(A, st);
+        case BASQ_FAMILY_MATERN52: return launch_blocksum<KK, BASQ_FAMILY_MATERN52>(A, st);
+        case BASQ_FAMILY_MATERN32: return launch_blocksum<KK, BASQ_FAMILY_MATERN32>(A, st);
+    }
+    return BASQ_EUNSUPPORTED;
+}
+
+static int dispatch_blocksum(int kk, int fam, const BlocksumArgs& A, hipStream_t st) {
+    switch (kk) {
+        case 1: return dispatch_blocksum_fam<1>(fam, A, st);
+        case 2: return dispatch_blocksum_fam<2>(fam, A, st);
+        case 3: return dispatch_blocksum_fam<3>(fam, A, st);
+        case 4: return dispatch_blocksum_fam<4>(fam, A, st);
+        case 5: return dispatch_blocksum_fam<5>(fam, A, st);
+        case 6: return dispatch_blocksum_fam<6>(fam, A, st);
+        case 7: return dispatch_blocksum_fam<7>(fam, A, st);
+        case 8: return dispatch_blocksum_fam<8>(fam, A, st);
+        case 9: return dispatch_blocksum_fam<9>(fam, A, st);
+        case 10: return dispatch_blocksum_fam<10>(fam, A, st);
+    }
+    return BASQ_EUNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense kernel matrix: wave = 64 rows x (CT x 16) columns, A fragments resident.
+// ------------------------------------------------------------------------------------------------
+template <int KK, int FAM>
+__global__ void __launch_bounds__(256) gram_kernel(const double* __restrict__ pa, long long na,
+                                                   const double* __restrict__ pb, long long nb, double scale,
+                                                   double* __restrict__ K, long long ldk, int ctiles_per_block) {
+    constexpr int KP = KK * 4, JT = 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const long long i0 = ((long long)blockIdx.y * 4 + wave) * 64;
+    if (i0 >= na) return;
+    double a[JT][KK];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        long long row = i0 + jt * 16 + c;
+        if (row >= na) row = na - 1;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) a[jt][kk] = pa[row * KP + kk * 4 + g];
+    }
+    const long long ct0 = (long long)blockIdx.x * ctiles_per_block;
+    for (int t = 0; t < ctiles_per_block; ++t) {
+        const long long j0 = (ct0 + t) * 16;
+        if (j0 >= nb) break;
+        long long col = j0 + c;
+        const bool ok = col < nb;
+        if (!ok) col = nb - 1;
+        double b[KK];
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) b[kk] = pb[col * KP + kk * 4 + g];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            d4 D = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) D = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt][kk], b[kk], D, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long row = i0 + jt * 16 + g + 4 * r;
+                if (ok && row < na) K[row * ldk + j0 + c] = scale * kernel_from_arg<FAM>(D[r]);
+            }
+        }
+    }
+}
+
+template <int KK>
+static int dispatch_gram_fam(int fam, const double* pa, long long na, const double* pb, long long nb, double scale,
+                             double* K, long long ldk, hipStream_t st) {
+    const int ct = 8;
+    const long long ctiles = (nb + 15) / 16;
+    dim3 grid((unsigned)((ctiles + ct - 1) / ct), (unsigned)((na + 255) / 256));
+    switch (fam) {
+        case BASQ_FAMILY_RBF:
+            hipLaunchKernelGGL((gram_kernel<KK, BASQ_FAMILY_RBF>), grid, dim3(256), 0, st, pa, na, pb, nb, scale, K, ldk, ct);
+            break;
+        case BASQ_FAMILY_MATERN52:
+            hipLaunchKernelGGL((gram_kernel<KK, BASQ_FAMILY_MATERN52>), grid, dim3(256), 0, st, pa, na, pb, nb, scale, K, ldk, ct);
+            break;
+        case BASQ_FAMILY_MATERN32:
+            hipLaunchKernelGGL((gram_kernel<KK, BASQ_FAMILY_MATERN32>), grid, dim3(256), 0, st, pa, na, pb, nb, scale, K, ldk, ct);
+            break;
+        default: return BASQ_EUNSUPPORTED;
+    }
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// f64 MFMA GEMM:  Cpart[z][M,N] = sum_{k in slice z} A[M,K] * (sum_c B[c][K,N]).
+// Wave tile (16 JT) x 16.  Used for the Nystrom-feature contraction (BASQ/_rchq.py:88) and as the
+// generic GEMM of the randomised SVD.
+// ------------------------------------------------------------------------------------------------
+template <int JT>
+__global__ void __launch_bounds__(256) gemm_kernel(const double* __restrict__ A, long long lda,
+                                                   const double* __restrict__ B, long long ldb, long long bstride,
+                                                   int nsum, double* __restrict__ C, long long ldc, long long cstride,
+                                                   int M, int N, int K, int kslice, double alpha) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int r0 = blockIdx.x * (16 * JT);
+    const int n0 = (blockIdx.y * 4 + wave) * 16;
+    if (n0 >= N) return;
+    const int k0 = blockIdx.z * kslice;
+    int k1 = k0 + kslice;
+    if (k1 > K) k1 = K;
+    const int col = (n0 + c < N) ? (n0 + c) : (N - 1);
+    long long arow[JT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        int r = r0 + jt * 16 + c;
+        if (r >= M) r = M - 1;
+        arow[jt] = (long long)r * lda;
+    }
+    d4 acc[JT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) acc[jt] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int k = k0; k < k1; k += 4) {
+        const int kg = k + g;
+        const bool kin = kg < k1;
+        double b = 0.0;
+        if (kin) {
+            const double* bp = B + (long long)kg * ldb + col;
+            b = bp[0];
+            for (int u = 1; u < nsum; ++u) b += bp[(long long)u * bstride];
+        }
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const double a = kin ? A[arow[jt] + kg] : 0.0;
+            acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[jt], 0, 0, 0);
+        }
+    }
+    if (n0 + c < N) {
+        double* Cz = C + (long long)blockIdx.z * cstride;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r0 + jt * 16 + g + 4 * r;
+                if (row < M) Cz[(long long)row * ldc + n0 + c] = alpha * acc[jt][r];
+            }
+    }
+}
+
+// out[0][s] = sum_c totpart[c][s];  out[1+r][s] = sum_z work[z][r][s]   (fixed order)
+__global__ void project_reduce_kernel(const double* __restrict__ work, int ksplit, int q, int S,
+                                      const double* __restrict__ totpart, int n_chunks, double* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (q + 1) * S) return;
+    const int r = idx / S, s = idx % S;
+    double v = 0.0;
+    if (r == 0) {
+        for (int cc = 0; cc < n_chunks; ++cc) v += totpart[(long long)cc * S + s];
+    } else {
+        for (int z = 0; z < ksplit; ++z) v += work[((long long)z * q + (r - 1)) * S + s];
+    }
+    out[idx] = v;
+}
+
+__global__ void finalize_kernel(const double* __restrict__ parts, int n_parts, int msg_rows, int q, int S,
+                                const double* __restrict__ diagU, long long ld_diag, int n_diag, double diag_noise,
+                                int diag_wrow, double* __restrict__ XcarT, double* __restrict__ tot_out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (q + 1) * S) return;
+    const int r = idx / S, s = idx % S;
+    const long long stride = (long long)msg_rows * S;
+    double tot = 0.0;
+    for (int p = 0; p < n_parts; ++p) tot += parts[p * stride + s];
+    if (r == 0) {
+        XcarT[idx] = 1.0;
+        tot_out[s] = tot;
+        return;
+    }
+    double v = 0.0;
+    for (int p = 0; p < n_parts; ++p) v += parts[p * stride + idx];
+    if (diagU && s < n_diag) {
+        double wgt = tot;
+        if (diag_wrow != 0) {
+            wgt = 0.0;
+            for (int p = 0; p < n_parts; ++p) wgt += parts[p * stride + (long long)diag_wrow * S + s];
+        }
+        v += diag_noise * wgt * diagU[(long long)(r - 1) * ld_diag + s];
+    }
+    XcarT[idx] = v / tot;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Caratheodory elimination (BASQ/_rchq.py:146-175), single work-group, reference op order.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) car_eliminate_kernel(double* __restrict__ PhiT, double* __restrict__ mu_g,
+                                                             int M, int s, int* __restrict__ keep_rank,
+                                                             int* __restrict__ kept, double* __restrict__ w_star,
+                                                             int* __restrict__ info) {
+    __shared__ double mu[1024];
+    __shared__ double pc[1024];
+    __shared__ double red_v[16];
+    __shared__ int red_i[16];
+    __shared__ double sh_alpha, sh_phij;
+    __shared__ int sh_j;
+    __shared__ int wave_cnt[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int nrows = M - s;
+    const double INF = __builtin_huge_val();
+    mu[tid] = (tid < M) ? mu_g[tid] : 0.0;
+    int status = 0;
+    // update-pass geometry: thread -> fixed column i, rows strided
+    const int rows_per_pass = 1024 / M;
+    const int my_i = tid % M, my_r = tid / M;
+    const bool upd = my_r < rows_per_pass;
+    __syncthreads();
+    for (int k = 0; k < nrows; ++k) {
+        const double* col = PhiT + (long long)k * M;
+        const double phi = (tid < M) ? col[tid] : 0.0;
+        const bool pos = (tid < M) && (phi > 0.0);
+        double av = pos ? __ddiv_rn(mu[tid], phi) : INF;
+        int ai = pos ? tid : 0x7fffffff;
+        // first-index argmin (torch.argmin semantics, :152)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const double ov = __shfl_xor(av, o, 64);
+            const int oi = __shfl_xor(ai, o, 64);
+            if (ov < av || (ov == av && oi < ai)) { av = ov; ai = oi; }
+        }
+        if (lane == 0) { red_v[wv] = av; red_i[wv] = ai; }
+        __syncthreads();
+        if (wv == 0) {
+            double v = (lane < 16) ? red_v[lane] : INF;
+            int i = (lane < 16) ? red_i[lane] : 0x7fffffff;
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) {
+                const double ov = __shfl_xor(v, o, 64);
+                const int oi = __shfl_xor(i, o, 64);
+                if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+            }
+            if (lane == 0) { sh_j = i; sh_alpha = v; }
+        }
+        __syncthreads();
+        const int j = sh_j;
+        if (j == 0x7fffffff) { status = 1; break; }   // uniform: no positive entry (reference raises)
+        if (tid == j) sh_phij = phi;
+        const double aj = sh_alpha;
+        if (tid < M) mu[tid] = (tid == j) ? 0.0 : __dsub_rn(mu[tid], __dmul_rn(aj, phi));   // :158-159
+        for (int cc = k + 1 + tid; cc < nrows; cc += 1024) pc[cc] = PhiT[(long long)cc * M + j];
+        __syncthreads();
+        const double phij = sh_phij;
+        const double phi_i = col[my_i];
+        if (upd) {
+            for (int cc = k + 1 + my_r; cc < nrows; cc += rows_per_pass) {   // :165-171
+                double* p = PhiT + (long long)cc * M + my_i;
+                const double o = __ddiv_rn(__dmul_rn(pc[cc], phi_i), phij);
+                *p = (my_i == j) ? 0.0 : __dsub_rn(*p, o);
+            }
+        }
+        __syncthreads();
+    }
+    // survivors: mu > 0 (:173-174), ascending
+    const bool keep = (tid < M) && (mu[tid] > 0.0);
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) wave_cnt[wv] = __popcll(bal);
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wv) base += wave_cnt[w];
+        total += wave_cnt[w];
+    }
+    const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
+    if (tid < M) {
+        keep_rank[tid] = keep ? rank : -1;
+        mu_g[tid] = mu[tid];
+        if (keep) { kept[rank] = tid; w_star[rank] = mu[tid]; }
+    }
+    if (tid == 0) { info[0] = total; info[1] = status; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Survivor re-weighting + order-preserving compaction (BASQ/_rchq.py:107-130).
+// ------------------------------------------------------------------------------------------------
+__global__ void reweight_compact_kernel(const double* __restrict__ cand, const double* __restrict__ mu,
+                                        const long long* __restrict__ gid, const double* __restrict__ wx,
+                                        long long Rl, long long off, long long n_full, int S, int kp,
+                                        const int* __restrict__ keep_rank, const double* __restrict__ w_star,
+                                        const double* __restrict__ tot, int n_keep, long long new_off,
+                                        double* __restrict__ cand_out, double* __restrict__ mu_out,
+                                        long long* __restrict__ gid_out, double* __restrict__ wx_out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Rl * kp) return;
+    const long long p = t / kp;
+    const int k = (int)(t - p * kp);
+    const long long pg = off + p;
+    int set;
+    long long dst;
+    if (pg < n_full) {
+        const long long blk = pg / S;
+        set = (int)(pg - blk * S);
+        dst = blk * n_keep;
+    } else {
+        set = S - 1;
+        dst = (n_full / S) * n_keep + (pg - n_full);
+    }
+    const int kr = keep_rank[set];
+    if (kr < 0) return;
+    if (pg < n_full) dst += kr;
+    dst -= new_off;
+    cand_out[dst * kp + k] = cand[t];
+    if (k == 0) {
+        mu_out[dst] = __ddiv_rn(__dmul_rn(mu[p], w_star[kr]), tot[set]);   // :113-114 / :121-122
+        gid_out[dst] = gid[p];
+        if (wx) wx_out[dst] = wx[p];
+    }
+}
+
+__global__ void axpb_strided_kernel(const double* __restrict__ x, long long n, long long stride, double a, double b,
+                                    double* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = __builtin_fma(a, x[i * stride], b);
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+static inline bool spec_ok(const basq_kernel_spec* s) {
+    return s && s->d >= 1 && s->d <= BASQ_MAX_DIM && s->lengthscale > 0.0 && s->family >= 0 && s->family <= 2;
+}
+
+extern "C" {
+
+const char* basq_strerror(int code) {
+    switch (code) {
+        case BASQ_OK: return "ok";
+        case BASQ_EINVAL: return "invalid argument";
+        case BASQ_ELAUNCH: return "HIP kernel launch failed";
+        case BASQ_EUNSUPPORTED: return "kernel family or size not supported";
+    }
+    return "unknown error";
+}
+
+int basq_abi_version(void) { return BASQ_ABI_VERSION; }
+
+int basq_kp(int d) {
+    if (d < 1 || d > BASQ_MAX_DIM) return BASQ_EINVAL;
+    return ((d + 2 + 3) / 4) * 4;
+}
+
+int basq_col_mean_f64(const double* X, int64_t n, int d, double* mean, void* stream) {
+    if (!X || !mean || n < 0 || d < 1 || d > BASQ_MAX_DIM) return BASQ_EINVAL;
+    hipLaunchKernelGGL(col_mean_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, X, (long long)n, d, mean);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_pack_points_f64(const basq_kernel_spec* spec, const double* X, int64_t n, const double* center, int role,
+                         double* out, void* stream) {
+    if (!spec_ok(spec) || !out || n < 0 || (n > 0 && !X) || (role != BASQ_ROLE_A && role != BASQ_ROLE_B))
+        return BASQ_EINVAL;
+    if (n == 0) return BASQ_OK;
+    const int kp = basq_kp(spec->d);
+    hipLaunchKernelGGL(pack_points_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X,
+                       (long long)n, spec->d, kp, center, 1.0 / spec->lengthscale, role, out);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_gram_f64(const basq_kernel_spec* spec, const double* packA, int64_t na, const double* packB, int64_t nb,
+                  double* K, int64_t ldk, void* stream) {
+    if (!spec_ok(spec) || na < 0 || nb < 0 || ldk < nb) return BASQ_EINVAL;
+    if (na == 0 || nb == 0) return BASQ_OK;
+    if (!packA || !packB || !K) return BASQ_EINVAL;
+    const int kk = basq_kp(spec->d) / 4;
+    hipStream_t st = (hipStream_t)stream;
+    const double sc = spec->outputscale;
+    switch (kk) {
+        case 1: return dispatch_gram_fam<1>(spec->family, packA, na, packB, nb, sc, K, ldk, st);
+        case 2: return dispatch_gram_fam<2>(spec->family, packA, na, packB, nb, sc, K, ldk, st);
+        case 3: return dispatch_gram_fam<3>(spec->family, packA, na, packB, nb, sc, K, ldk, st);
+        case 4: return dispatch_gram_fam<4>(spec->family, packA, na, packB, nb, sc, K, ldk, st);
+        case 5: return dispatch_gram_fam<5>(spec->family, packA, na, packB, nb, sc, K, ldk, st);
+        case 6: return dispatch_gram_fam<6>(spec->family, packA, na, packB, nb, sc, K, ldk, st);
+        case 7: return dispatch_gram_fam<7>(spec->family, packA, na, packB, nb, sc, K, ldk, st);
+        case 8: return dispatch_gram_fam<8>(spec->family, packA, na, packB, nb, sc, K, ldk, st);
+        case 9: return dispatch_gram_fam<9>(spec->family, packA, na, packB, nb, sc, K, ldk, st);
+        case 10: return dispatch_gram_fam<10>(spec->family, packA, na, packB, nb, sc, K, ldk, st);
+    }
+    return BASQ_EUNSUPPORTED;
+}
+
+static int blocksum_impl(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
+                         const double* mu, const double* wx, int64_t Rl, int64_t off, int64_t n_full, int32_t S,
+                         int32_t n_chunks, double* Xpart, double* totpart, void* stream) {
+    if (!spec_ok(spec) || !nys || !cand || !mu || !Xpart) return BASQ_EINVAL;
+    if (m < 1 || Rl < 1 || off < 0 || n_full < 0 || S < 1 || n_chunks < 1) return BASQ_EINVAL;
+    if (n_full % S != 0) return BASQ_EINVAL;
+    BlocksumArgs A;
+    A.nys = nys; A.cand = cand; A.mu = mu; A.wx = wx; A.Xpart = Xpart; A.totpart = totpart;
+    A.Rl = Rl; A.off = off; A.n_full = n_full; A.m = m; A.S = S; A.n_chunks = n_chunks;
+    A.n_stiles = (S + 15) / 16;
+    // global blocks that intersect [off, min(off+Rl, n_full))
+    const long long lim = (off + Rl < n_full) ? (off + Rl) : n_full;
+    if (lim > off) {
+        A.blk_lo = off / S;
+        A.blk_hi = (lim + S - 1) / S;
+    } else {
+        A.blk_lo = 0;
+        A.blk_hi = 0;
+    }
+    const long long nblk = A.blk_hi - A.blk_lo;
+    A.blk_per_chunk = (nblk + n_chunks - 1) / n_chunks;
+    if (A.blk_per_chunk < 1) A.blk_per_chunk = 1;
+    return dispatch_blocksum(basq_kp(spec->d) / 4, spec->family, A, (hipStream_t)stream);
+}
+
+int basq_blocksum_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
+                      const double* mu, const double* wx, int64_t Rl, int64_t off, int64_t n_full, int32_t S,
+                      int32_t n_chunks, double* Xpart, double* totpart, void* stream) {
+    if (!totpart) return BASQ_EINVAL;
+    return blocksum_impl(spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, Xpart, totpart, stream);
+}
+
+int basq_kernel_matvec_f64(const basq_kernel_spec* spec, const double* packA, int64_t na, const double* packB,
+                           int64_t nb, const double* v, double bias, double* out, void* stream) {
+    // blocksum with a single set and everything in the "tail": out[i] = sum_j k(A_i, B_j) v_j.
+    if (!spec_ok(spec) || !packA || !packB || !v || !out || na < 1 || nb < 1 || na > 0x7fffffffLL)
+        return BASQ_EINVAL;
+    int rc = blocksum_impl(spec, packA, (int32_t)na, packB, v, nullptr, nb, 0, 0, 1, 1, out, nullptr, stream);
+    if (rc != BASQ_OK) return rc;
+    hipLaunchKernelGGL(axpb_strided_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out,
+                       (long long)na, 1LL, spec->outputscale, bias, out);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_project_f64(const double* U, int32_t q, int32_t m, const double* Xpart, const double* totpart,
+                     int32_t n_chunks, int32_t S, double outputscale, int32_t ksplit, double* work, double* out,
+                     void* stream) {
+    if (!U || !Xpart || !totpart || !work || !out || q < 1 || m < 1 || S < 1 || n_chunks < 1 || ksplit < 1)
+        return BASQ_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    int kslice = (m + ksplit - 1) / ksplit;
+    kslice = ((kslice + 3) / 4) * 4;
+    const int nz = (m + kslice - 1) / kslice;
+    dim3 grid((unsigned)((q + 15) / 16), (unsigned)((S + 63) / 64), (unsigned)nz);
+    hipLaunchKernelGGL((gemm_kernel<1>), grid, dim3(256), 0, st, U, (long long)m, Xpart, (long long)S,
+                       (long long)m * S, n_chunks, work, (long long)S, (long long)q * S, q, S, m, kslice, outputscale);
+    BASQ_CHECK_LAUNCH();
+    const int tot = (q + 1) * S;
+    hipLaunchKernelGGL(project_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, work, nz, q, S,
+                       totpart, n_chunks, out);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_finalize_f64(const double* parts, int32_t n_parts, int32_t msg_rows, int32_t q, int32_t S,
+                      const double* diagU, int64_t ld_diag, int32_t n_diag, double diag_noise, int32_t diag_wrow,
+                      double* XcarT, double* tot_out, void* stream) {
+    if (!parts || !XcarT || !tot_out || n_parts < 1 || q < 1 || S < 1 || msg_rows < q + 1) return BASQ_EINVAL;
+    if (diag_wrow < 0 || diag_wrow >= msg_rows) return BASQ_EINVAL;
+    const int tot = (q + 1) * S;
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, parts,
+                       n_parts, msg_rows, q, S, diagU, (long long)ld_diag, n_diag, diag_noise, diag_wrow, XcarT,
+                       tot_out);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32_t* keep_rank, int32_t* kept,
+                           double* w_star, int32_t* info, void* stream) {
+    if (!PhiT || !mu || !keep_rank || !kept || !w_star || !info || M < 1 || M > 1024 || s < 1 || s > M)
+        return BASQ_EINVAL;
+    hipLaunchKernelGGL(car_eliminate_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, PhiT, mu, M, s, keep_rank,
+                       kept, w_star, info);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_reweight_compact_f64(const double* cand, const double* mu, const int64_t* gid, const double* wx,
+                              int64_t Rl, int64_t off, int64_t n_full, int32_t S, int32_t kp,
+                              const int32_t* keep_rank, const double* w_star, const double* tot, int32_t n_keep,
+                              int64_t new_off, double* cand_out, double* mu_out, int64_t* gid_out, double* wx_out,
+                              void* stream) {
+    if (!cand || !mu || !gid || !keep_rank || !w_star || !tot || !cand_out || !mu_out || !gid_out) return BASQ_EINVAL;
+    if (Rl < 0 || S < 1 || kp < 4 || n_keep < 0 || (wx && !wx_out)) return BASQ_EINVAL;
+    if (Rl == 0) return BASQ_OK;
+    const long long nt = (long long)Rl * kp;
+    hipLaunchKernelGGL(reweight_compact_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       cand, mu, (const long long*)gid, wx, (long long)Rl, (long long)off, (long long)n_full, S, kp,
+                       keep_rank, w_star, tot, n_keep, (long long)new_off, cand_out, mu_out, (long long*)gid_out,
+                       wx_out);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_init_state_f64(double* mu, int64_t* gid, int64_t Rl, int64_t gid0, int64_t n_total, void* stream) {
+    if (!mu || !gid || Rl < 0 || n_total < 1) return BASQ_EINVAL;
+    if (Rl == 0) return BASQ_OK;
+    // torch.ones(N) / N (BASQ/_rchq.py:53): one correctly rounded division
+    hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((Rl + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mu,
+                       (long long*)gid, (long long)Rl, (long long)gid0, 1.0 / (double)n_total);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_gemm_f64(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, int32_t M,
+                  int32_t N, int32_t K, double alpha, void* stream) {
+    if (!A || !B || !C || M < 1 || N < 1 || K < 1 || lda < K || ldb < N || ldc < N) return BASQ_EINVAL;
+    dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64), 1);
+    const int kslice = ((K + 3) / 4) * 4;
+    hipLaunchKernelGGL((gemm_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, A, (long long)lda, B, (long long)ldb,
+                       0LL, 1, C, (long long)ldc, 0LL, M, N, K, kslice, alpha);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+}  // extern "C"

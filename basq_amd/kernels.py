@@ -1,0 +1,192 @@
+"""Kernel objects accepted by :func:`basq_amd.recombination` in place of the reference's callables.
+
+The reference passes ``kernel`` as an opaque Python callable ``(X[a,d], Y[b,d]) -> Tensor[a,b]``
+(``BASQ/_rchq.py:4-25``): a bound method of a GP wrapper (``VanillaGP.predictive_kernel``
+``BASQ/_vbq.py:119-128``, ``WsabiGP.wsabil_kernel`` / ``wsabim_kernel`` ``BASQ/_wsabi.py:205-249``) or
+``ScaleKernel.forward`` (``BASQ/_quadrature.py:101``).  A GPU kernel cannot call back into Python per
+block, so the native path needs the kernel's *structure*.  The classes here are still callables with
+the reference's dense semantics (``k(X, Y)`` returns the ``[a, b]`` matrix, computed by the HIP Gram
+kernel) -- so code such as ``VarZy = w @ kernel(X, X) @ w`` (``BASQ/_quadrature.py:62``) keeps working --
+and additionally expose what the fused recombination kernels need:
+
+=====================  =====================================================================
+``StationaryKernel``   ``ScaleKernel(RBFKernel | MaternKernel(nu))`` (``_parameters.py:192-208``)
+``PosteriorKernel``    ``predictive_covariance`` (``BASQ/_gp.py:259-277``), incl. the noise it adds
+                       to the leading diagonal of every block
+``WsabiKernel``        ``wsabil_kernel`` / ``wsabim_kernel`` (``BASQ/_wsabi.py:205-249``)
+=====================  =====================================================================
+
+``from_gpytorch_model`` builds them from a fitted gpytorch model by attribute access only (gpytorch
+itself is not imported).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+
+from ._lib import FAMILY, MAX_DIM, ROLE_A, ROLE_B
+
+
+@dataclass(frozen=True)
+class KernelSpec:
+    family: str
+    d: int
+    lengthscale: float
+    outputscale: float
+
+
+def _ops_for(x):
+    from ._ops import HipOps
+
+    return HipOps(x.device)
+
+
+class StationaryKernel:
+    """``outputscale * base(|x - y| / lengthscale)``, base in {rbf, matern52, matern32}, shared lengthscale."""
+
+    def __init__(self, family: str, lengthscale: float, outputscale: float = 1.0):
+        if family not in FAMILY:
+            raise ValueError(f"unknown kernel family {family!r}; expected one of {sorted(FAMILY)}")
+        if not lengthscale > 0:
+            raise ValueError("lengthscale must be positive")
+        self.family = family
+        self.lengthscale = float(lengthscale)
+        self.outputscale = float(outputscale)
+
+    def spec(self, d: int) -> KernelSpec:
+        if not 1 <= d <= MAX_DIM:
+            raise ValueError(f"dimension {d} outside 1..{MAX_DIM}")
+        return KernelSpec(self.family, int(d), self.lengthscale, self.outputscale)
+
+    def dense(self, ops, x, y, center=None):
+        spec = self.spec(x.shape[1])
+        if center is None:
+            center = ops.col_mean(x)          # gpytorch centres on the first operand
+        pa = ops.pack(spec, x, center, ROLE_A)
+        pb = ops.pack(spec, y, center, ROLE_B)
+        return ops.gram(spec, pa, x.shape[0], pb, y.shape[0])
+
+    def __call__(self, x, y):
+        x = x.to(torch.float64).contiguous()
+        y = y.to(torch.float64).contiguous()
+        return self.dense(_ops_for(x), x, y)
+
+    # structure queried by the engine
+    base = property(lambda self: self)
+    posterior = None
+    warp = "none"
+
+
+class PosteriorKernel:
+    """GP posterior covariance ``k(x,y) - k(x,X) W k(X,y)`` + ``noise`` on the leading diagonal."""
+
+    warp = "none"
+
+    def __init__(self, base: StationaryKernel, Xobs, woodbury_inv, noise: float):
+        self.base = base
+        self.Xobs = Xobs
+        self.W = woodbury_inv
+        self.noise = float(noise)
+
+    @property
+    def posterior(self):
+        return self
+
+    def dense(self, ops, x, y, center=None):
+        Xo = ops.to_device(self.Xobs, torch.float64)
+        W = ops.to_device(self.W, torch.float64)
+        if center is None:
+            center = ops.col_mean(x)
+        cov = self.base.dense(ops, x, y, center)
+        KxX = self.base.dense(ops, x, Xo, center)
+        KXy = self.base.dense(ops, Xo, y, center)
+        cov = cov - KxX @ W @ KXy
+        k = min(x.shape[0], y.shape[0])
+        cov.diagonal()[:k] += self.noise                      # _gp.py:275-276
+        return cov
+
+    def __call__(self, x, y):
+        x = x.to(torch.float64).contiguous()
+        y = y.to(torch.float64).contiguous()
+        return self.dense(_ops_for(x), x, y)
+
+
+class WsabiKernel:
+    """``mu(x) cov(x,y) mu(y)`` (+ ``0.5 cov^2`` for WSABI-M), ``mu`` = warped-GP posterior mean."""
+
+    def __init__(self, post: PosteriorKernel, mean_const: float, mean_cache, label: str = "wsabil",
+                 jitter: float = 0.0):
+        if label not in ("wsabil", "wsabim"):
+            raise ValueError(label)
+        self.posterior = post
+        self.base = post.base
+        self.mean_const = float(mean_const)
+        self.mean_cache = mean_cache
+        self.warp = label
+        self.jitter = float(jitter)
+
+    def mean(self, ops, x, center=None):
+        """``predict(x, model)[0]`` (``BASQ/_gp.py:213-230``) = const + k(x, Xobs) @ mean_cache, via the HIP mat-vec."""
+        spec = self.base.spec(x.shape[1])
+        Xo = ops.to_device(self.posterior.Xobs, torch.float64)
+        v = ops.to_device(self.mean_cache, torch.float64)
+        if center is None:
+            center = ops.col_mean(x)
+        pa = ops.pack(spec, x, center, ROLE_A, pad_rows_to=64)
+        pb = ops.pack(spec, Xo, center, ROLE_B)
+        return ops.matvec(spec, pa, x.shape[0], pb, Xo.shape[0], v, self.mean_const)
+
+    def dense(self, ops, x, y, center=None):
+        if center is None:
+            center = ops.col_mean(x)
+        cov = self.posterior.dense(ops, x, y, center)
+        out = self.mean(ops, x, center).unsqueeze(1) * cov * self.mean(ops, y, center).unsqueeze(0)
+        if self.warp == "wsabim":
+            out = out + 0.5 * cov * cov
+        k = min(x.shape[0], y.shape[0])
+        out.diagonal()[:k] += self.jitter
+        return out
+
+    def __call__(self, x, y):
+        x = x.to(torch.float64).contiguous()
+        y = y.to(torch.float64).contiguous()
+        return self.dense(_ops_for(x), x, y)
+
+
+def from_gpytorch_model(model, kind: str = "predictive", wsabi_label: str = "wsabil"):
+    """Build a kernel object from a fitted gpytorch ``ExactGP`` (duck-typed; gpytorch is not imported).
+
+    ``kind``: ``"prior"`` -> ``model.covar_module.forward`` (``_quadrature.py:101``);
+    ``"predictive"`` -> ``predictive_covariance`` (``_vbq.py:119-128``); ``"wsabi"`` -> WSABI-L/M.
+    Reads the same attributes the reference reads at ``_gp.py:233-256`` and ``_gaussian_calc.py:44-51``.
+    """
+    cm = model.covar_module
+    bk = cm.base_kernel
+    name = type(bk).__name__
+    if "RBF" in name:
+        family = "rbf"
+    elif "Matern" in name:
+        nu = float(getattr(bk, "nu"))
+        family = {2.5: "matern52", 1.5: "matern32"}.get(nu)
+        if family is None:
+            raise ValueError(f"Matern nu={nu} not supported")
+    else:
+        raise ValueError(f"unsupported base kernel {name}")
+    ls = bk.lengthscale
+    if getattr(ls, "numel", lambda: 1)() != 1:
+        raise ValueError("ARD lengthscales are not supported (the reference uses a single shared lengthscale)")
+    base = StationaryKernel(family, float(ls.detach().reshape(-1)[0]), float(cm.outputscale.detach().reshape(-1)[0]))
+    if kind == "prior":
+        return base
+    Xobs = model.train_inputs[0].detach()
+    noise = float(model.likelihood.noise.detach().reshape(-1)[0])
+    S = model.prediction_strategy.covar_cache.detach()
+    post = PosteriorKernel(base, Xobs, S @ S.T, noise)       # _gp.py:255
+    if kind == "predictive":
+        return post
+    if kind == "wsabi":
+        mean_cache = model.prediction_strategy.mean_cache.detach()
+        const = float(model.mean_module.constant.detach().reshape(-1)[0])
+        return WsabiKernel(post, const, mean_cache, wsabi_label)
+    raise ValueError(kind)

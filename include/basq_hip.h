@@ -1,0 +1,170 @@
+/*
+ * basq_hip.h -- C ABI of libbasq_hip.so: MI355X (gfx950) kernels for the kernel-recombination
+ * hot path of ma921/BASQ (BASQ/_rchq.py), float64.
+ *
+ * The reference has no FFI: its boundary is the Python function
+ *     recombination(pts_rec, pts_nys, num_pts, kernel, device, init_weights)   BASQ/_rchq.py:4-25
+ * reached through BASQ.run_rchq (BASQ/_basq.py:59-80) and KernelQuadrature.rchq
+ * (BASQ/_quadrature.py:29-51).  This library is what a binding of that path would call; the Python
+ * shim basq_amd/_rchq.py (ctypes, tensor.data_ptr(), current HIP stream) keeps the reference's
+ * signatures.  Each entry point below names the reference lines it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all buffers;
+ *    the library allocates nothing and keeps no global mutable state;
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *  - return value: 0 on success, a negative BASQ_E* code otherwise; never throws, never exits;
+ *  - matrices are row-major, float64; indices are int64 unless stated.
+ *
+ * Packed operands.  Points are pre-packed once per batch into rows of KP = basq_kp(d) doubles so that
+ * the pairwise exponent argument is ONE dot product on the f64 matrix cores:
+ *     role A (left / Nystrom side):  [ (x-c)/l ... , h,  1, 0.. ]     h = -1/2 |(x-c)/l|^2
+ *     role B (right / candidate side): [ (y-c)/l ... , 1,  h, 0.. ]
+ *     A_row . B_row = -1/2 |(x-y)/l|^2   (c = centring vector, l = lengthscale)
+ * (the centring mirrors gpytorch's mean-centred squared distance, see oracle/kernels_oracle.py).
+ */
+#ifndef BASQ_HIP_H
+#define BASQ_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BASQ_ABI_VERSION 1
+
+/* error codes */
+#define BASQ_OK            0
+#define BASQ_EINVAL       -1   /* bad argument (null pointer, negative size, unsupported d, ...) */
+#define BASQ_ELAUNCH      -2   /* HIP launch error (see hipGetLastError on the caller side)       */
+#define BASQ_EUNSUPPORTED -3   /* kernel family / size not compiled in                            */
+
+/* kernel families: the stationary kernels the reference selects at BASQ/_parameters.py:192-208 */
+#define BASQ_FAMILY_RBF      0   /* s2 * exp(-r^2/2)                           */
+#define BASQ_FAMILY_MATERN52 1   /* s2 * (1 + sqrt5 r + 5 r^2/3) exp(-sqrt5 r) */
+#define BASQ_FAMILY_MATERN32 2   /* s2 * (1 + sqrt3 r) exp(-sqrt3 r)           */
+
+#define BASQ_ROLE_A 0
+#define BASQ_ROLE_B 1
+
+#define BASQ_MAX_DIM 38   /* KP <= 40 */
+
+typedef struct basq_kernel_spec {
+    int32_t family;        /* BASQ_FAMILY_*                                        */
+    int32_t d;             /* input dimension, 1..BASQ_MAX_DIM                     */
+    double  lengthscale;   /* single shared lengthscale (no ARD), > 0              */
+    double  outputscale;   /* ScaleKernel outputscale s2                           */
+} basq_kernel_spec;
+
+const char* basq_strerror(int code);
+int         basq_abi_version(void);
+
+/* KP: packed row length (multiple of 4, >= d + 2). */
+int basq_kp(int d);
+
+/* Column means of X[n,d] -> mean[d]  (the centring vector; gpytorch centres on the first operand). */
+int basq_col_mean_f64(const double* X, int64_t n, int d, double* mean, void* stream);
+
+/* Pack X[n,d] into out[n,KP] for `role`; `center` may be NULL (no centring). */
+int basq_pack_points_f64(const basq_kernel_spec* spec, const double* X, int64_t n, const double* center,
+                         int role, double* out, void* stream);
+
+/*
+ * Dense kernel matrix K[na,nb] = k(A_i, B_j) from packed operands (ldk = row stride of K, >= nb).
+ * Replaces the `kernel(x, y)` callable of the reference where a dense block is really needed:
+ * the Nystrom Gram `kernel(pt, pt)` (BASQ/_rchq.py:29) and K(X,X) of the quadrature (BASQ/_quadrature.py:62).
+ */
+int basq_gram_f64(const basq_kernel_spec* spec, const double* packA, int64_t na, const double* packB, int64_t nb,
+                  double* K, int64_t ldk, void* stream);
+
+/*
+ * Kernel mat-vec: out[i] = bias + sum_j k(A_i, B_j) * v[j], i < na   (GP posterior mean of predict(),
+ * BASQ/_gp.py:213-230, with v = mean_cache, bias = constant mean).
+ */
+int basq_kernel_matvec_f64(const basq_kernel_spec* spec, const double* packA, int64_t na, const double* packB,
+                           int64_t nb, const double* v, double bias, double* out, void* stream);
+
+/*
+ * Fused block sums -- the hot loop BASQ/_rchq.py:79-86 (+ tot_weights :90 and the ragged tail :91-99).
+ *
+ * The rank holds `Rl` surviving candidates (rows of `cand`, role-B packed, in ascending global
+ * position) starting at global position `off`; global position p belongs to set  p % S  when
+ * p < n_full (= number_of_el * S) and to set S-1 otherwise (the tail).  For every Nystrom row j < m
+ * (role-A packed `nys`, allocated with rows padded to a multiple of 64) and set s < S:
+ *     Xpart[c][j][s]  = sum over this rank's candidates p of chunk c in set s of  k(nys_j, cand_p) * mu_p * (wx ? wx_p : 1)
+ *     totpart[c][s]   = sum of mu_p over the same candidates
+ * The candidate blocks are split into `n_chunks` contiguous chunks (more parallelism; the consumer
+ * adds the chunks in index order, so results do not depend on scheduling).  Chunk n_chunks-1 also
+ * receives the tail.  Xpart: [n_chunks, m, S], totpart: [n_chunks, S]; both fully overwritten.
+ * The output is NOT multiplied by outputscale (basq_project_f64 applies it).
+ */
+int basq_blocksum_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
+                      const double* mu, const double* wx, int64_t Rl, int64_t off, int64_t n_full, int32_t S,
+                      int32_t n_chunks, double* Xpart, double* totpart, void* stream);
+
+/*
+ * Nystrom-feature contraction BASQ/_rchq.py:88-90:  out[0][s] = sum_c totpart[c][s];
+ *     out[1+r][s] = outputscale * sum_j U[r][j] * (sum_c Xpart[c][j][s])        r < q
+ * on the f64 matrix cores (v_mfma_f64_16x16x4_f64), K split `ksplit` ways through `work`
+ * ([ksplit, q, S] doubles) and re-added in index order.  `out` is [(q+1), S]: the per-rank message
+ * of the multi-GPU all-gather; it is NOT yet divided by the set weights.
+ */
+int basq_project_f64(const double* U, int32_t q, int32_t m, const double* Xpart, const double* totpart,
+                     int32_t n_chunks, int32_t S, double outputscale, int32_t ksplit, double* work, double* out,
+                     void* stream);
+
+/*
+ * Sum `n_parts` rank messages [msg_rows, S] in index order, divide feature rows 1..q by row 0 (block
+ * barycentres, BASQ/_rchq.py:101) and write the matrix the reduction decomposes
+ * (BASQ/_rchq.py:138-140):  XcarT[0][s] = 1, XcarT[1+r][s] = feature_r(s) / tot[s];  tot[s] -> tot_out.
+ * Optional additive term (predictive_covariance's diagonal noise, BASQ/_gp.py:275-276, which the
+ * reference adds to entry [k][k] of EVERY kernel block):  if diagU != NULL,
+ *     feature_r(s) += diag_noise * weight(s) * diagU[r*ld_diag + s]      for s < n_diag
+ * with weight = message row `diag_wrow` (0 = the set weights; q+1 = an extra message row, used by the
+ * WSABI-L kernel whose block sums carry a per-candidate factor).  msg_rows >= q + 1.
+ */
+int basq_finalize_f64(const double* parts, int32_t n_parts, int32_t msg_rows, int32_t q, int32_t S,
+                      const double* diagU, int64_t ld_diag, int32_t n_diag, double diag_noise, int32_t diag_wrow,
+                      double* XcarT, double* tot_out, void* stream);
+
+/*
+ * Caratheodory elimination -- the loop of Tchernychova_Lyons_CAR, BASQ/_rchq.py:146-175, in the
+ * reference's floating-point op order (separate multiply / subtract, outer product then divide).
+ * PhiT is the null-space basis as ROWS: PhiT[k][i] = Phi[i][k], [M-s, M] (the last M-s rows of the
+ * full Vh of the SVD at :140-143); it is destroyed.  mu [M] holds the set weights on entry and the
+ * reduced weights on exit (zero for eliminated sets).  Outputs: keep_rank[M] (rank among survivors
+ * or -1), kept[<=s] ascending survivor ids, w_star[<=s], info[0] = n_keep, info[1] = status
+ * (0 ok, 1 = a null vector had no positive entry: the reference would raise at :152).
+ * Single work-group kernel; M <= 1024.
+ */
+int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32_t* keep_rank, int32_t* kept,
+                           double* w_star, int32_t* info, void* stream);
+
+/*
+ * Survivor re-weighting and order-preserving compaction, BASQ/_rchq.py:107-130.
+ * For each local candidate p (global position off+p): its set's survivor rank kr = keep_rank[set];
+ * dropped if kr < 0; otherwise mu' = (mu * w_star[kr]) / tot[set] (multiply, then divide: :113-114)
+ * and the row moves to new local position
+ *     (blk * n_keep + kr) - new_off              for block positions (blk = position / S)
+ *     (nb * n_keep + position - n_full) - new_off for tail positions
+ * cand/mu/gid/wx -> cand_out/mu_out/gid_out/wx_out (wx may be NULL).  new_off is computed by the
+ * host from the same closed form (basq_amd/_partition.py).
+ */
+int basq_reweight_compact_f64(const double* cand, const double* mu, const int64_t* gid, const double* wx,
+                              int64_t Rl, int64_t off, int64_t n_full, int32_t S, int32_t kp,
+                              const int32_t* keep_rank, const double* w_star, const double* tot, int32_t n_keep,
+                              int64_t new_off, double* cand_out, double* mu_out, int64_t* gid_out, double* wx_out,
+                              void* stream);
+
+/* Initial state: mu[p] = 1/N_total (BASQ/_rchq.py:53), gid[p] = gid0 + p (:55). */
+int basq_init_state_f64(double* mu, int64_t* gid, int64_t Rl, int64_t gid0, int64_t n_total, void* stream);
+
+/* Dense f64 GEMM on the matrix cores: C[M,N] = alpha * A[M,K] @ B[K,N] (row-major, lda/ldb/ldc). */
+int basq_gemm_f64(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, int32_t M,
+                  int32_t N, int32_t K, double alpha, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BASQ_HIP_H */

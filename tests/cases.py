@@ -1,0 +1,127 @@
+"""Parity cases: how the inputs of every golden fixture are rebuilt from seeds.
+
+A case is a plain dict (it is stored verbatim inside the fixture):
+
+    name, N, d, m (n_nys), n (num_pts), pool_seed, torch_seed,
+    kernel: {family, lengthscale, outputscale,
+             posterior: {n_obs, noise, obs_seed} | None,
+             warp: "none" | "wsabil" | "wsabim"}
+
+Inputs are *regenerated* (``basq_amd.pools.gmm_pool`` is bit-reproducible across
+hosts), only expected outputs are committed under ``tests/golden/``.
+"""
+from __future__ import annotations
+
+import torch
+
+from basq_amd.pools import gmm_pool
+
+
+def K(family="rbf", lengthscale=2.0, outputscale=1.0, posterior=None, warp="none"):
+    return dict(family=family, lengthscale=lengthscale, outputscale=outputscale, posterior=posterior, warp=warp)
+
+
+def case(name, N, d, m, n, kernel, pool_seed=0, torch_seed=1, slow=False):
+    return dict(name=name, N=N, d=d, m=m, n=n, pool_seed=pool_seed, torch_seed=torch_seed, kernel=kernel, slow=slow)
+
+
+POST = dict(n_obs=102, noise=1e-10, obs_seed=11)
+POST_W = dict(n_obs=202, noise=1e-10, obs_seed=12)
+
+CASES = [
+    # SURVEY §8c known-answer shape (N=1000, d=2, m=50, n=10) on the portable pool.
+    case("kat_small", 1000, 2, 50, 10, K("rbf", 1.0)),
+    # BASELINE config 1 shape: N=1e4, posterior-corrected RBF (vbq default kernel).
+    case("cfg1_posterior_1e4", 10_000, 10, 100, 100, K("rbf", 2.0, 1.3, posterior=POST)),
+    case("rbf_1e4", 10_000, 10, 100, 100, K("rbf", 2.0)),
+    # BASQ defaults n_rec=20000, nys_ratio=1e-2, batch 100 (_parameters.py:38-41).
+    case("rbf_2e4_defaults", 20_000, 10, 200, 100, K("rbf", 2.0), pool_seed=1),
+    # ragged sizes: N not a multiple of 2n, m < 2n, odd d
+    case("rbf_ragged", 12_345, 7, 123, 37, K("rbf", 1.5, 0.7), pool_seed=2),
+    case("rbf_exact_blocks", 200 * 32, 3, 128, 100, K("rbf", 1.0), pool_seed=3),   # N = 32 * 2n exactly
+    case("rbf_d1", 5_000, 1, 50, 20, K("rbf", 0.8), pool_seed=4),
+    case("rbf_direct_car", 150, 3, 30, 60, K("rbf", 2.0), pool_seed=5),          # m < q: rank clipped to m
+    case("rbf_tiny_final", 150, 3, 100, 100, K("rbf", 2.0), pool_seed=5),        # n < N <= 2n: single reduction
+    case("rbf_all_kept", 90, 3, 90, 100, K("rbf", 2.0), pool_seed=6),            # N <= n: everything returned
+    case("matern52_3e4_d32", 30_000, 32, 300, 200, K("matern52", 4.0), pool_seed=7),
+    case("matern32_8e3", 8_000, 5, 80, 50, K("matern32", 3.0, 2.0), pool_seed=8),
+    case("wsabil_2e4", 20_000, 10, 200, 100, K("rbf", 2.0, 1.0, posterior=POST_W, warp="wsabil"), pool_seed=9),
+    case("wsabim_1e4", 10_000, 6, 100, 50, K("rbf", 2.0, 1.0, posterior=POST, warp="wsabim"), pool_seed=10),
+    case("matern52_posterior", 9_000, 8, 90, 60, K("matern52", 3.0, 1.0, posterior=POST), pool_seed=13),
+    # BASELINE config 2: N=1e5, d=10, n=100, m=1e3.
+    case("cfg2_rbf_1e5", 100_000, 10, 1_000, 100, K("rbf", 2.0)),
+    # BASELINE config 3 / headline metric: N=1e6, d=10, n=100, m=1e4 (reference: ~2 min of CPU).
+    case("cfg3_rbf_1e6", 1_000_000, 10, 10_000, 100, K("rbf", 2.0), slow=True),
+    # BASELINE config 4: Matern-5/2, N=1e6, d=32, n=200, m=1e4.
+    case("cfg4_matern52_1e6_d32", 1_000_000, 32, 10_000, 200, K("matern52", 4.0), pool_seed=7, slow=True),
+    # BASELINE config 5: WSABI-L, N=5e5, d=10, n=100, m=5e3, n_obs=202.
+    case("cfg5_wsabil_5e5", 500_000, 10, 5_000, 100, K("rbf", 2.0, 1.0, posterior=POST_W, warp="wsabil"),
+         pool_seed=9, slow=True),
+]
+
+BY_NAME = {c["name"]: c for c in CASES}
+
+
+def build_pool(c):
+    """-> (pts_rec [N,d] f64 CPU, pts_nys = pts_rec[:m])  (prefix split: ``BASQ/_sampler.py:31-33``)."""
+    pts = gmm_pool(c["N"], c["d"], c["pool_seed"])
+    return pts, pts[: c["m"]]
+
+
+def build_obs(c):
+    p = c["kernel"]["posterior"]
+    if p is None:
+        return None
+    return gmm_pool(p["n_obs"], c["d"], p["obs_seed"])
+
+
+def build_oracle_kernel(c):
+    """The CPU callable handed to the reference / oracle for this case (and its GP state, if any)."""
+    from oracle.kernels_oracle import PosteriorOracle, StationaryOracle, WsabiOracle, synthetic_gp_state
+
+    k = c["kernel"]
+    base = StationaryOracle(k["family"], k["lengthscale"], k["outputscale"])
+    if k["posterior"] is None:
+        return base, None
+    Xobs = build_obs(c)
+    W, mean_const, mean_cache, _ = synthetic_gp_state(Xobs, base, k["posterior"]["noise"], k["posterior"]["obs_seed"])
+    state = dict(Xobs=Xobs, W=W, mean_const=mean_const, mean_cache=mean_cache, noise=k["posterior"]["noise"])
+    post = PosteriorOracle(base, Xobs, W, k["posterior"]["noise"])
+    if k["warp"] == "none":
+        return post, state
+    return WsabiOracle(post, mean_const, mean_cache, k["warp"]), state
+
+
+def seed_all(c):
+    torch.manual_seed(c["torch_seed"])
+
+
+def build_product_kernel(c, state=None):
+    """The structured ``basq_amd.kernels`` object equivalent to ``build_oracle_kernel(c)``."""
+    from basq_amd import kernels as BK
+
+    k = c["kernel"]
+    base = BK.StationaryKernel(k["family"], k["lengthscale"], k["outputscale"])
+    if k["posterior"] is None:
+        return base
+    if state is None:
+        _, state = build_oracle_kernel(c)
+    post = BK.PosteriorKernel(base, state["Xobs"], state["W"], state["noise"])
+    if k["warp"] == "none":
+        return post
+    return BK.WsabiKernel(post, state["mean_const"], state["mean_cache"], k["warp"])
+
+
+def load_golden(name):
+    import json
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".json")
+    with open(path) as f:
+        return json.load(f)
+
+
+def has_golden(name):
+    import os
+
+    return os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".json"))

@@ -1,0 +1,195 @@
+"""TEST-ONLY stand-in for ``basq_amd._ops.HipOps`` on the CPU.
+
+It exists so the ``-m "not gpu"`` suite can exercise the *host logic* of
+``basq_amd._engine`` (round geometry, sharding, offsets, collectives over gloo,
+extended operands for the posterior / WSABI kernels) where no GPU is present.
+It is never imported by the product (``basq_amd`` has no CPU path) and it says
+nothing about the HIP kernels: those are checked by the ``-m gpu`` tests.
+
+Each method restates, with plain torch ops, the contract documented for the
+corresponding entry point in ``include/basq_hip.h``.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+ROLE_A, ROLE_B = 0, 1
+
+
+class CpuStandInOps:
+    name = "cpu-stand-in"
+
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self.calls = {}
+
+    def _count(self, k):
+        self.calls[k] = self.calls.get(k, 0) + 1
+
+    def empty(self, *shape, dtype=torch.float64):
+        return torch.empty(*shape, dtype=dtype)
+
+    def zeros(self, *shape, dtype=torch.float64):
+        return torch.zeros(*shape, dtype=dtype)
+
+    def to_device(self, t, dtype=None):
+        return t.to(dtype=dtype or t.dtype).contiguous()
+
+    def kp(self, d):
+        return ((d + 2 + 3) // 4) * 4
+
+    def col_mean(self, X):
+        return X.mean(0)
+
+    def pack(self, spec, X, center, role, pad_rows_to=1):
+        n, d = X.shape
+        kp = self.kp(d)
+        rows = ((n + pad_rows_to - 1) // pad_rows_to) * pad_rows_to
+        out = torch.zeros(max(rows, 1), kp, dtype=torch.float64)
+        v = (X - (center if center is not None else 0.0)) * (1.0 / spec.lengthscale)
+        h = -0.5 * (v * v).sum(1)
+        out[:n, :d] = v
+        if role == ROLE_A:
+            out[:n, d] = h
+            out[:n, d + 1] = 1.0
+        else:
+            out[:n, d] = 1.0
+            out[:n, d + 1] = h
+        return out
+
+    @staticmethod
+    def _kfun(spec, D):
+        if spec.family == "rbf":
+            return torch.exp(D.clamp_max(0.0))
+        r2 = (-2.0 * D).clamp_min(1e-30)
+        r = r2.sqrt()
+        if spec.family == "matern52":
+            a = math.sqrt(5.0) * r
+            return ((a + 1.0) + (5.0 / 3.0) * r2) * torch.exp(-a)
+        a = math.sqrt(3.0) * r
+        return (a + 1.0) * torch.exp(-a)
+
+    def gram(self, spec, packA, na, packB, nb):
+        self._count("gram")
+        return spec.outputscale * self._kfun(spec, packA[:na] @ packB[:nb].T)
+
+    def matvec(self, spec, packA, na, packB, nb, v, bias):
+        self._count("matvec")
+        return bias + spec.outputscale * (self._kfun(spec, packA[:na] @ packB[:nb].T) @ v)
+
+    def blocksum(self, spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks):
+        self._count("blocksum")
+        Xpart = torch.zeros(n_chunks, m, S, dtype=torch.float64)
+        totpart = torch.zeros(n_chunks, S, dtype=torch.float64)
+        if Rl == 0:
+            return Xpart, totpart
+        pg = off + torch.arange(Rl)
+        sets = torch.where(pg < n_full, pg % S, torch.full_like(pg, S - 1))
+        # chunk assignment as documented: contiguous block ranges; tail -> last chunk
+        lim = min(off + Rl, n_full)
+        if lim > off:
+            blk_lo, blk_hi = off // S, (lim + S - 1) // S
+        else:
+            blk_lo = blk_hi = 0
+        per = max(1, -(-(blk_hi - blk_lo) // n_chunks))
+        chunk = torch.where(pg < n_full, (pg // S - blk_lo) // per, torch.full_like(pg, n_chunks - 1))
+        w = mu[:Rl] * (wx[:Rl] if wx is not None else 1.0)
+        flat = chunk * S + sets
+        Xf = torch.zeros(m, n_chunks * S, dtype=torch.float64)
+        step = 8192
+        for lo in range(0, Rl, step):                          # bounded temporaries
+            hi = min(Rl, lo + step)
+            Kw = self._kfun(spec, nys[:m] @ cand[lo:hi].T) * w[lo:hi].unsqueeze(0)
+            Xf.index_add_(1, flat[lo:hi], Kw)
+        Xpart = Xf.reshape(m, n_chunks, S).permute(1, 0, 2).contiguous()
+        tf = torch.zeros(n_chunks * S, dtype=torch.float64)
+        tf.index_add_(0, flat, mu[:Rl])
+        totpart = tf.reshape(n_chunks, S)
+        return Xpart, totpart
+
+    def project(self, U, q, m, Xpart, totpart, n_chunks, S, outputscale, ksplit=None):
+        self._count("project")
+        X = Xpart.sum(0)
+        return torch.cat([totpart.sum(0).unsqueeze(0), outputscale * (U @ X)], 0)
+
+    def finalize(self, parts, n_parts, msg_rows, q, S, diagU=None, ld_diag=0, n_diag=0, diag_noise=0.0, diag_wrow=0):
+        self._count("finalize")
+        msg = parts[0].clone()
+        for p in range(1, n_parts):
+            msg = msg + parts[p]
+        tot = msg[0].clone()
+        feat = msg[1:q + 1].clone()
+        if diagU is not None and n_diag > 0:
+            wgt = msg[diag_wrow]
+            feat[:, :n_diag] += diag_noise * wgt[:n_diag].unsqueeze(0) * diagU[:, :n_diag]
+        XcarT = torch.cat([torch.ones(1, S, dtype=torch.float64), feat / tot.unsqueeze(0)], 0)
+        return XcarT, tot
+
+    def car_eliminate(self, PhiT, mu, M, s):
+        self._count("car")
+        Phi = PhiT.T.clone()                                   # [M, M-s]
+        status = 0
+        for _ in range(M - s):
+            col = Phi[:, 0]
+            pos = col > 0
+            if not bool(pos.any()):
+                status = 1
+                break
+            alpha = torch.zeros(M, dtype=torch.float64)
+            alpha[pos] = mu[pos] / col[pos]
+            j = torch.arange(M)[pos][torch.argmin(alpha[pos])]
+            mu[:] = mu - alpha[j] * col
+            mu[j] = 0.0
+            Phi = Phi[:, 1:]
+            Phi = Phi - torch.matmul(Phi[j].unsqueeze(1), col.unsqueeze(1).T).T / col[j]
+            Phi[j, :] = 0.0
+        keep = mu > 0
+        n_keep = int(keep.sum())
+        keep_rank = torch.full((M,), -1, dtype=torch.int32)
+        keep_rank[keep] = torch.arange(n_keep, dtype=torch.int32)
+        kept = torch.zeros(max(s, 1), dtype=torch.int32)
+        kept[:n_keep] = torch.arange(M, dtype=torch.int32)[keep]
+        w_star = torch.zeros(max(s, 1), dtype=torch.float64)
+        w_star[:n_keep] = mu[keep]
+        info = torch.tensor([n_keep, status], dtype=torch.int32)
+        return keep_rank, kept, w_star, info
+
+    def reweight_compact(self, cand, mu, gid, wx, Rl, off, n_full, S, kp, keep_rank, w_star, tot, n_keep, new_off,
+                         new_Rl):
+        self._count("compact")
+        cand_o = torch.zeros(max(new_Rl, 1), kp, dtype=torch.float64)
+        mu_o = torch.zeros(max(new_Rl, 1), dtype=torch.float64)
+        gid_o = torch.zeros(max(new_Rl, 1), dtype=torch.int64)
+        wx_o = torch.zeros(max(new_Rl, 1), dtype=torch.float64) if wx is not None else None
+        if Rl == 0:
+            return cand_o, mu_o, gid_o, wx_o
+        pg = off + torch.arange(Rl)
+        inblk = pg < n_full
+        sets = torch.where(inblk, pg % S, torch.full_like(pg, S - 1))
+        kr = keep_rank.to(torch.int64)[sets]
+        dst = torch.where(inblk, (pg // S) * n_keep + kr, (n_full // S) * n_keep + (pg - n_full)) - new_off
+        sel = kr >= 0
+        d = dst[sel]
+        assert d.numel() == new_Rl and (d.numel() == 0 or (int(d.min()) == 0 and int(d.max()) == new_Rl - 1))
+        cand_o[d] = cand[:Rl][sel]
+        mu_o[d] = (mu[:Rl][sel] * w_star[kr[sel]]) / tot[sets[sel]]
+        gid_o[d] = gid[:Rl][sel]
+        if wx is not None:
+            wx_o[d] = wx[:Rl][sel]
+        return cand_o, mu_o, gid_o, wx_o
+
+    def init_state(self, Rl, gid0, n_total):
+        mu = torch.full((max(Rl, 1),), 1.0 / n_total, dtype=torch.float64)
+        gid = gid0 + torch.arange(max(Rl, 1), dtype=torch.int64)
+        return mu, gid
+
+    def matmul(self, A, B):
+        return torch.matmul(A, B)
+
+    def gemm(self, A, B, alpha=1.0):
+        return alpha * (A @ B)
+
+    def synchronize(self):
+        pass

@@ -1,0 +1,197 @@
+"""Unit parity of each HIP entry point (through ctypes / the C ABI) against plain torch on the CPU.
+
+The CPU side is ``tests/cpu_stand_in.py`` (contract restatement) and ``oracle/kernels_oracle.py``
+(gpytorch-style kernel values).  Integer/index outputs and the elimination (same op order as the
+reference) must match bit for bit; floating-point sums within 1e-12 relative.
+"""
+import pytest
+import torch
+
+from tests.cpu_stand_in import CpuStandInOps
+
+pytestmark = pytest.mark.gpu
+
+
+def _spec(family, d, ell=1.7, os_=1.3):
+    from basq_amd.kernels import StationaryKernel
+
+    return StationaryKernel(family, ell, os_).spec(d)
+
+
+def _rand(n, d, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, d, generator=g, dtype=torch.float64) * 1.5
+
+
+@pytest.mark.parametrize("family", ["rbf", "matern52", "matern32"])
+@pytest.mark.parametrize("d", [1, 2, 3, 7, 10, 14, 32, 38])
+def test_gram_vs_oracle(hip_ops, family, d):
+    from oracle.kernels_oracle import StationaryOracle
+
+    x, y = _rand(77, d, 1), _rand(131, d, 2)
+    spec = _spec(family, d)
+    c = hip_ops.col_mean(hip_ops.to_device(x))
+    pa = hip_ops.pack(spec, hip_ops.to_device(x), c, 0)
+    pb = hip_ops.pack(spec, hip_ops.to_device(y), c, 1)
+    K = hip_ops.gram(spec, pa, 77, pb, 131).cpu()
+    ref = StationaryOracle(family, spec.lengthscale, spec.outputscale)(x, y)
+    # values agree to fp64 round-off of the squared distance (absolute error ~1e-14 in the exponent)
+    assert (K - ref).abs().max().item() <= 5e-13 * ref.abs().max().item()
+
+
+def test_gram_extreme_distances(hip_ops):
+    """exp underflow region: far-apart points give 0 (not NaN/inf), identical points give outputscale."""
+    spec = _spec("rbf", 3, ell=0.01, os_=2.0)
+    x = torch.tensor([[0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [0.0, 0.0, 0.0]], dtype=torch.float64)
+    xd = hip_ops.to_device(x)
+    pa = hip_ops.pack(spec, xd, None, 0)
+    pb = hip_ops.pack(spec, xd, None, 1)
+    K = hip_ops.gram(spec, pa, 3, pb, 3).cpu()
+    assert torch.isfinite(K).all()
+    assert K[0, 0].item() == pytest.approx(2.0, rel=1e-14) and K[0, 2].item() == pytest.approx(2.0, rel=1e-14)
+    assert K[0, 1].item() < 1e-300
+
+
+@pytest.mark.parametrize("family,d,m,S,Rl,off,n_full,n_chunks,use_wx", [
+    ("rbf", 10, 100, 200, 5000, 0, 5000, 1, False),          # exact blocks
+    ("rbf", 10, 130, 200, 5077, 0, 5000, 3, False),          # tail + chunks, m not multiple of 64
+    ("rbf", 2, 50, 22, 1000, 0, 990, 2, True),               # S not multiple of 16, weights
+    ("matern52", 32, 64, 400, 3000, 0, 2800, 2, False),
+    ("matern32", 5, 33, 102, 777, 0, 714, 1, False),
+    ("rbf", 10, 100, 200, 2500, 1234, 5000, 2, False),       # a middle shard of a 2-rank split
+    ("rbf", 10, 100, 200, 1311, 3766, 5000, 2, True),        # the last shard: block part + tail
+    ("rbf", 3, 70, 150, 150, 0, 150, 1, False),              # final stage: one block, S = R
+    ("rbf", 3, 70, 40, 37, 4003, 4000, 1, False),            # shard holding only tail positions
+])
+def test_blocksum_vs_standin(hip_ops, family, d, m, S, Rl, off, n_full, n_chunks, use_wx):
+    cpu = CpuStandInOps()
+    spec = _spec(family, d)
+    nys, cand = _rand(m, d, 3), _rand(Rl, d, 4)
+    g = torch.Generator().manual_seed(5)
+    mu = torch.rand(Rl, generator=g, dtype=torch.float64) + 0.1
+    wx = (torch.rand(Rl, generator=g, dtype=torch.float64) + 0.5) if use_wx else None
+    center = nys.mean(0)
+    A_c = cpu.pack(spec, nys, center, 0, pad_rows_to=64)
+    B_c = cpu.pack(spec, cand, center, 1)
+    Xc, tc = cpu.blocksum(spec, A_c, m, B_c, mu, wx, Rl, off, n_full, S, n_chunks)
+    dev = hip_ops.to_device
+    A_g = hip_ops.pack(spec, dev(nys), dev(center), 0, pad_rows_to=64)
+    B_g = hip_ops.pack(spec, dev(cand), dev(center), 1)
+    Xg, tg = hip_ops.blocksum(spec, A_g, m, B_g, dev(mu), dev(wx) if use_wx else None, Rl, off, n_full, S, n_chunks)
+    Xg, tg = Xg.cpu(), tg.cpu()
+    scale = Xc.abs().max().item()
+    assert (Xg - Xc).abs().max().item() <= 1e-12 * scale
+    assert (tg - tc).abs().max().item() <= 1e-13 * tc.abs().max().item()
+
+
+def test_matvec_vs_standin(hip_ops):
+    cpu = CpuStandInOps()
+    spec = _spec("rbf", 10)
+    x, xo = _rand(1000, 10, 6), _rand(202, 10, 7)
+    v = _rand(202, 1, 8).reshape(-1)
+    center = x.mean(0)
+    ref = cpu.matvec(spec, cpu.pack(spec, x, center, 0), 1000, cpu.pack(spec, xo, center, 1), 202, v, 0.7)
+    dev = hip_ops.to_device
+    out = hip_ops.matvec(spec, hip_ops.pack(spec, dev(x), dev(center), 0, pad_rows_to=64), 1000,
+                         hip_ops.pack(spec, dev(xo), dev(center), 1), 202, dev(v), 0.7).cpu()
+    assert (out - ref).abs().max().item() <= 1e-12 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("q,m,S,n_chunks", [(99, 1000, 200, 1), (99, 1030, 200, 3), (9, 50, 20, 2), (199, 333, 400, 1),
+                                            (30, 77, 62, 1)])
+def test_project_finalize_vs_standin(hip_ops, q, m, S, n_chunks):
+    cpu = CpuStandInOps()
+    U = _rand(q, m, 9)
+    Xpart = _rand(n_chunks * m, S, 10).reshape(n_chunks, m, S)
+    totpart = _rand(n_chunks, S, 11).abs() + 0.2
+    ref = cpu.project(U, q, m, Xpart, totpart, n_chunks, S, 1.3)
+    dev = hip_ops.to_device
+    out = hip_ops.project(dev(U), q, m, dev(Xpart), dev(totpart), n_chunks, S, 1.3)
+    assert (out.cpu() - ref).abs().max().item() <= 1e-12 * ref.abs().max().item()
+    # finalize: 2 "ranks", diagonal-noise term on
+    parts_c = torch.stack([ref, 0.5 * ref])
+    Xc, tc = cpu.finalize(parts_c, 2, q + 1, q, S, U, m, min(m, S), 1e-3, 0)
+    Xg, tg = hip_ops.finalize(dev(parts_c), 2, q + 1, q, S, dev(U), m, min(m, S), 1e-3, 0)
+    assert (Xg.cpu() - Xc).abs().max().item() <= 1e-13 * Xc.abs().max().item()
+    assert torch.equal(tg.cpu(), tc)
+
+
+@pytest.mark.parametrize("M,s,seed", [(200, 100, 0), (200, 100, 1), (400, 200, 2), (150, 100, 3), (20, 10, 4),
+                                      (62, 31, 5), (101, 100, 6)])
+def test_car_eliminate_bit_exact(hip_ops, M, s, seed):
+    """Same null-space basis in -> same pivots, and bit-identical weights (reference op order)."""
+    cpu = CpuStandInOps()
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(s, M, generator=g, dtype=torch.float64)
+    X[0] = 1.0
+    Vh = torch.linalg.svd(X)[2]
+    PhiT = Vh[-(M - s):, :].contiguous()
+    mu = torch.rand(M, generator=g, dtype=torch.float64) + 0.05
+    mu = mu / mu.sum()
+    kr_c, kept_c, w_c, info_c = cpu.car_eliminate(PhiT.clone(), mu.clone(), M, s)
+    mu_g = hip_ops.to_device(mu.clone())
+    kr_g, kept_g, w_g, info_g = hip_ops.car_eliminate(hip_ops.to_device(PhiT.clone()), mu_g, M, s)
+    n = int(info_c[0])
+    assert info_g.cpu().tolist() == info_c.tolist()
+    assert torch.equal(kr_g.cpu(), kr_c)
+    assert torch.equal(kept_g.cpu()[:n], kept_c[:n])
+    assert torch.equal(w_g.cpu()[:n], w_c[:n])          # bit-exact
+    assert n <= s
+
+
+def test_car_eliminate_degenerate_flag(hip_ops):
+    """A null vector without a positive entry sets status=1 (the reference raises at _rchq.py:152)."""
+    M, s = 8, 4
+    PhiT = -torch.ones(M - s, M, dtype=torch.float64)
+    mu = torch.full((M,), 1.0 / M, dtype=torch.float64)
+    _, _, _, info = hip_ops.car_eliminate(hip_ops.to_device(PhiT), hip_ops.to_device(mu), M, s)
+    assert int(info.cpu()[1]) == 1
+
+
+@pytest.mark.parametrize("Rl,off,n_full,S,kept", [
+    (5000, 0, 5000, 200, list(range(0, 200, 2))),
+    (5077, 0, 5000, 200, list(range(1, 200, 2))),            # last set kept -> tail survives
+    (5077, 0, 5000, 200, list(range(0, 198, 2))),            # last set dropped
+    (2500, 1234, 5000, 200, [3, 4, 50, 199]),
+    (1311, 3766, 5000, 200, [0, 7, 199]),
+])
+def test_reweight_compact_vs_standin(hip_ops, Rl, off, n_full, S, kept):
+    from basq_amd._partition import RoundGeometry, next_shard
+
+    cpu = CpuStandInOps()
+    kp = 12
+    R = max(off + Rl, n_full)
+    geo = RoundGeometry(R, S, n_full // S, n_full, R - n_full)
+    new_off, new_Rl = next_shard(off, Rl, geo, kept)
+    g = torch.Generator().manual_seed(1)
+    cand = torch.randn(Rl, kp, generator=g, dtype=torch.float64)
+    mu = torch.rand(Rl, generator=g, dtype=torch.float64) + 0.1
+    wx = torch.rand(Rl, generator=g, dtype=torch.float64)
+    gid = torch.arange(Rl, dtype=torch.int64) * 3 + 7
+    keep_rank = torch.full((S,), -1, dtype=torch.int32)
+    keep_rank[torch.tensor(kept)] = torch.arange(len(kept), dtype=torch.int32)
+    w_star = torch.rand(len(kept), generator=g, dtype=torch.float64) + 0.1
+    tot = torch.rand(S, generator=g, dtype=torch.float64) + 0.5
+    ref = cpu.reweight_compact(cand, mu, gid, wx, Rl, off, n_full, S, kp, keep_rank, w_star, tot, len(kept), new_off, new_Rl)
+    dev = hip_ops.to_device
+    out = hip_ops.reweight_compact(dev(cand), dev(mu), dev(gid), dev(wx), Rl, off, n_full, S, kp, dev(keep_rank),
+                                   dev(w_star), dev(tot), len(kept), new_off, new_Rl)
+    for a, b in zip(out, ref):
+        assert torch.equal(a.cpu()[:new_Rl], b[:new_Rl])     # bit-exact (multiply, then divide)
+
+
+def test_gemm_f64(hip_ops):
+    A, B = _rand(300, 257, 12), _rand(257, 99, 13)
+    C = hip_ops.gemm(hip_ops.to_device(A), hip_ops.to_device(B), 0.5).cpu()
+    ref = 0.5 * (A @ B)
+    assert (C - ref).abs().max().item() <= 1e-12 * ref.abs().max().item()
+
+
+def test_no_cpu_path():
+    """The product refuses CPU devices instead of silently computing there."""
+    import basq_amd
+    from basq_amd._lib import BasqHipError
+
+    with pytest.raises(BasqHipError):
+        basq_amd.recombination(torch.zeros(10, 2), torch.zeros(5, 2), 3, basq_amd.kernels.StationaryKernel("rbf", 1.0),
+                               torch.device("cpu"))

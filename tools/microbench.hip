@@ -1,0 +1,71 @@
+// microbench.hip -- per-CU issue rates that bound the blocksum kernel on gfx950:
+//   v_fma_f64 (VALU fp64), v_mfma_f64_16x16x4_f64 (matrix fp64), and both together.
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/microbench tools/microbench.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+template <int MODE>   // 0 = fma only, 1 = mfma only, 2 = both interleaved (1 mfma : 20 fma)
+__global__ void __launch_bounds__(256) rate_kernel(double* out, int iters, double seed) {
+    double a0 = seed + threadIdx.x, a1 = a0 * 0.5, a2 = a0 * 0.25, a3 = a0 * 0.125;
+    double a4 = a0 + 1, a5 = a0 + 2, a6 = a0 + 3, a7 = a0 + 4;
+    const double m = 0.999999, c = 1e-9;
+    d4 D0 = {0, 0, 0, 0}, D1 = {0, 0, 0, 0}, D2 = {0, 0, 0, 0}, D3 = {0, 0, 0, 0};
+    const double pa = seed * 1e-3, pb = seed * 2e-3;
+    for (int i = 0; i < iters; ++i) {
+        if (MODE == 0 || MODE == 2) {
+#pragma unroll
+            for (int u = 0; u < (MODE == 2 ? 10 : 16); ++u) {
+                a0 = __builtin_fma(a0, m, c); a1 = __builtin_fma(a1, m, c); a2 = __builtin_fma(a2, m, c); a3 = __builtin_fma(a3, m, c);
+                a4 = __builtin_fma(a4, m, c); a5 = __builtin_fma(a5, m, c); a6 = __builtin_fma(a6, m, c); a7 = __builtin_fma(a7, m, c);
+            }
+        }
+        if (MODE == 1 || MODE == 2) {
+            D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, D0, 0, 0, 0);
+            D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, D1, 0, 0, 0);
+            D2 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, D2, 0, 0, 0);
+            D3 = __builtin_amdgcn_mfma_f64_16x16x4f64(pa, pb, D3, 0, 0, 0);
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + D0[0] + D1[1] + D2[2] + D3[3];
+}
+
+template <int MODE>
+static void run(const char* name, int waves_per_simd, double fma_per_iter, double mfma_per_iter) {
+    const int blocks = 256 * waves_per_simd;   // 256 CUs x (4 waves = 1 per SIMD) per block
+    const int iters = 20000;
+    double* out;
+    hipMalloc(&out, (size_t)blocks * 256 * 8);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(rate_kernel<MODE>, dim3(blocks), dim3(256), 0, 0, out, 100, 1.0);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(rate_kernel<MODE>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double waves = (double)blocks * 4;
+    const double fma = waves * iters * fma_per_iter;      // wave-level instructions
+    const double mfma = waves * iters * mfma_per_iter;
+    const double tf_valu = fma * 64 * 2 / (ms * 1e-3) / 1e12;
+    const double tf_mfma = mfma * 2048 / (ms * 1e-3) / 1e12;
+    // cycles per wave-instruction per SIMD at 2.4 GHz nominal
+    const double simd_cycles = ms * 1e-3 * 2.4e9;
+    printf("%-22s waves/SIMD=%d  %8.3f ms  VALU %7.2f TF/s (%.2f cyc/fma/SIMD)  MFMA %7.2f TF/s (%.1f cyc/mfma/SIMD)\n", name,
+           waves_per_simd, ms, tf_valu, fma > 0 ? simd_cycles / (fma / 1024.0) : 0.0, tf_mfma,
+           mfma > 0 ? simd_cycles / (mfma / 1024.0) : 0.0);
+    hipFree(out);
+}
+
+int main() {
+    hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+    printf("device: %s  CUs=%d  clock=%d kHz\n", p.name, p.multiProcessorCount, p.clockRate);
+    for (int w = 1; w <= 4; w *= 2) {
+        run<0>("fma_f64 only", w, 128, 0);
+        run<1>("mfma_f64 16x16x4 only", w, 0, 4);
+        run<2>("both (80 fma : 4 mfma)", w, 80, 4);
+    }
+    return 0;
+}
