@@ -78,14 +78,61 @@ class EngineTrace:
     U: torch.Tensor | None = None
     timers: dict = field(default_factory=dict)
     keep_tensors: bool = False
+    time_kernels: bool = False                      # record HIP events around every block-sum launch
+    kernel_events: list = field(default_factory=list)   # (start_evt, end_evt, dict(pairs=, R=, m=, S=))
+    host_sync: bool = True                          # synchronise around phases to attribute host timers
 
     def add_time(self, key, dt):
         self.timers[key] = self.timers.get(key, 0.0) + dt
 
 
-def _host_qr_q(ops, X):
+class _Timer:
+    """Host timer feeding ``EngineTrace.timers`` (synchronising only when the trace asks for it)."""
+
+    def __init__(self, ops, trace, key):
+        self.ops, self.trace, self.key = ops, trace, key
+
+    def __enter__(self):
+        if self.trace is not None:
+            if self.trace.host_sync:
+                self.ops.synchronize()
+            self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        if self.trace is not None:
+            if self.trace.host_sync:
+                self.ops.synchronize()
+            self.trace.add_time(self.key, time.perf_counter() - self.t0)
+        return False
+
+
+# Host LAPACK calls on small matrices (100 x 200 SVD, 1e4 x 99 QR) are slower, not faster, on a many-core
+# host with every core in the team (measured: 30 ms per 100x200 gesdd with 128 threads vs ~2 ms with 8).
+HOST_LAPACK_THREADS = 8
+
+
+class _lapack_threads:
+    def __enter__(self):
+        self.prev = torch.get_num_threads()
+        if self.prev > HOST_LAPACK_THREADS:
+            torch.set_num_threads(HOST_LAPACK_THREADS)
+        return self
+
+    def __exit__(self, *exc):
+        if torch.get_num_threads() != self.prev:
+            torch.set_num_threads(self.prev)
+        return False
+
+
+def _host_qr_q(ops, X, trace=None):
     """Q factor by host LAPACK (geqrf/orgqr), as ``torch.linalg.qr(X).Q`` on a CPU tensor."""
-    return ops.to_device(torch.linalg.qr(X.cpu()).Q)
+    with _Timer(ops, trace, "basis.d2h"):
+        Xh = X.cpu()
+    with _Timer(ops, trace, "basis.host_qr"), _lapack_threads():
+        Qh = torch.linalg.qr(Xh).Q
+    with _Timer(ops, trace, "basis.h2d"):
+        return ops.to_device(Qh)
 
 
 def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None):
@@ -96,16 +143,28 @@ def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None):
     ``torch.randn(m, q)`` from the CPU global generator.
     """
     m = A.shape[0]
-    R = torch.randn(m, q_req, dtype=torch.float64)           # CPU generator (reference: A is a CPU tensor)
+    with _Timer(ops, trace, "basis.randn"):
+        R = ops.to_device(torch.randn(m, q_req, dtype=torch.float64))   # CPU generator (reference: CPU tensor A)
     At = A.t()
-    Q = _host_qr_q(ops, ops.matmul(A, ops.to_device(R)))
+    with _Timer(ops, trace, "basis.gemm"):
+        X = ops.matmul(A, R)
+    Q = _host_qr_q(ops, X, trace)
     for _ in range(2):
-        Q = _host_qr_q(ops, ops.matmul(At, Q))
-        Q = _host_qr_q(ops, ops.matmul(A, Q))
-    B = ops.matmul(Q.t(), A)                                   # [k, m]
-    Ub, _, _ = torch.linalg.svd(B.cpu(), full_matrices=False)
-    U = ops.matmul(Q, ops.to_device(Ub))                       # [m, k]
-    return (-1 * U.t()).contiguous()                           # :30
+        with _Timer(ops, trace, "basis.gemm"):
+            X = ops.matmul(At, Q)
+        Q = _host_qr_q(ops, X, trace)
+        with _Timer(ops, trace, "basis.gemm"):
+            X = ops.matmul(A, Q)
+        Q = _host_qr_q(ops, X, trace)
+    with _Timer(ops, trace, "basis.gemm"):
+        B = ops.matmul(Q.t(), A)                               # [k, m]
+    with _Timer(ops, trace, "basis.d2h"):
+        Bh = B.cpu()
+    with _Timer(ops, trace, "basis.host_svd"), _lapack_threads():
+        Ub, _, _ = torch.linalg.svd(Bh, full_matrices=False)
+    with _Timer(ops, trace, "basis.gemm"):
+        U = ops.matmul(Q, ops.to_device(Ub))                   # [m, k]
+        return (-1 * U.t()).contiguous()                       # :30
 
 
 class RecombinationEngine:
@@ -138,7 +197,8 @@ class RecombinationEngine:
         # ---- Nystrom basis: rank 0 computes, everyone receives (one randn draw, as in the reference) ----
         t0 = time.perf_counter()
         if comm.rank == 0:
-            A = kernel.dense(ops, pts_nys, pts_nys, center)
+            with _Timer(ops, trace, "basis.gram"):
+                A = kernel.dense(ops, pts_nys, pts_nys, center)
             U = nystrom_basis(ops, A, num_pts - 1, trace)
             del A
             qbuf = torch.tensor([U.shape[0]], dtype=torch.int64, device=U.device)
@@ -153,7 +213,8 @@ class RecombinationEngine:
         s = q + 1
         S = 2 * s                                               # :50
         if trace is not None:
-            ops.synchronize()
+            if trace.host_sync:
+                ops.synchronize()
             trace.add_time("basis", time.perf_counter() - t0)
             if trace.keep_tensors:
                 trace.U = U.clone()
@@ -207,7 +268,8 @@ class RecombinationEngine:
             wx = kernel.mean(ops, pts_local, center) if Rl > 0 else ops.empty(1)
         off, R = gid0, n_total
         if trace is not None:
-            ops.synchronize()
+            if trace.host_sync:
+                ops.synchronize()
             trace.add_time("setup", time.perf_counter() - t0)
 
         # ---- rounds -------------------------------------------------------------------------------------
@@ -222,10 +284,17 @@ class RecombinationEngine:
             geo = RoundGeometry.of(R, S_r)
             t0 = time.perf_counter()
             n_chunks = choose_chunks(local_blocks(off, Rl, geo), m_ext, S_r)
-            Xpart, totpart = ops.blocksum(spec, nys_ext, m_ext, cand, mu, wx, Rl, off, geo.n_full, S_r, n_chunks)
-            msg = ops.project(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S_r, spec.outputscale)
+            ev0 = ops.record_event() if (trace is not None and trace.time_kernels) else None
+            with _Timer(ops, trace, "blocksum"):
+                Xpart, totpart = ops.blocksum(spec, nys_ext, m_ext, cand, mu, wx, Rl, off, geo.n_full, S_r, n_chunks)
+            if ev0 is not None:
+                trace.kernel_events.append((ev0, ops.record_event(), dict(pairs=float(Rl) * m_ext, R=Rl, m=m_ext, S=S_r,
+                                                                         chunks=n_chunks)))
+            with _Timer(ops, trace, "project"):
+                msg = ops.project(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S_r, spec.outputscale)
             if trace is not None:
-                ops.synchronize()
+                if trace.host_sync:
+                    ops.synchronize()
                 trace.add_time("blocksum+project", time.perf_counter() - t0)
                 t0 = time.perf_counter()
             parts = comm.all_gather(msg) if comm.world > 1 else msg.unsqueeze(0)
@@ -234,12 +303,15 @@ class RecombinationEngine:
             if comm.rank == 0:
                 XcarT, tot = ops.finalize(parts, comm.world, q_ext + 1, q, S_r, diagU, m, min(m, S_r), diag_noise, wrow)
                 t1 = time.perf_counter()
-                Vh = torch.linalg.svd(XcarT.cpu())[2]            # :140 full SVD of [s, M] on host LAPACK
+                Xh = XcarT.cpu()
+                with _lapack_threads():
+                    Vh = torch.linalg.svd(Xh)[2]                 # :140 full SVD of [s, M] on host LAPACK
                 PhiT = ops.to_device(Vh[-(M - s):, :])           # :143 (rows = null-space vectors)
                 if trace is not None:
                     trace.add_time("host_svd", time.perf_counter() - t1)
                 mu_car = tot.clone()
-                keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, mu_car, M, s)
+                with _Timer(ops, trace, "eliminate"):
+                    keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, mu_car, M, s)
                 res[0:2] = info.to(torch.float64)
                 res[2:2 + s] = kept.to(torch.float64)
                 res[2 + s:2 + 2 * s] = w_star
@@ -257,7 +329,8 @@ class RecombinationEngine:
             keep_rank = res[2 + 2 * s:2 + 2 * s + M].to(torch.int32)
             tot = res[2 + 2 * s + M:].contiguous()
             if trace is not None:
-                ops.synchronize()
+                if trace.host_sync:
+                    ops.synchronize()
                 trace.add_time("reduce", time.perf_counter() - t0)
                 rec = dict(R=R, S=S_r, nb=geo.nb, n_tail=geo.n_tail, kept=kept_list)
                 if trace.keep_tensors:
@@ -278,10 +351,12 @@ class RecombinationEngine:
             R = survivors_before(R, geo, kept_list)
             off, Rl = new_off, new_Rl
             if trace is not None:
-                ops.synchronize()
+                if trace.host_sync:
+                    ops.synchronize()
                 trace.add_time("compact", time.perf_counter() - t0)
         if trace is not None:
-            ops.synchronize()
+            if trace.host_sync:
+                ops.synchronize()
             trace.add_time("total", time.perf_counter() - t_all)
         return idx, w
 

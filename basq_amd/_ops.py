@@ -102,7 +102,7 @@ class HipOps:
                                               _ptr(out), self._stream()), "basq_kernel_matvec_f64")
         return out
 
-    def blocksum(self, spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks):
+    def blocksum(self, spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, impl="valu"):
         Xpart = self.empty(n_chunks, m, S)
         totpart = self.empty(n_chunks, S)
         if Rl == 0:
@@ -110,8 +110,9 @@ class HipOps:
             totpart.zero_()
             return Xpart, totpart
         sc = self.spec_c(spec)
-        check(self.lib.basq_blocksum_f64(C.byref(sc), _ptr(nys), m, _ptr(cand), _ptr(mu), _ptr(wx), Rl, off, n_full, S,
-                                         n_chunks, _ptr(Xpart), _ptr(totpart), self._stream()), "basq_blocksum_f64")
+        fn = self.lib.basq_blocksum_f64 if impl == "valu" else self.lib.basq_blocksum_mfma_f64
+        check(fn(C.byref(sc), _ptr(nys), m, _ptr(cand), _ptr(mu), _ptr(wx), Rl, off, n_full, S, n_chunks, _ptr(Xpart),
+                 _ptr(totpart), self._stream()), "basq_blocksum_f64")
         return Xpart, totpart
 
     def project(self, U, q, m, Xpart, totpart, n_chunks, S, outputscale, ksplit=None):
@@ -182,3 +183,9 @@ class HipOps:
 
     def synchronize(self):
         torch.cuda.current_stream(self.device).synchronize()
+
+    def record_event(self):
+        """HIP event recorded on the stream the kernels are launched on (torch's current stream)."""
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(self.device))
+        return ev

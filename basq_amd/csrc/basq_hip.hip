@@ -24,10 +24,10 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // ------------------------------------------------------------------------------------------------
 // fp64 exp for arguments <= 0 (every kernel family evaluates exp of a non-positive number).
 // x = n ln2 + r, |r| <= ln2/2; degree-10 polynomial (2.9e-16 rel. before rounding); 2^n applied by an
-// integer add on the exponent field.  Arguments below -708 are clamped (result ~3e-308 instead of 0).
+// integer add on the exponent field; arguments below about -708 return (almost exactly) 0.  Valid for
+// -1.4e9 < x <= ~1 (the callers pass minus a scaled squared distance or minus a scaled distance).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double exp_nonpos(double x) {
-    x = fmax(x, -708.0);
     const double MAGIC = 0x1.8p52;
     const double t = __builtin_fma(x, BASQ_LOG2E, MAGIC);
     const double nf = t - MAGIC;
@@ -45,7 +45,45 @@ __device__ __forceinline__ double exp_nonpos(double x) {
     p = __builtin_fma(p, r, BASQ_EXP_P1);
     p = __builtin_fma(p, r, BASQ_EXP_P0);
     const int n = __double2loint(t);               // low word of t holds n (two's complement)
-    const int hi = __double2hiint(p) + (n << 20);  // p * 2^n, p in [0.70, 1.42], n >= -1022
+    int hi = __double2hiint(p) + (n << 20);        // p * 2^n, p in [0.70, 1.42]
+    hi = (n < -1021) ? 0 : hi;                     // underflow: return ~0 (a denormal <= 2^-1042)
+    return __hiloint2double(hi, __double2loint(p));
+}
+
+// The same evaluation with every constant held in a VGPR (one copy per lane).  The blocksum kernel keeps
+// two candidate rows (2 x 26 SGPRs at d=10) in scalar registers; the 15 fp64 literals of exp would
+// otherwise claim 30 more SGPRs and push the rows into v_writelane spills.
+struct ExpK {
+    double log2e, nln2hi, nln2lo, magic, p[11];
+};
+
+__device__ __forceinline__ double vgpr_const(double x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+__device__ __forceinline__ void expk_init(ExpK& k) {
+    k.log2e = vgpr_const(BASQ_LOG2E);
+    k.nln2hi = vgpr_const(-BASQ_LN2_HI);
+    k.nln2lo = vgpr_const(-BASQ_LN2_LO);
+    k.magic = vgpr_const(0x1.8p52);
+    const double c[11] = {BASQ_EXP_P0, BASQ_EXP_P1, BASQ_EXP_P2, BASQ_EXP_P3, BASQ_EXP_P4, BASQ_EXP_P5,
+                          BASQ_EXP_P6, BASQ_EXP_P7, BASQ_EXP_P8, BASQ_EXP_P9, BASQ_EXP_P10};
+#pragma unroll
+    for (int i = 0; i < 11; ++i) k.p[i] = vgpr_const(c[i]);
+}
+
+__device__ __forceinline__ double exp_nonpos_k(double x, const ExpK& k) {
+    const double t = __builtin_fma(x, k.log2e, k.magic);
+    const double nf = t - k.magic;
+    double r = __builtin_fma(nf, k.nln2hi, x);
+    r = __builtin_fma(nf, k.nln2lo, r);
+    double p = k.p[10];
+#pragma unroll
+    for (int i = 9; i >= 0; --i) p = __builtin_fma(p, r, k.p[i]);
+    const int n = __double2loint(t);
+    int hi = __double2hiint(p) + (n << 20);
+    hi = (n < -1021) ? 0 : hi;
     return __hiloint2double(hi, __double2loint(p));
 }
 
@@ -53,7 +91,7 @@ __device__ __forceinline__ double exp_nonpos(double x) {
 template <int FAM>
 __device__ __forceinline__ double kernel_from_arg(double D) {
     if (FAM == BASQ_FAMILY_RBF) {
-        return exp_nonpos(fmin(D, 0.0));           // clamp: squared distance >= 0
+        return exp_nonpos(D);                      // D <= ~1e-14: no clamp needed for exp
     } else {
         const double r2 = fmax(-2.0 * D, 1e-30);   // gpytorch: clamp_min(1e-30) before sqrt
         const double r = sqrt(r2);
@@ -64,6 +102,24 @@ __device__ __forceinline__ double kernel_from_arg(double D) {
         } else {
             const double a = 0x1.bb67ae8584caap+0 * r;   // sqrt(3) r
             return (a + 1.0) * exp_nonpos(-a);
+        }
+    }
+}
+
+template <int FAM>
+__device__ __forceinline__ double kernel_from_arg_k(double D, const ExpK& k) {
+    if (FAM == BASQ_FAMILY_RBF) {
+        return exp_nonpos_k(D, k);
+    } else {
+        const double r2 = fmax(-2.0 * D, 1e-30);
+        const double r = sqrt(r2);
+        if (FAM == BASQ_FAMILY_MATERN52) {
+            const double a = 0x1.1e3779b97f4a8p+1 * r;
+            const double poly = (a + 1.0) + (5.0 / 3.0) * r2;
+            return poly * exp_nonpos_k(-a, k);
+        } else {
+            const double a = 0x1.bb67ae8584caap+0 * r;
+            return (a + 1.0) * exp_nonpos_k(-a, k);
         }
     }
 }
@@ -112,9 +168,9 @@ __global__ void pack_points_kernel(const double* __restrict__ X, long long n, in
         h = __builtin_fma(v, v, h);
     }
     h *= -0.5;
-    o[d] = (role == BASQ_ROLE_A) ? h : 1.0;
-    o[d + 1] = (role == BASQ_ROLE_A) ? 1.0 : h;
-    for (int k = d + 2; k < kp; ++k) o[k] = 0.0;
+    for (int k = d; k < kp - 2; ++k) o[k] = 0.0;
+    o[kp - 2] = (role == BASQ_ROLE_A) ? h : 1.0;
+    o[kp - 1] = (role == BASQ_ROLE_A) ? 1.0 : h;
 }
 
 __global__ void init_state_kernel(double* __restrict__ mu, long long* __restrict__ gid, long long Rl, long long gid0,
@@ -126,7 +182,8 @@ __global__ void init_state_kernel(double* __restrict__ mu, long long* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fused block sums (BASQ/_rchq.py:79-99).  One wave owns a 64 x 16 tile of (Nystrom rows x sets):
+// Fused block sums, MFMA form (kept for A/B measurement only: basq_blocksum_mfma_f64; see the VALU form
+// below for why it is not the shipped one).  One wave owns a 64 x 16 tile of (Nystrom rows x sets):
 // the A fragments of its 64 rows stay in registers for the whole launch; every iteration streams
 // the 16 candidates of one block that fall in the wave's 16 sets (B fragments), issues
 // JT*KK MFMAs for the exponent arguments and evaluates 16 kernel values per lane on the VALU.
@@ -296,6 +353,260 @@ static int dispatch_blocksum(int kk, int fam, const BlocksumArgs& A, hipStream_t
         case 8: return dispatch_blocksum_fam<8>(fam, A, st);
         case 9: return dispatch_blocksum_fam<9>(fam, A, st);
         case 10: return dispatch_blocksum_fam<10>(fam, A, st);
+    }
+    return BASQ_EUNSUPPORTED;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused block sums, VALU form (the shipped one).  Measured on MI355X (profiles/r01_microbench_*):
+// v_mfma_f64_16x16x4 issues at ~100 cycles and shares the fp64 datapath with v_fma_f64 (~4.5 cycles);
+// per flop the matrix path is ~1.4x SLOWER than plain FMAs and does not overlap with them, so the
+// exponent argument is built with d FMAs per pair instead.
+//
+// One lane owns one Nystrom row j (its packed row lives in VGPRs for the whole launch); the candidates
+// are wave-uniform, so their rows arrive through the scalar cache (s_load) and feed the FMAs as SGPR
+// operands: no LDS, no VGPRs, no cross-lane traffic.  A wave covers ST consecutive sets of every block
+// of its chunk and keeps ST accumulators per lane.
+// ------------------------------------------------------------------------------------------------
+// One candidate, wave-uniform: KK tuples of 8 SGPRs (4 doubles each) + its weight(s).  The loads are
+// explicit s_load_dwordx8 with immediate offsets (hipcc's own choice was to load all ST rows up front and
+// spill them to VGPR lanes); per cdna_hip_programming.md §5.7 the destination registers are not touched by
+// compiler code until row_wait() has named them ("+s") behind the s_waitcnt.
+template <int KK>
+struct CandRow {
+    d4 v[KK];
+    double w;    // mu
+    double x;    // wx (only loaded when HAS_WX)
+};
+
+// T = candidate index relative to the base pointers (compile-time -> immediate offsets).
+template <int KK, int T, bool HAS_WX>
+__device__ __forceinline__ void row_issue(CandRow<KK>& r, const double* cand_base, const double* mu_base,
+                                          const double* wx_base) {
+#pragma unroll
+    for (int k = 0; k < KK; ++k)
+        asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(r.v[k]) : "s"(cand_base), "i"(T * KK * 32 + k * 32) : "memory");
+    asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(r.w) : "s"(mu_base), "i"(T * 8) : "memory");
+    if (HAS_WX) asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(r.x) : "s"(wx_base), "i"(T * 8) : "memory");
+}
+
+template <int KK, bool HAS_WX>
+__device__ __forceinline__ void row_wait(CandRow<KK>& r) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < KK; ++k) asm volatile("" : "+s"(r.v[k]));
+    asm volatile("" : "+s"(r.w));
+    if (HAS_WX) asm volatile("" : "+s"(r.x));
+}
+
+template <int KK, int FAM, bool HAS_WX>
+__device__ __forceinline__ double pair_term(const double (&pt)[KK * 4 - 2], double hj, double onej,
+                                            const CandRow<KK>& r, const ExpK& ek, double acc) {
+    constexpr int KP = KK * 4, DIMS = KP - 2;
+    double D = __builtin_fma(onej, r.v[KK - 1][3], hj);   // h_j + h_x  (onej = 1; 0 for the "all-ones" pseudo row)
+#pragma unroll
+    for (int k = 0; k < DIMS; ++k) D = __builtin_fma(pt[k], r.v[k >> 2][k & 3], D);
+    double e = kernel_from_arg_k<FAM>(D, ek);
+    if (HAS_WX) e *= r.x;
+    return __builtin_fma(e, r.w, acc);
+}
+
+// Fast path: ST consecutive candidates, all present.  Two rows live in SGPRs: the scalar loads of
+// candidate t+1 are in flight during the ~30 VALU instructions of candidate t.
+template <int KK, int FAM, int ST, bool HAS_WX, int T>
+struct BlockStep {
+    static __device__ __forceinline__ void run(const double (&pt)[KK * 4 - 2], double hj, double onej, const ExpK& ek,
+                                               CandRow<KK> (&rows)[2], const double* cb, const double* mb,
+                                               const double* xb, double (&acc)[ST]) {
+        row_wait<KK, HAS_WX>(rows[T & 1]);
+        if (T + 1 < ST) row_issue<KK, T + 1, HAS_WX>(rows[(T + 1) & 1], cb, mb, xb);
+        acc[T] = pair_term<KK, FAM, HAS_WX>(pt, hj, onej, rows[T & 1], ek, acc[T]);
+        BlockStep<KK, FAM, ST, HAS_WX, T + 1>::run(pt, hj, onej, ek, rows, cb, mb, xb, acc);
+    }
+};
+template <int KK, int FAM, int ST, bool HAS_WX>
+struct BlockStep<KK, FAM, ST, HAS_WX, ST> {
+    static __device__ __forceinline__ void run(const double (&)[KK * 4 - 2], double, double, const ExpK&,
+                                               CandRow<KK> (&)[2], const double*, const double*, const double*,
+                                               double (&)[ST]) {}
+};
+
+template <int KK, int FAM, int ST, bool HAS_WX>
+__global__ void __launch_bounds__(256)
+blocksum_valu_kernel(const double* __restrict__ nys, const double* __restrict__ cand, const double* __restrict__ mu,
+                     const double* __restrict__ wx, double* __restrict__ Xpart, long long Rl, long long off,
+                     long long n_full, long long blk_lo, long long blk_hi, long long blk_per_chunk, int m, int S,
+                     int n_chunks, int n_stiles) {
+    constexpr int KP = KK * 4, DIMS = KP - 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int b = blockIdx.x;
+    const int st = b % n_stiles;
+    b /= n_stiles;
+    const int chunk = b % n_chunks;
+    const int jg = b / n_chunks;
+    const int jw = (jg * 4 + wave) * 64;
+    if (jw >= m) return;                       // wave-uniform; no barriers in this kernel
+    const int j = jw + lane;                   // rows are padded to a multiple of 64: always in bounds
+    double pt[DIMS];
+#pragma unroll
+    for (int k = 0; k < DIMS; ++k) pt[k] = nys[(long long)j * KP + k];
+    const double hj = nys[(long long)j * KP + KP - 2];
+    const double onej = nys[(long long)j * KP + KP - 1];
+
+    double acc[ST];
+#pragma unroll
+    for (int t = 0; t < ST; ++t) acc[t] = 0.0;
+    ExpK ek;
+    expk_init(ek);
+
+    const int s0 = st * ST;
+    const int nset = (S - s0 < ST) ? (S - s0) : ST;                 // sets handled by this wave (uniform)
+    // local positions fit 32 bits (the pool is < 2^31 candidates)
+    const int lim = (int)(((off + Rl < n_full) ? (off + Rl) : n_full) - off);   // local end of block positions
+    long long bA = blk_lo + (long long)chunk * blk_per_chunk;
+    long long bB = bA + blk_per_chunk;
+    if (bB > blk_hi) bB = blk_hi;
+
+    // L2 warm-up.  The scalar path has no prefetcher and a candidate row is used once per wave, so an
+    // un-warmed s_load pays the full HBM latency (~750 cycles measured per candidate, 4 lockstep waves per
+    // block cannot hide it).  One vector load per lane touches the 128-B lines of the rows PF blocks ahead;
+    // its (dummy) result is waited for one block later, when it has long landed.
+    constexpr int PF = 2;
+    constexpr int ROW_LINES = (ST * KP * 8 + 127) / 128 + 1;         // lines spanned by ST packed rows (+1: alignment)
+    float pf_dummy = 0.f;
+    for (long long i = bA; i < bB; ++i) {
+        const long long base = i * S + s0 - off;                    // local position of set s0 in block i
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_dummy) : : "memory");
+        {
+            const long long pbase = base + (long long)PF * S;
+            if (i + PF < bB && pbase >= 0 && pbase + ST <= lim) {
+                const char* line = (const char*)(cand + pbase * KP) + lane * 128;
+                const char* mline = (const char*)(mu + pbase) + (lane - ROW_LINES) * 128;
+                const char* a = (lane < ROW_LINES) ? line : mline;
+                const char* last = (lane < ROW_LINES) ? (const char*)(cand + Rl * KP) - 4 : (const char*)(mu + Rl) - 4;
+                a = (a < last) ? a : last;
+                if (lane < ROW_LINES + (ST * 8 + 127) / 128 + 1)
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(pf_dummy) : "v"(a) : "memory");
+            }
+        }
+        if (nset == ST && base >= 0 && base + ST <= lim) {
+            CandRow<KK> rows[2];
+            const double* cb = cand + base * KP;
+            const double* mb = mu + base;
+            const double* xb = HAS_WX ? (wx + base) : mu;
+            row_issue<KK, 0, HAS_WX>(rows[0], cb, mb, xb);
+            BlockStep<KK, FAM, ST, HAS_WX, 0>::run(pt, hj, onej, ek, rows, cb, mb, xb, acc);
+        } else {
+            // shard edges / ragged last set tile: candidate by candidate, wave-uniform branches
+#pragma unroll
+            for (int t = 0; t < ST; ++t) {
+                const long long pl = base + t;
+                if (t < nset && pl >= 0 && pl < lim) {
+                    CandRow<KK> r;
+                    row_issue<KK, 0, HAS_WX>(r, cand + pl * KP, mu + pl, HAS_WX ? (wx + pl) : mu);
+                    row_wait<KK, HAS_WX>(r);
+                    acc[t] = pair_term<KK, FAM, HAS_WX>(pt, hj, onej, r, ek, acc[t]);
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_dummy) : : "memory");
+
+    // Ragged tail (BASQ/_rchq.py:91-99): every local position >= n_full belongs to set S-1.
+    const long long t0 = (n_full > off) ? (n_full - off) : 0;
+    const int tl = (S - 1) - s0;
+    if (chunk == n_chunks - 1 && tl >= 0 && tl < ST && t0 < Rl) {
+        double ta = 0.0;
+        for (long long pl = t0; pl < Rl; ++pl) {
+            CandRow<KK> r;
+            row_issue<KK, 0, HAS_WX>(r, cand + pl * KP, mu + pl, HAS_WX ? (wx + pl) : mu);
+            row_wait<KK, HAS_WX>(r);
+            ta = pair_term<KK, FAM, HAS_WX>(pt, hj, onej, r, ek, ta);
+        }
+#pragma unroll
+        for (int t = 0; t < ST; ++t)
+            if (t == tl) acc[t] += ta;
+    }
+
+    if (j < m) {
+        double* out = Xpart + ((long long)chunk * m + j) * S + s0;
+#pragma unroll
+        for (int t = 0; t < ST; ++t)
+            if (t < nset) out[t] = acc[t];
+    }
+}
+
+// totpart[chunk][s] = sum of mu over the chunk's candidates of set s (BASQ/_rchq.py:90, :99); block order.
+__global__ void setsum_kernel(const double* __restrict__ mu, double* __restrict__ totpart, long long Rl, long long off,
+                              long long n_full, long long blk_lo, long long blk_hi, long long blk_per_chunk, int S,
+                              int n_chunks) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_chunks * S) return;
+    const int chunk = idx / S, s = idx % S;
+    const long long lim = ((off + Rl < n_full) ? (off + Rl) : n_full) - off;
+    long long bA = blk_lo + (long long)chunk * blk_per_chunk;
+    long long bB = bA + blk_per_chunk;
+    if (bB > blk_hi) bB = blk_hi;
+    double tot = 0.0;
+    for (long long i = bA; i < bB; ++i) {
+        const long long pl = i * S + s - off;
+        if (pl >= 0 && pl < lim) tot += mu[pl];
+    }
+    if (chunk == n_chunks - 1 && s == S - 1) {
+        const long long t0 = (n_full > off) ? (n_full - off) : 0;
+        for (long long pl = t0; pl < Rl; ++pl) tot += mu[pl];
+    }
+    totpart[idx] = tot;
+}
+
+#define BASQ_ST 20
+
+template <int KK, int FAM>
+static int launch_blocksum_valu(const BlocksumArgs& A, hipStream_t st) {
+    const int n_stiles = (A.S + BASQ_ST - 1) / BASQ_ST;
+    const int jgroups = (A.m + 255) / 256;
+    const long long nblk = (long long)n_stiles * A.n_chunks * jgroups;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return BASQ_EINVAL;
+    if (A.wx)
+        hipLaunchKernelGGL((blocksum_valu_kernel<KK, FAM, BASQ_ST, true>), dim3((unsigned)nblk), dim3(256), 0, st, A.nys,
+                           A.cand, A.mu, A.wx, A.Xpart, A.Rl, A.off, A.n_full, A.blk_lo, A.blk_hi, A.blk_per_chunk, A.m,
+                           A.S, A.n_chunks, n_stiles);
+    else
+        hipLaunchKernelGGL((blocksum_valu_kernel<KK, FAM, BASQ_ST, false>), dim3((unsigned)nblk), dim3(256), 0, st, A.nys,
+                           A.cand, A.mu, A.wx, A.Xpart, A.Rl, A.off, A.n_full, A.blk_lo, A.blk_hi, A.blk_per_chunk, A.m,
+                           A.S, A.n_chunks, n_stiles);
+    BASQ_CHECK_LAUNCH();
+    if (A.totpart) {
+        const int n = A.n_chunks * A.S;
+        hipLaunchKernelGGL(setsum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A.mu, A.totpart, A.Rl,
+                           A.off, A.n_full, A.blk_lo, A.blk_hi, A.blk_per_chunk, A.S, A.n_chunks);
+        BASQ_CHECK_LAUNCH();
+    }
+    return BASQ_OK;
+}
+
+template <int KK>
+static int dispatch_blocksum_valu_fam(int fam, const BlocksumArgs& A, hipStream_t st) {
+    switch (fam) {
+        case BASQ_FAMILY_RBF: return launch_blocksum_valu<KK, BASQ_FAMILY_RBF>(A, st);
+        case BASQ_FAMILY_MATERN52: return launch_blocksum_valu<KK, BASQ_FAMILY_MATERN52>(A, st);
+        case BASQ_FAMILY_MATERN32: return launch_blocksum_valu<KK, BASQ_FAMILY_MATERN32>(A, st);
+    }
+    return BASQ_EUNSUPPORTED;
+}
+
+static int dispatch_blocksum_valu(int kk, int fam, const BlocksumArgs& A, hipStream_t st) {
+    switch (kk) {
+        case 1: return dispatch_blocksum_valu_fam<1>(fam, A, st);
+        case 2: return dispatch_blocksum_valu_fam<2>(fam, A, st);
+        case 3: return dispatch_blocksum_valu_fam<3>(fam, A, st);
+        case 4: return dispatch_blocksum_valu_fam<4>(fam, A, st);
+        case 5: return dispatch_blocksum_valu_fam<5>(fam, A, st);
+        case 6: return dispatch_blocksum_valu_fam<6>(fam, A, st);
+        case 7: return dispatch_blocksum_valu_fam<7>(fam, A, st);
+        case 8: return dispatch_blocksum_valu_fam<8>(fam, A, st);
+        case 9: return dispatch_blocksum_valu_fam<9>(fam, A, st);
+        case 10: return dispatch_blocksum_valu_fam<10>(fam, A, st);
     }
     return BASQ_EUNSUPPORTED;
 }
@@ -471,6 +782,8 @@ __global__ void __launch_bounds__(1024) car_eliminate_kernel(double* __restrict_
                                                              int M, int s, int* __restrict__ keep_rank,
                                                              int* __restrict__ kept, double* __restrict__ w_star,
                                                              int* __restrict__ info) {
+#pragma clang fp contract(off)   // plain operators below: the reference rounds after every mul / sub / div
+    // (HIP's __dmul_rn/__dsub_rn are inline functions compiled with contraction allowed: they DO fuse)
     __shared__ double mu[1024];
     __shared__ double pc[1024];
     __shared__ double red_v[16];
@@ -492,7 +805,7 @@ __global__ void __launch_bounds__(1024) car_eliminate_kernel(double* __restrict_
         const double* col = PhiT + (long long)k * M;
         const double phi = (tid < M) ? col[tid] : 0.0;
         const bool pos = (tid < M) && (phi > 0.0);
-        double av = pos ? __ddiv_rn(mu[tid], phi) : INF;
+        double av = pos ? (mu[tid] / phi) : INF;
         int ai = pos ? tid : 0x7fffffff;
         // first-index argmin (torch.argmin semantics, :152)
 #pragma unroll
@@ -519,7 +832,10 @@ __global__ void __launch_bounds__(1024) car_eliminate_kernel(double* __restrict_
         if (j == 0x7fffffff) { status = 1; break; }   // uniform: no positive entry (reference raises)
         if (tid == j) sh_phij = phi;
         const double aj = sh_alpha;
-        if (tid < M) mu[tid] = (tid == j) ? 0.0 : __dsub_rn(mu[tid], __dmul_rn(aj, phi));   // :158-159
+        if (tid < M) {                                                                  // :158-159
+            const double step = aj * phi;
+            mu[tid] = (tid == j) ? 0.0 : (mu[tid] - step);
+        }
         for (int cc = k + 1 + tid; cc < nrows; cc += 1024) pc[cc] = PhiT[(long long)cc * M + j];
         __syncthreads();
         const double phij = sh_phij;
@@ -527,8 +843,9 @@ __global__ void __launch_bounds__(1024) car_eliminate_kernel(double* __restrict_
         if (upd) {
             for (int cc = k + 1 + my_r; cc < nrows; cc += rows_per_pass) {   // :165-171
                 double* p = PhiT + (long long)cc * M + my_i;
-                const double o = __ddiv_rn(__dmul_rn(pc[cc], phi_i), phij);
-                *p = (my_i == j) ? 0.0 : __dsub_rn(*p, o);
+                const double prod = pc[cc] * phi_i;
+                const double o = prod / phij;
+                *p = (my_i == j) ? 0.0 : (*p - o);
             }
         }
         __syncthreads();
@@ -562,6 +879,7 @@ __global__ void reweight_compact_kernel(const double* __restrict__ cand, const d
                                         const double* __restrict__ tot, int n_keep, long long new_off,
                                         double* __restrict__ cand_out, double* __restrict__ mu_out,
                                         long long* __restrict__ gid_out, double* __restrict__ wx_out) {
+#pragma clang fp contract(off)
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= Rl * kp) return;
     const long long p = t / kp;
@@ -583,7 +901,8 @@ __global__ void reweight_compact_kernel(const double* __restrict__ cand, const d
     dst -= new_off;
     cand_out[dst * kp + k] = cand[t];
     if (k == 0) {
-        mu_out[dst] = __ddiv_rn(__dmul_rn(mu[p], w_star[kr]), tot[set]);   // :113-114 / :121-122
+        const double scaled = mu[p] * w_star[kr];                          // :113-114 / :121-122
+        mu_out[dst] = scaled / tot[set];
         gid_out[dst] = gid[p];
         if (wx) wx_out[dst] = wx[p];
     }
@@ -665,7 +984,7 @@ int basq_gram_f64(const basq_kernel_spec* spec, const double* packA, int64_t na,
 
 static int blocksum_impl(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
                          const double* mu, const double* wx, int64_t Rl, int64_t off, int64_t n_full, int32_t S,
-                         int32_t n_chunks, double* Xpart, double* totpart, void* stream) {
+                         int32_t n_chunks, double* Xpart, double* totpart, void* stream, bool use_mfma) {
     if (!spec_ok(spec) || !nys || !cand || !mu || !Xpart) return BASQ_EINVAL;
     if (m < 1 || Rl < 1 || off < 0 || n_full < 0 || S < 1 || n_chunks < 1) return BASQ_EINVAL;
     if (n_full % S != 0) return BASQ_EINVAL;
@@ -685,14 +1004,22 @@ static int blocksum_impl(const basq_kernel_spec* spec, const double* nys, int32_
     const long long nblk = A.blk_hi - A.blk_lo;
     A.blk_per_chunk = (nblk + n_chunks - 1) / n_chunks;
     if (A.blk_per_chunk < 1) A.blk_per_chunk = 1;
-    return dispatch_blocksum(basq_kp(spec->d) / 4, spec->family, A, (hipStream_t)stream);
+    if (use_mfma) return dispatch_blocksum(basq_kp(spec->d) / 4, spec->family, A, (hipStream_t)stream);
+    return dispatch_blocksum_valu(basq_kp(spec->d) / 4, spec->family, A, (hipStream_t)stream);
 }
 
 int basq_blocksum_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
                       const double* mu, const double* wx, int64_t Rl, int64_t off, int64_t n_full, int32_t S,
                       int32_t n_chunks, double* Xpart, double* totpart, void* stream) {
     if (!totpart) return BASQ_EINVAL;
-    return blocksum_impl(spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, Xpart, totpart, stream);
+    return blocksum_impl(spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, Xpart, totpart, stream, false);
+}
+
+int basq_blocksum_mfma_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
+                           const double* mu, const double* wx, int64_t Rl, int64_t off, int64_t n_full, int32_t S,
+                           int32_t n_chunks, double* Xpart, double* totpart, void* stream) {
+    if (!totpart) return BASQ_EINVAL;
+    return blocksum_impl(spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, Xpart, totpart, stream, true);
 }
 
 int basq_kernel_matvec_f64(const basq_kernel_spec* spec, const double* packA, int64_t na, const double* packB,
@@ -700,7 +1027,7 @@ int basq_kernel_matvec_f64(const basq_kernel_spec* spec, const double* packA, in
     // blocksum with a single set and everything in the "tail": out[i] = sum_j k(A_i, B_j) v_j.
     if (!spec_ok(spec) || !packA || !packB || !v || !out || na < 1 || nb < 1 || na > 0x7fffffffLL)
         return BASQ_EINVAL;
-    int rc = blocksum_impl(spec, packA, (int32_t)na, packB, v, nullptr, nb, 0, 0, 1, 1, out, nullptr, stream);
+    int rc = blocksum_impl(spec, packA, (int32_t)na, packB, v, nullptr, nb, 0, 0, 1, 1, out, nullptr, stream, false);
     if (rc != BASQ_OK) return rc;
     hipLaunchKernelGGL(axpb_strided_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out,
                        (long long)na, 1LL, spec->outputscale, bias, out);

@@ -1,0 +1,186 @@
+"""bench.py -- recombination batches/sec (N candidates -> n points) at N=1e6, d=10 on 1/2/4/8 MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 the driver launches it as
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`` (one rank per GPU, RCCL).
+Rank 0 prints ONE JSON line.
+
+* step      = one end-to-end ``recombination(pts_rec[N,d], pts_nys[m,d], n, kernel)`` batch: Nystrom Gram +
+              randomised SVD + all divide-and-conquer rounds + reductions -> ``(idx, w)``;
+* workload  = BASELINE.json's headline configuration (configs[2]; it fits one GPU): RBF l=2, N=1e6, d=10,
+              n=100, m=N/100=1e4, synthetic Gaussian-mixture pool (``basq_amd.pools.gmm_pool``), float64;
+* residency = the pool is on the GPU(s) before the clock starts (the reference's boundary hands over torch
+              tensors; H2D of the pool is reported separately in DESIGN.md, never in ``value``);
+* N > 1     = the SAME batch with the pool sharded over the ranks (strong scaling; one small all-gather +
+              broadcast per round);
+* roofline  = the dominant kernel (``blocksum_valu_kernel``): algorithmic flops = pairs * (3d + 3)
+               over its HIP-event time on the launch stream, against the fp64 vector peak;
+* cpu_baseline = the oracle (= the reference's CPU op sequence) on this host's cores, bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP64_VECTOR_TFLOPS = 78.6      # MI355X: 256 CU x 128 flop/clk x 2.4 GHz (fp64 vector == fp64 matrix peak)
+PEAK_HBM_GBS = 8000.0
+
+WORKLOAD = dict(N=1_000_000, d=10, n=100, nys_ratio=1e-2, family="rbf", lengthscale=2.0, outputscale=1.0, pool_seed=0)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--N", type=int, default=WORKLOAD["N"])
+    ap.add_argument("--d", type=int, default=WORKLOAD["d"])
+    ap.add_argument("--n", type=int, default=WORKLOAD["n"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-stride", type=int, default=0, help="run every k-th hot-loop block on the CPU (0 = auto)")
+    ap.add_argument("--breakdown", action="store_true", help="print a per-phase host timer breakdown to stderr")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path exists in basq_amd)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import basq_amd
+    from basq_amd._partition import initial_shards
+    from basq_amd.pools import gmm_pool
+
+    N, d, n = args.N, args.d, args.n
+    m = int(N * WORKLOAD["nys_ratio"])
+    kern = basq_amd.kernels.StationaryKernel(WORKLOAD["family"], WORKLOAD["lengthscale"], WORKLOAD["outputscale"])
+    pool = gmm_pool(N, d, WORKLOAD["pool_seed"])                     # every rank regenerates the same pool
+    off, Rl = initial_shards(N, world)[rank]
+    pts_nys = pool[:m].to(dev)                                       # PriorSampler: prefix of the pool
+    pts_local = pool[off:off + Rl].to(dev)                           # resident before the clock starts
+    if world == 1:
+        pool_dev = pts_local
+
+    def one_batch(trace=None):
+        torch.manual_seed(1)                                         # manual_seed(1) before each call
+        if world == 1:
+            return basq_amd.recombination(pool_dev, pts_nys, n, kern, dev, trace=trace)
+        return basq_amd.recombination_sharded(pts_local, off, N, pts_nys, n, kern, dev, trace=trace)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_batch()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        idx, w = one_batch()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # ---- kernel-level roofline: one extra traced batch (HIP events on the launch stream, no host syncs) ----
+    tr = basq_amd.EngineTrace(time_kernels=True, host_sync=False)
+    one_batch(tr)
+    torch.cuda.synchronize()
+    k_ms = sum(a.elapsed_time(b) for a, b, _ in tr.kernel_events)
+    k_pairs = sum(info["pairs"] for _, _, info in tr.kernel_events)
+    k_launches = len(tr.kernel_events)
+    flops = k_pairs * (3 * d + 3)
+    bytes_alg = sum(info["R"] * (8 * d + 16) + 8 * info["m"] * d for _, _, info in tr.kernel_events)
+    achieved_tf = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+
+    if args.breakdown:
+        tb = basq_amd.EngineTrace(time_kernels=False, host_sync=True)
+        one_batch(tb)
+        if rank == 0:
+            print("phase breakdown (s):", {k: round(v, 4) for k, v in tb.timers.items()}, file=sys.stderr)
+            print("rounds:", [(r["R"], r["S"], len(r["kept"])) for r in tb.rounds], file=sys.stderr)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle.cpu_baseline import sampled_batch_seconds
+        from oracle.kernels_oracle import StationaryOracle
+
+        stride = args.cpu_stride or max(1, N // 50_000)             # ~10-30 s of CPU work at N=1e6
+        torch.manual_seed(1)
+        res = sampled_batch_seconds(pool, pool[:m], n, StationaryOracle(WORKLOAD["family"], WORKLOAD["lengthscale"],
+                                                                        WORKLOAD["outputscale"]), stride)
+        cpu = dict(
+            value=1.0 / res["seconds_per_batch"], unit="batches/s", cores=torch.get_num_threads(), kind="port",
+            sample=(f"oracle (reference op sequence, float64, torch CPU) on the same pool: Gram+svd_lowrank, all "
+                    f"{res['n_rounds']} rounds' projection/SVD/elimination in full; hot loop every {stride}th block "
+                    f"({res['kernel_calls_run']}/{res['kernel_calls_total']} kernel calls), loop time scaled; "
+                    f"{res['measured_seconds']:.1f}s measured -> {res['seconds_per_batch']:.1f}s/batch"),
+        )
+
+    if rank == 0:
+        value = args.steps / dt
+        out = {
+            "metric": "recombination batches/sec (N candidates -> n points) at N=1e6 d=10",
+            "value": value,
+            "unit": "batches/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"RBF kernel l=2, N={N} candidates, d={d}, n={n} recombination, m={m} Nystrom points, "
+                                   f"float64, pool sharded over {world} GPU(s)",
+                       "N": N, "d": d, "n": n, "m": m, "kernel": "rbf", "parallelism": f"pool-sharded x{world}"},
+            "roofline": {
+                "bound": "valu_f64",
+                "kernel": "blocksum_valu_kernel (fused pairwise-kernel block sums, BASQ/_rchq.py:79-99)",
+                "achieved": achieved_tf, "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved_tf / PEAK_FP64_VECTOR_TFLOPS,
+                "traffic": None,
+                "launches_per_batch": k_launches, "kernel_ms_per_batch": k_ms, "pairs_per_batch": k_pairs,
+                "flops_per_pair": 3 * d + 3,
+                "hbm_algorithmic_GBs": bytes_alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
+                "hbm_peak_GBs": PEAK_HBM_GBS,
+                "note": "compute-bound on the fp64 vector ALU (SURVEY 8d); measured per rank 0; traffic: see profiles/",
+            },
+            "cpu_baseline": cpu,
+            "result_digest": {"n_selected": int(idx.numel()), "w_sum": float(w.sum().item())},
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

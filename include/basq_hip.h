@@ -18,8 +18,8 @@
  *
  * Packed operands.  Points are pre-packed once per batch into rows of KP = basq_kp(d) doubles so that
  * the pairwise exponent argument is ONE dot product on the f64 matrix cores:
- *     role A (left / Nystrom side):  [ (x-c)/l ... , h,  1, 0.. ]     h = -1/2 |(x-c)/l|^2
- *     role B (right / candidate side): [ (y-c)/l ... , 1,  h, 0.. ]
+ *     role A (left / Nystrom side):    [ (x-c)/l ... , 0.. , h, 1 ]     h = -1/2 |(x-c)/l|^2
+ *     role B (right / candidate side): [ (y-c)/l ... , 0.. , 1, h ]     (h and 1 in the LAST two slots)
  *     A_row . B_row = -1/2 |(x-y)/l|^2   (c = centring vector, l = lengthscale)
  * (the centring mirrors gpytorch's mean-centred squared distance, see oracle/kernels_oracle.py).
  */
@@ -102,6 +102,14 @@ int basq_kernel_matvec_f64(const basq_kernel_spec* spec, const double* packA, in
 int basq_blocksum_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
                       const double* mu, const double* wx, int64_t Rl, int64_t off, int64_t n_full, int32_t S,
                       int32_t n_chunks, double* Xpart, double* totpart, void* stream);
+
+/*
+ * Same contract as basq_blocksum_f64, exponent arguments on the f64 matrix cores.  Kept for A/B
+ * measurement: on gfx950 it is the slower form, the product path does not use it.
+ */
+int basq_blocksum_mfma_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
+                           const double* mu, const double* wx, int64_t Rl, int64_t off, int64_t n_full, int32_t S,
+                           int32_t n_chunks, double* Xpart, double* totpart, void* stream);
 
 /*
  * Nystrom-feature contraction BASQ/_rchq.py:88-90:  out[0][s] = sum_c totpart[c][s];

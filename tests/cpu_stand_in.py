@@ -52,11 +52,11 @@ class CpuStandInOps:
         h = -0.5 * (v * v).sum(1)
         out[:n, :d] = v
         if role == ROLE_A:
-            out[:n, d] = h
-            out[:n, d + 1] = 1.0
+            out[:n, kp - 2] = h
+            out[:n, kp - 1] = 1.0
         else:
-            out[:n, d] = 1.0
-            out[:n, d + 1] = h
+            out[:n, kp - 2] = 1.0
+            out[:n, kp - 1] = h
         return out
 
     @staticmethod
@@ -193,3 +193,6 @@ class CpuStandInOps:
 
     def synchronize(self):
         pass
+
+    def record_event(self):
+        return None
