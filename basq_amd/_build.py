@@ -32,15 +32,19 @@ def needs_build() -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + DEPS)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = True, defines: dict | None = None, out: str | None = None) -> str:
+    """Build the library.  ``defines``/``out`` build a tuning variant (tools/ only; e.g. BASQ_ST, BASQ_TJ)."""
+    target = out or LIB
+    if not force and out is None and not needs_build():
         return LIB
     cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wall", "-Wno-unused-function", "-o", target] + [os.path.join(CSRC, s) for s in SOURCES]
+    for k, v in (defines or {}).items():
+        cmd.append(f"-D{k}={v}")
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=CSRC)
-    return LIB
+    return target
 
 
 if __name__ == "__main__":

@@ -135,17 +135,71 @@ def _host_qr_q(ops, X, trace=None):
         return ops.to_device(Qh)
 
 
+def _cholqr2(ops, X, flags):
+    """Orthonormal basis of range(X) ([m,k], k <= m) by two CholeskyQR passes, entirely on the GPU.
+
+    ``X^T X = L L^T``, ``Q = X L^{-T}``; the second pass restores orthogonality to round-off whenever
+    cond(X) < ~1e7.  The pivot flags (device int32) are appended to ``flags`` and checked once, later.
+    """
+    for _ in range(2):
+        G = ops.matmul(X.t(), X)
+        W, info = ops.chol_inv(G)
+        flags.append(info)
+        X = ops.matmul(X, W)
+    return X
+
+
+# The GPU range finder may be switched off (tests compare both paths).
+GPU_RANGE_FINDER = True
+
+
 def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None):
     """``ker_svd_sparsify`` (``BASQ/_rchq.py:28-31``): ``-svd_lowrank(A, q)[0].T`` -> ``[min(q,m), m]``.
 
     Restates ``torch._lowrank.get_approximate_basis`` / ``_svd_lowrank`` (torch 2.10, niter=2, square A so
     no transposition): the Gaussian test matrix is drawn exactly where the reference draws it -- one
     ``torch.randn(m, q)`` from the CPU global generator.
+
+    What the reference's result depends on is only (i) that draw and (ii) the *range* of each intermediate
+    ``Q``: the rows of the returned ``U`` are the left singular vectors of ``Q Q^T A``, unique up to sign,
+    and the recombination is bit-for-bit invariant under row sign flips of ``U`` (tests/test_oracle.py).
+    So the five Householder QRs (host LAPACK in the reference) are replaced by CholeskyQR2 on the GPU and
+    the ``[k, m]`` SVD by an LQ reduction on the GPU + a ``k x k`` SVD on the host.  If a Cholesky pivot
+    signals a numerically rank-deficient panel (cond > ~1e6) the whole basis is recomputed with host
+    Householder QR, from the same Gaussian draw.
     """
     m = A.shape[0]
     with _Timer(ops, trace, "basis.randn"):
         R = ops.to_device(torch.randn(m, q_req, dtype=torch.float64))   # CPU generator (reference: CPU tensor A)
     At = A.t()
+    if GPU_RANGE_FINDER and q_req <= m:
+        with _Timer(ops, trace, "basis.gpu_range"):
+            flags = []
+            Q = _cholqr2(ops, ops.matmul(A, R), flags)
+            for _ in range(2):
+                Q = _cholqr2(ops, ops.matmul(At, Q), flags)
+                Q = _cholqr2(ops, ops.matmul(A, Q), flags)
+            B = ops.matmul(Q.t(), A)                           # [k, m]
+            # LQ of B (CholeskyQR2 on its rows):  B = L1 L2 Qb^T  ->  left singular vectors of B = those of L
+            G1 = ops.matmul(B, B.t())
+            W1, i1 = ops.chol_inv(G1)
+            Bq = ops.matmul(W1.t(), B)
+            G2 = ops.matmul(Bq, Bq.t())
+            _, i2 = ops.chol_inv(G2)
+            L = ops.matmul(torch.tril(G1), torch.tril(G2))
+            bad = torch.stack([f.reshape(()) for f in flags + [i1, i2]]).max()
+        with _Timer(ops, trace, "basis.host_svd"):
+            Lh = L.cpu()                                       # one synchronisation for the whole range finder
+            ok = int(bad.item()) == 0
+            if ok:
+                with _lapack_threads():
+                    Ub = torch.linalg.svd(Lh)[0]
+        if ok:
+            with _Timer(ops, trace, "basis.gemm"):
+                U = ops.matmul(Q, ops.to_device(Ub))           # [m, k]
+                return (-1 * U.t()).contiguous()               # :30
+        if trace is not None:
+            trace.timers["basis.fallback"] = trace.timers.get("basis.fallback", 0) + 1
     with _Timer(ops, trace, "basis.gemm"):
         X = ops.matmul(A, R)
     Q = _host_qr_q(ops, X, trace)

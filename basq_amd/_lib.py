@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbasq_hip.so")
+# BASQ_HIP_LIB selects a tuning-variant build of the SAME library (tools/bench_blocksum.py); never a fallback.
+LIB_PATH = os.environ.get("BASQ_HIP_LIB") or os.path.join(_HERE, "csrc", "libbasq_hip.so")
 
 # error codes / enums (mirror include/basq_hip.h)
 BASQ_OK = 0
@@ -45,6 +46,7 @@ SIGNATURES = {
     "basq_reweight_compact_f64": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i32,
                                             _i64, _vp, _vp, _vp, _vp, _vp]),
     "basq_init_state_f64": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
+    "basq_chol_inv_f64": (C.c_int, [_vp, _i32, _vp, _vp, _f64, _vp]),
     "basq_gemm_f64": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _f64, _vp]),
 }
 

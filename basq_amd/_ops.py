@@ -118,8 +118,8 @@ class HipOps:
     def project(self, U, q, m, Xpart, totpart, n_chunks, S, outputscale, ksplit=None):
         self._chk(U)
         if ksplit is None:
-            ksplit = max(1, min(64, m // 128))
-        work = self.empty(ksplit, q, S)
+            ksplit = max(1, min(64 // n_chunks, m // 128))
+        work = self.empty(n_chunks * ksplit, q, S)
         out = self.empty(q + 1, S)
         check(self.lib.basq_project_f64(_ptr(U), q, m, _ptr(Xpart), _ptr(totpart), n_chunks, S, float(outputscale),
                                         ksplit, _ptr(work), _ptr(out), self._stream()), "basq_project_f64")
@@ -164,6 +164,16 @@ class HipOps:
         check(self.lib.basq_init_state_f64(_ptr(mu), _ptr(gid), Rl, gid0, n_total, self._stream()),
               "basq_init_state_f64")
         return mu, gid
+
+    def chol_inv(self, G, rel_tol=1e-12):
+        """In place: G -> L (lower).  Returns (W = L^{-T}, info[1] int32 on device)."""
+        self._chk(G)
+        q = G.shape[0]
+        W = self.empty(q, q)
+        info = self.empty(1, dtype=torch.int32)
+        check(self.lib.basq_chol_inv_f64(_ptr(G), q, _ptr(W), _ptr(info), float(rel_tol), self._stream()),
+              "basq_chol_inv_f64")
+        return W, info
 
     def gemm(self, A, B, alpha=1.0):
         """C = alpha * A @ B on the f64 matrix cores (own kernel)."""

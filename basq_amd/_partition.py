@@ -70,13 +70,30 @@ def local_blocks(off: int, Rl: int, geo: RoundGeometry) -> int:
     return (lim + geo.S - 1) // geo.S - off // geo.S
 
 
-def choose_chunks(n_local_blocks: int, m: int, S: int, target_waves: int = 4096, min_blocks: int = 8,
-                  max_chunks: int = 64) -> int:
-    """Split the block loop so the launch has ~``target_waves`` waves without starving a chunk.
+# Launch geometry of the block-sum kernels (must mirror basq_hip.hip): a wave covers 64 Nystrom rows x
+# SETS_PER_WAVE sets, 4 waves per work-group; RESIDENT_WAVES = 256 CUs x 4 SIMDs x 3 waves (register-limited).
+SETS_PER_WAVE = 20
+RESIDENT_WAVES = 256 * 4 * 3
 
-    One wave covers 64 Nystrom rows x 16 sets; chunks multiply the wave count.
+
+def choose_chunks(n_local_blocks: int, m: int, S: int, max_chunks: int = 32, min_blocks: int = 4,
+                  sets_per_wave: int = SETS_PER_WAVE, resident: int = RESIDENT_WAVES) -> int:
+    """Number of chunks the block loop is split into.
+
+    All waves of a launch do the same amount of work, so the launch takes ``ceil(waves / resident)``
+    "rounds": 4800 waves on 3072 resident slots cost 2 rounds for 1.56 rounds of work (measured: 22 % of
+    the kernel time).  Pick the smallest chunk count whose efficiency ``(waves/resident) /
+    ceil(waves/resident)`` reaches 95 % (fewer chunks = less partial-sum traffic for the projection), else
+    the most efficient one.
     """
-    waves = ((m + 63) // 64) * ((S + 15) // 16)
-    want = max(1, -(-target_waves // max(waves, 1)))
-    cap = max(1, n_local_blocks // min_blocks)
-    return max(1, min(want, cap, max_chunks))
+    per_chunk = ((m + 255) // 256) * 4 * ((S + sets_per_wave - 1) // sets_per_wave)
+    cap = max(1, min(max_chunks, n_local_blocks // min_blocks))
+    best, best_eff = 1, -1.0
+    for c in range(1, cap + 1):
+        rounds = per_chunk * c / resident
+        eff = rounds / max(1.0, float(-(-per_chunk * c // resident)))
+        if eff >= 0.95:
+            return c
+        if eff > best_eff + 1e-9:
+            best, best_eff = c, eff
+    return best

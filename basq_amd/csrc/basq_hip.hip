@@ -411,27 +411,36 @@ __device__ __forceinline__ double pair_term(const double (&pt)[KK * 4 - 2], doub
     return __builtin_fma(e, r.w, acc);
 }
 
-// Fast path: ST consecutive candidates, all present.  Two rows live in SGPRs: the scalar loads of
-// candidate t+1 are in flight during the ~30 VALU instructions of candidate t.
-template <int KK, int FAM, int ST, bool HAS_WX, int T>
-struct BlockStep {
-    static __device__ __forceinline__ void run(const double (&pt)[KK * 4 - 2], double hj, double onej, const ExpK& ek,
-                                               CandRow<KK> (&rows)[2], const double* cb, const double* mb,
-                                               const double* xb, double (&acc)[ST]) {
-        row_wait<KK, HAS_WX>(rows[T & 1]);
-        if (T + 1 < ST) row_issue<KK, T + 1, HAS_WX>(rows[(T + 1) & 1], cb, mb, xb);
-        acc[T] = pair_term<KK, FAM, HAS_WX>(pt, hj, onej, rows[T & 1], ek, acc[T]);
-        BlockStep<KK, FAM, ST, HAS_WX, T + 1>::run(pt, hj, onej, ek, rows, cb, mb, xb, acc);
-    }
-};
-template <int KK, int FAM, int ST, bool HAS_WX>
-struct BlockStep<KK, FAM, ST, HAS_WX, ST> {
-    static __device__ __forceinline__ void run(const double (&)[KK * 4 - 2], double, double, const ExpK&,
-                                               CandRow<KK> (&)[2], const double*, const double*, const double*,
-                                               double (&)[ST]) {}
+// The TJ Nystrom rows owned by one lane (rows jw + u*64 + lane, u < TJ).
+template <int KK, int TJ>
+struct LaneRows {
+    double pt[TJ][KK * 4 - 2];
+    double hj[TJ];
+    double onej[TJ];
 };
 
-template <int KK, int FAM, int ST, bool HAS_WX>
+// Fast path: ST consecutive candidates, all present.  Two rows live in SGPRs: the scalar loads of
+// candidate t+1 are in flight during the TJ * ~27 VALU instructions of candidate t.
+template <int KK, int FAM, int ST, int TJ, bool HAS_WX, int T>
+struct BlockStep {
+    static __device__ __forceinline__ void run(const LaneRows<KK, TJ>& L, const ExpK& ek, CandRow<KK> (&rows)[2],
+                                               const double* cb, const double* mb, const double* xb,
+                                               double (&acc)[TJ][ST]) {
+        row_wait<KK, HAS_WX>(rows[T & 1]);
+        if (T + 1 < ST) row_issue<KK, T + 1, HAS_WX>(rows[(T + 1) & 1], cb, mb, xb);
+#pragma unroll
+        for (int u = 0; u < TJ; ++u)
+            acc[u][T] = pair_term<KK, FAM, HAS_WX>(L.pt[u], L.hj[u], L.onej[u], rows[T & 1], ek, acc[u][T]);
+        BlockStep<KK, FAM, ST, TJ, HAS_WX, T + 1>::run(L, ek, rows, cb, mb, xb, acc);
+    }
+};
+template <int KK, int FAM, int ST, int TJ, bool HAS_WX>
+struct BlockStep<KK, FAM, ST, TJ, HAS_WX, ST> {
+    static __device__ __forceinline__ void run(const LaneRows<KK, TJ>&, const ExpK&, CandRow<KK> (&)[2], const double*,
+                                               const double*, const double*, double (&)[TJ][ST]) {}
+};
+
+template <int KK, int FAM, int ST, int TJ, bool HAS_WX>
 __global__ void __launch_bounds__(256)
 blocksum_valu_kernel(const double* __restrict__ nys, const double* __restrict__ cand, const double* __restrict__ mu,
                      const double* __restrict__ wx, double* __restrict__ Xpart, long long Rl, long long off,
@@ -444,18 +453,26 @@ blocksum_valu_kernel(const double* __restrict__ nys, const double* __restrict__ 
     b /= n_stiles;
     const int chunk = b % n_chunks;
     const int jg = b / n_chunks;
-    const int jw = (jg * 4 + wave) * 64;
+    const int jw = (jg * 4 + wave) * (64 * TJ);
     if (jw >= m) return;                       // wave-uniform; no barriers in this kernel
-    const int j = jw + lane;                   // rows are padded to a multiple of 64: always in bounds
-    double pt[DIMS];
+    const int mrows = ((m + 63) / 64) * 64;    // rows the caller allocated (padded to a multiple of 64)
+    LaneRows<KK, TJ> L;
 #pragma unroll
-    for (int k = 0; k < DIMS; ++k) pt[k] = nys[(long long)j * KP + k];
-    const double hj = nys[(long long)j * KP + KP - 2];
-    const double onej = nys[(long long)j * KP + KP - 1];
+    for (int u = 0; u < TJ; ++u) {
+        int j = jw + u * 64 + lane;
+        if (j >= mrows) j = mrows - 1;         // rows past the padding: computed, never stored
+        const double* row = nys + (long long)j * KP;
+#pragma unroll
+        for (int k = 0; k < DIMS; ++k) L.pt[u][k] = row[k];
+        L.hj[u] = row[KP - 2];
+        L.onej[u] = row[KP - 1];
+    }
 
-    double acc[ST];
+    double acc[TJ][ST];
 #pragma unroll
-    for (int t = 0; t < ST; ++t) acc[t] = 0.0;
+    for (int u = 0; u < TJ; ++u)
+#pragma unroll
+        for (int t = 0; t < ST; ++t) acc[u][t] = 0.0;
     ExpK ek;
     expk_init(ek);
 
@@ -468,9 +485,9 @@ blocksum_valu_kernel(const double* __restrict__ nys, const double* __restrict__ 
     if (bB > blk_hi) bB = blk_hi;
 
     // L2 warm-up.  The scalar path has no prefetcher and a candidate row is used once per wave, so an
-    // un-warmed s_load pays the full HBM latency (~750 cycles measured per candidate, 4 lockstep waves per
-    // block cannot hide it).  One vector load per lane touches the 128-B lines of the rows PF blocks ahead;
-    // its (dummy) result is waited for one block later, when it has long landed.
+    // un-warmed s_load pays the full HBM latency (~750 cycles measured per candidate; the 4 waves of a block
+    // run in lockstep and cannot hide it for each other).  One vector load per lane touches the 128-B lines
+    // of the rows PF blocks ahead; its (dummy) result is waited for one block later, when it has long landed.
     constexpr int PF = 2;
     constexpr int ROW_LINES = (ST * KP * 8 + 127) / 128 + 1;         // lines spanned by ST packed rows (+1: alignment)
     float pf_dummy = 0.f;
@@ -495,7 +512,7 @@ blocksum_valu_kernel(const double* __restrict__ nys, const double* __restrict__ 
             const double* mb = mu + base;
             const double* xb = HAS_WX ? (wx + base) : mu;
             row_issue<KK, 0, HAS_WX>(rows[0], cb, mb, xb);
-            BlockStep<KK, FAM, ST, HAS_WX, 0>::run(pt, hj, onej, ek, rows, cb, mb, xb, acc);
+            BlockStep<KK, FAM, ST, TJ, HAS_WX, 0>::run(L, ek, rows, cb, mb, xb, acc);
         } else {
             // shard edges / ragged last set tile: candidate by candidate, wave-uniform branches
 #pragma unroll
@@ -505,7 +522,9 @@ blocksum_valu_kernel(const double* __restrict__ nys, const double* __restrict__ 
                     CandRow<KK> r;
                     row_issue<KK, 0, HAS_WX>(r, cand + pl * KP, mu + pl, HAS_WX ? (wx + pl) : mu);
                     row_wait<KK, HAS_WX>(r);
-                    acc[t] = pair_term<KK, FAM, HAS_WX>(pt, hj, onej, r, ek, acc[t]);
+#pragma unroll
+                    for (int u = 0; u < TJ; ++u)
+                        acc[u][t] = pair_term<KK, FAM, HAS_WX>(L.pt[u], L.hj[u], L.onej[u], r, ek, acc[u][t]);
                 }
             }
         }
@@ -516,23 +535,32 @@ blocksum_valu_kernel(const double* __restrict__ nys, const double* __restrict__ 
     const long long t0 = (n_full > off) ? (n_full - off) : 0;
     const int tl = (S - 1) - s0;
     if (chunk == n_chunks - 1 && tl >= 0 && tl < ST && t0 < Rl) {
-        double ta = 0.0;
+        double ta[TJ];
+#pragma unroll
+        for (int u = 0; u < TJ; ++u) ta[u] = 0.0;
         for (long long pl = t0; pl < Rl; ++pl) {
             CandRow<KK> r;
             row_issue<KK, 0, HAS_WX>(r, cand + pl * KP, mu + pl, HAS_WX ? (wx + pl) : mu);
             row_wait<KK, HAS_WX>(r);
-            ta = pair_term<KK, FAM, HAS_WX>(pt, hj, onej, r, ek, ta);
+#pragma unroll
+            for (int u = 0; u < TJ; ++u) ta[u] = pair_term<KK, FAM, HAS_WX>(L.pt[u], L.hj[u], L.onej[u], r, ek, ta[u]);
         }
 #pragma unroll
-        for (int t = 0; t < ST; ++t)
-            if (t == tl) acc[t] += ta;
+        for (int u = 0; u < TJ; ++u)
+#pragma unroll
+            for (int t = 0; t < ST; ++t)
+                if (t == tl) acc[u][t] += ta[u];
     }
 
-    if (j < m) {
-        double* out = Xpart + ((long long)chunk * m + j) * S + s0;
 #pragma unroll
-        for (int t = 0; t < ST; ++t)
-            if (t < nset) out[t] = acc[t];
+    for (int u = 0; u < TJ; ++u) {
+        const int j = jw + u * 64 + lane;
+        if (j < m) {
+            double* out = Xpart + ((long long)chunk * m + j) * S + s0;
+#pragma unroll
+            for (int t = 0; t < ST; ++t)
+                if (t < nset) out[t] = acc[u][t];
+        }
     }
 }
 
@@ -559,20 +587,25 @@ __global__ void setsum_kernel(const double* __restrict__ mu, double* __restrict_
     totpart[idx] = tot;
 }
 
-#define BASQ_ST 20
+#ifndef BASQ_ST
+#define BASQ_ST 20   // sets per wave
+#endif
+#ifndef BASQ_TJ
+#define BASQ_TJ 1    // Nystrom rows per lane
+#endif
 
 template <int KK, int FAM>
 static int launch_blocksum_valu(const BlocksumArgs& A, hipStream_t st) {
     const int n_stiles = (A.S + BASQ_ST - 1) / BASQ_ST;
-    const int jgroups = (A.m + 255) / 256;
+    const int jgroups = (A.m + 256 * BASQ_TJ - 1) / (256 * BASQ_TJ);
     const long long nblk = (long long)n_stiles * A.n_chunks * jgroups;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return BASQ_EINVAL;
     if (A.wx)
-        hipLaunchKernelGGL((blocksum_valu_kernel<KK, FAM, BASQ_ST, true>), dim3((unsigned)nblk), dim3(256), 0, st, A.nys,
+        hipLaunchKernelGGL((blocksum_valu_kernel<KK, FAM, BASQ_ST, BASQ_TJ, true>), dim3((unsigned)nblk), dim3(256), 0, st, A.nys,
                            A.cand, A.mu, A.wx, A.Xpart, A.Rl, A.off, A.n_full, A.blk_lo, A.blk_hi, A.blk_per_chunk, A.m,
                            A.S, A.n_chunks, n_stiles);
     else
-        hipLaunchKernelGGL((blocksum_valu_kernel<KK, FAM, BASQ_ST, false>), dim3((unsigned)nblk), dim3(256), 0, st, A.nys,
+        hipLaunchKernelGGL((blocksum_valu_kernel<KK, FAM, BASQ_ST, BASQ_TJ, false>), dim3((unsigned)nblk), dim3(256), 0, st, A.nys,
                            A.cand, A.mu, A.wx, A.Xpart, A.Rl, A.off, A.n_full, A.blk_lo, A.blk_hi, A.blk_per_chunk, A.m,
                            A.S, A.n_chunks, n_stiles);
     BASQ_CHECK_LAUNCH();
@@ -686,13 +719,16 @@ template <int JT>
 __global__ void __launch_bounds__(256) gemm_kernel(const double* __restrict__ A, long long lda,
                                                    const double* __restrict__ B, long long ldb, long long bstride,
                                                    int nsum, double* __restrict__ C, long long ldc, long long cstride,
-                                                   int M, int N, int K, int kslice, double alpha) {
+                                                   int M, int N, int K, int kslice, double alpha, int zdiv,
+                                                   long long b_zstride) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int r0 = blockIdx.x * (16 * JT);
     const int n0 = (blockIdx.y * 4 + wave) * 16;
     if (n0 >= N) return;
-    const int k0 = blockIdx.z * kslice;
+    // blockIdx.z = (B slab) * zdiv + (K slice): one launch covers every chunk partial of the projection
+    B += (long long)(blockIdx.z / zdiv) * b_zstride;
+    const int k0 = (blockIdx.z % zdiv) * kslice;
     int k1 = k0 + kslice;
     if (k1 > K) k1 = K;
     const int col = (n0 + c < N) ? (n0 + c) : (N - 1);
@@ -908,6 +944,71 @@ __global__ void reweight_compact_kernel(const double* __restrict__ cand, const d
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small dense Cholesky + triangular inverse, one work-group, in place in global memory (L2-resident):
+// G (SPD, q x q) -> L in the lower triangle;  W = L^{-T} (upper triangular), so that for X with
+// X^T X = G the matrix Q = X W has orthonormal columns (CholeskyQR step of the randomised SVD).
+// info[0] = 0, or j+1 if pivot j fell below rel_tol * max diag (caller falls back to Householder QR).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) chol_inv_kernel(double* __restrict__ G, int q, double* __restrict__ W,
+                                                        int* __restrict__ info, double rel_tol) {
+    __shared__ double colj[1024];
+    __shared__ double red[16];
+    __shared__ double s_dmax;
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double dm = (tid < q) ? G[(long long)tid * q + tid] : 0.0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) dm = fmax(dm, __shfl_xor(dm, o, 64));
+    if (lane == 0) red[wv] = dm;
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    if (tid == 0) {
+        double v = red[0];
+        for (int w = 1; w < 16; ++w) v = fmax(v, red[w]);
+        s_dmax = v;
+    }
+    for (long long e = tid; e < (long long)q * q; e += 1024) W[e] = 0.0;
+    __syncthreads();
+    const double floor_ = rel_tol * s_dmax;
+    for (int j = 0; j < q; ++j) {
+        if (tid == 0) {
+            const double d = G[(long long)j * q + j];
+            if (!(d > floor_)) s_bad = j + 1;
+            else G[(long long)j * q + j] = sqrt(d);
+        }
+        __syncthreads();
+        if (s_bad) break;                                   // uniform
+        const double piv = G[(long long)j * q + j];
+        for (int i = j + 1 + tid; i < q; i += 1024) {
+            const double v = G[(long long)i * q + j] / piv;
+            G[(long long)i * q + j] = v;
+            colj[i] = v;
+        }
+        __syncthreads();
+        const int n = q - j - 1;
+        for (int idx = tid; idx < n * n; idx += 1024) {
+            const int a = idx / n, b = idx - a * n;
+            if (b <= a) {
+                const int i = j + 1 + a, k = j + 1 + b;
+                G[(long long)i * q + k] -= colj[i] * colj[k];
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) info[0] = s_bad;
+    if (s_bad || tid >= q) return;
+    // column c of Y = L^{-1} by forward substitution; stored as row c of W (= Y^T)
+    const int c = tid;
+    double* wrow = W + (long long)c * q;
+    for (int i = c; i < q; ++i) {
+        const double* lrow = G + (long long)i * q;
+        double acc = (i == c) ? 1.0 : 0.0;
+        for (int k = c; k < i; ++k) acc -= lrow[k] * wrow[k];
+        wrow[i] = acc / lrow[i];
+    }
+}
+
 __global__ void axpb_strided_kernel(const double* __restrict__ x, long long n, long long stride, double a, double b,
                                     double* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1043,14 +1144,15 @@ int basq_project_f64(const double* U, int32_t q, int32_t m, const double* Xpart,
     hipStream_t st = (hipStream_t)stream;
     int kslice = (m + ksplit - 1) / ksplit;
     kslice = ((kslice + 3) / 4) * 4;
-    const int nz = (m + kslice - 1) / kslice;
-    dim3 grid((unsigned)((q + 15) / 16), (unsigned)((S + 63) / 64), (unsigned)nz);
-    hipLaunchKernelGGL((gemm_kernel<1>), grid, dim3(256), 0, st, U, (long long)m, Xpart, (long long)S,
-                       (long long)m * S, n_chunks, work, (long long)S, (long long)q * S, q, S, m, kslice, outputscale);
+    const int nz = (m + kslice - 1) / kslice;          // <= ksplit slabs per chunk
+    // z = chunk * nz + K slice; slabs [chunk][slice] are contiguous in `work`
+    dim3 grid((unsigned)((q + 15) / 16), (unsigned)((S + 63) / 64), (unsigned)(nz * n_chunks));
+    hipLaunchKernelGGL((gemm_kernel<1>), grid, dim3(256), 0, st, U, (long long)m, Xpart, (long long)S, 0LL, 1, work,
+                       (long long)S, (long long)q * S, q, S, m, kslice, outputscale, nz, (long long)m * S);
     BASQ_CHECK_LAUNCH();
     const int tot = (q + 1) * S;
-    hipLaunchKernelGGL(project_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, work, nz, q, S,
-                       totpart, n_chunks, out);
+    hipLaunchKernelGGL(project_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, work,
+                       nz * n_chunks, q, S, totpart, n_chunks, out);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }
@@ -1105,13 +1207,20 @@ int basq_init_state_f64(double* mu, int64_t* gid, int64_t Rl, int64_t gid0, int6
     return BASQ_OK;
 }
 
+int basq_chol_inv_f64(double* G, int32_t q, double* W, int32_t* info, double rel_tol, void* stream) {
+    if (!G || !W || !info || q < 1 || q > 1024 || !(rel_tol >= 0.0)) return BASQ_EINVAL;
+    hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, G, q, W, info, rel_tol);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
 int basq_gemm_f64(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, int32_t M,
                   int32_t N, int32_t K, double alpha, void* stream) {
     if (!A || !B || !C || M < 1 || N < 1 || K < 1 || lda < K || ldb < N || ldc < N) return BASQ_EINVAL;
     dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64), 1);
     const int kslice = ((K + 3) / 4) * 4;
     hipLaunchKernelGGL((gemm_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, A, (long long)lda, B, (long long)ldb,
-                       0LL, 1, C, (long long)ldc, 0LL, M, N, K, kslice, alpha);
+                       0LL, 1, C, (long long)ldc, 0LL, M, N, K, kslice, alpha, 1, 0LL);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }

@@ -114,8 +114,8 @@ int basq_blocksum_mfma_f64(const basq_kernel_spec* spec, const double* nys, int3
 /*
  * Nystrom-feature contraction BASQ/_rchq.py:88-90:  out[0][s] = sum_c totpart[c][s];
  *     out[1+r][s] = outputscale * sum_j U[r][j] * (sum_c Xpart[c][j][s])        r < q
- * on the f64 matrix cores (v_mfma_f64_16x16x4_f64), K split `ksplit` ways through `work`
- * ([ksplit, q, S] doubles) and re-added in index order.  `out` is [(q+1), S]: the per-rank message
+ * on the f64 matrix cores (v_mfma_f64_16x16x4_f64); every chunk partial is split `ksplit` ways along K
+ * through `work` ([n_chunks * ksplit, q, S] doubles) and the slabs are re-added in index order.  `out` is [(q+1), S]: the per-rank message
  * of the multi-GPU all-gather; it is NOT yet divided by the set weights.
  */
 int basq_project_f64(const double* U, int32_t q, int32_t m, const double* Xpart, const double* totpart,
@@ -167,6 +167,15 @@ int basq_reweight_compact_f64(const double* cand, const double* mu, const int64_
 
 /* Initial state: mu[p] = 1/N_total (BASQ/_rchq.py:53), gid[p] = gid0 + p (:55). */
 int basq_init_state_f64(double* mu, int64_t* gid, int64_t Rl, int64_t gid0, int64_t n_total, void* stream);
+
+/*
+ * CholeskyQR building block of the randomised range finder behind torch.svd_lowrank (BASQ/_rchq.py:29):
+ * G [q,q] (symmetric positive definite, = X^T X) is overwritten by its Cholesky factor L (lower triangle;
+ * the strict upper triangle is left as it was) and W [q,q] receives L^{-T} (upper triangular), so that
+ * Q = X W has orthonormal columns.  info[0] = 0 on success, j+1 if pivot j <= rel_tol * max_i G[i][i]
+ * (numerically rank-deficient: the caller falls back to Householder QR on the host).  q <= 1024.
+ */
+int basq_chol_inv_f64(double* G, int32_t q, double* W, int32_t* info, double rel_tol, void* stream);
 
 /* Dense f64 GEMM on the matrix cores: C[M,N] = alpha * A[M,K] @ B[K,N] (row-major, lda/ldb/ldc). */
 int basq_gemm_f64(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, int32_t M,

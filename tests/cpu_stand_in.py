@@ -185,6 +185,21 @@ class CpuStandInOps:
         gid = gid0 + torch.arange(max(Rl, 1), dtype=torch.int64)
         return mu, gid
 
+    def chol_inv(self, G, rel_tol=1e-12):
+        self._count("chol_inv")
+        q = G.shape[0]
+        L, inf = torch.linalg.cholesky_ex(G)
+        bad = int(inf.item())
+        d = torch.diagonal(L)
+        if bad == 0 and bool((d * d <= rel_tol * torch.diagonal(G).max()).any()):
+            bad = int(torch.nonzero(d * d <= rel_tol * torch.diagonal(G).max())[0]) + 1
+        info = torch.tensor([bad], dtype=torch.int32)
+        if bad:
+            return torch.zeros(q, q, dtype=torch.float64), info
+        W = torch.linalg.solve_triangular(L, torch.eye(q, dtype=torch.float64), upper=False).T.contiguous()
+        G.copy_(torch.tril(L) + torch.triu(G, 1))
+        return W, info
+
     def matmul(self, A, B):
         return torch.matmul(A, B)
 

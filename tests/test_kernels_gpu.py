@@ -195,3 +195,25 @@ def test_no_cpu_path():
     with pytest.raises(BasqHipError):
         basq_amd.recombination(torch.zeros(10, 2), torch.zeros(5, 2), 3, basq_amd.kernels.StationaryKernel("rbf", 1.0),
                                torch.device("cpu"))
+
+
+@pytest.mark.parametrize("q", [5, 99, 199, 300])
+def test_chol_inv(hip_ops, q):
+    """CholeskyQR building block: L L^T = G and (X W)^T (X W) = I."""
+    X = _rand(4 * q + 7, q, 20 + q)
+    G = X.T @ X
+    Gd = hip_ops.to_device(G.clone())
+    W, info = hip_ops.chol_inv(Gd)
+    assert int(info.cpu()[0]) == 0
+    L = torch.tril(Gd.cpu())
+    assert (L @ L.T - G).abs().max().item() <= 1e-12 * G.abs().max().item()
+    Q = X @ W.cpu()
+    assert (Q.T @ Q - torch.eye(q, dtype=torch.float64)).abs().max().item() <= 1e-10
+    assert torch.equal(torch.tril(W.cpu(), -1), torch.zeros(q, q, dtype=torch.float64))
+
+
+def test_chol_inv_flags_rank_deficiency(hip_ops):
+    X = _rand(50, 8, 3)
+    X[:, 7] = X[:, 0] + X[:, 1]              # exactly dependent column
+    _, info = hip_ops.chol_inv(hip_ops.to_device(X.T @ X))
+    assert int(info.cpu()[0]) == 8
