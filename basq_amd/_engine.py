@@ -60,8 +60,9 @@ class TorchDistComm:
         self.world = dist.get_world_size(group)
 
     def all_gather(self, t):
+        """-> ``[world, *t.shape]`` (rank order).  Messages are tiny ((q+1) x S doubles): latency-bound."""
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        self.dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+        self.dist.all_gather(list(out.unbind(0)), t.contiguous(), group=self.group)
         return out
 
     def broadcast(self, t, src=0):

@@ -590,6 +590,9 @@ __global__ void setsum_kernel(const double* __restrict__ mu, double* __restrict_
 #ifndef BASQ_ST
 #define BASQ_ST 20   // sets per wave
 #endif
+#ifndef BASQ_VALU_MAX_KK
+#define BASQ_VALU_MAX_KK 3
+#endif
 #ifndef BASQ_TJ
 #define BASQ_TJ 1    // Nystrom rows per lane
 #endif
@@ -633,13 +636,9 @@ static int dispatch_blocksum_valu(int kk, int fam, const BlocksumArgs& A, hipStr
         case 1: return dispatch_blocksum_valu_fam<1>(fam, A, st);
         case 2: return dispatch_blocksum_valu_fam<2>(fam, A, st);
         case 3: return dispatch_blocksum_valu_fam<3>(fam, A, st);
+#if BASQ_VALU_MAX_KK >= 4
         case 4: return dispatch_blocksum_valu_fam<4>(fam, A, st);
-        case 5: return dispatch_blocksum_valu_fam<5>(fam, A, st);
-        case 6: return dispatch_blocksum_valu_fam<6>(fam, A, st);
-        case 7: return dispatch_blocksum_valu_fam<7>(fam, A, st);
-        case 8: return dispatch_blocksum_valu_fam<8>(fam, A, st);
-        case 9: return dispatch_blocksum_valu_fam<9>(fam, A, st);
-        case 10: return dispatch_blocksum_valu_fam<10>(fam, A, st);
+#endif
     }
     return BASQ_EUNSUPPORTED;
 }
@@ -1105,8 +1104,11 @@ static int blocksum_impl(const basq_kernel_spec* spec, const double* nys, int32_
     const long long nblk = A.blk_hi - A.blk_lo;
     A.blk_per_chunk = (nblk + n_chunks - 1) / n_chunks;
     if (A.blk_per_chunk < 1) A.blk_per_chunk = 1;
-    if (use_mfma) return dispatch_blocksum(basq_kp(spec->d) / 4, spec->family, A, (hipStream_t)stream);
-    return dispatch_blocksum_valu(basq_kp(spec->d) / 4, spec->family, A, (hipStream_t)stream);
+    // VALU form while two candidate rows fit the SGPR budget without spills (KP <= 12, i.e. d <= 10: audited by
+    // tools/audit_isa.py); the MFMA form (operands in VGPRs) beyond.
+    const int kk = basq_kp(spec->d) / 4;
+    if (use_mfma || kk > BASQ_VALU_MAX_KK) return dispatch_blocksum(kk, spec->family, A, (hipStream_t)stream);
+    return dispatch_blocksum_valu(kk, spec->family, A, (hipStream_t)stream);
 }
 
 int basq_blocksum_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,

@@ -1,0 +1,103 @@
+"""The C-ABI library: builds for gfx950, loads, and exports every symbol include/basq_hip.h declares.
+No compute call is made (no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from basq_amd import _build
+
+    if not os.path.exists(_build.LIB):
+        try:
+            _build.build(verbose=False)
+        except Exception as e:                       # pragma: no cover
+            pytest.fail(f"could not build the HIP library: {e}")
+    return _build.LIB
+
+
+def _declared():
+    header = open(os.path.join(ROOT, "include", "basq_hip.h")).read()
+    names = set(re.findall(r"\b(basq_[a-z0-9_]+)\s*\(", header))
+    return names
+
+
+def test_header_symbols_exported(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    missing = [n for n in sorted(_declared()) if not hasattr(lib, n)]
+    assert not missing, f"library does not export {missing}"
+
+
+def test_binding_covers_header(lib_path):
+    from basq_amd import _lib
+
+    assert _declared() == set(_lib.SIGNATURES), "ctypes prototypes and include/basq_hip.h disagree"
+    lib = _lib.load()
+    assert lib.basq_abi_version() == _lib.ABI_VERSION
+    assert lib.basq_strerror(0) == b"ok" and lib.basq_strerror(-1) == b"invalid argument"
+    assert [lib.basq_kp(d) for d in (1, 2, 3, 10, 32, 38)] == [4, 4, 8, 12, 36, 40]
+    assert lib.basq_kp(0) < 0 and lib.basq_kp(39) < 0
+
+
+def test_argument_validation_without_gpu(lib_path):
+    """Entry points reject bad arguments before touching the device."""
+    from basq_amd import _lib
+
+    lib = _lib.load()
+    spec = _lib.KernelSpecC(0, 10, 2.0, 1.0)
+    assert lib.basq_pack_points_f64(ctypes.byref(spec), None, 5, None, 0, None, None) == -1
+    assert lib.basq_blocksum_f64(ctypes.byref(spec), None, 1, None, None, None, 1, 0, 0, 1, 1, None, None, None) == -1
+    bad = _lib.KernelSpecC(7, 10, 2.0, 1.0)
+    assert lib.basq_gram_f64(ctypes.byref(bad), None, 1, None, 1, None, 1, None) == -1
+    assert lib.basq_car_eliminate_f64(None, None, 2000, 10, None, None, None, None, None) == -1
+
+
+def test_product_has_no_cpu_path():
+    import torch
+
+    import basq_amd
+    from basq_amd._lib import BasqHipError
+
+    with pytest.raises(BasqHipError):
+        basq_amd.recombination(torch.zeros(10, 2), torch.zeros(5, 2), 3, basq_amd.kernels.StationaryKernel("rbf", 1.0),
+                               torch.device("cpu"))
+    with pytest.raises(TypeError):
+        basq_amd.recombination(torch.zeros(10, 2), torch.zeros(5, 2), 3, lambda a, b: a @ b.T, torch.device("cuda"))
+
+
+def test_product_does_not_import_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, "basq_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+                assert "tests.cpu_stand_in" not in src
+
+
+def test_isa_audit_of_scalar_load_kernel():
+    """The inline-asm s_load pipeline of blocksum_valu_kernel: no instruction may touch an SGPR whose load is
+    still in flight (tools/audit_isa.py).  Checks the auditor on a synthetic violation, then the real build."""
+    import importlib.util
+    import shutil
+    import tempfile
+
+    spec = importlib.util.spec_from_file_location("audit_isa", os.path.join(ROOT, "tools", "audit_isa.py"))
+    audit_isa = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(audit_isa)
+    fake = ("_Z20blocksum_valu_kernelILi1EE: ; @x\n\ts_load_dwordx8 s[8:15], s[2:3], 32\n\tv_writelane_b32 v1, s9, 0\n"
+            "\ts_waitcnt lgkmcnt(0)\n\tv_fma_f64 v[0:1], s[8:9], v[2:3], v[4:5]\n\ts_endpgm\n")
+    seen, problems = audit_isa.audit(fake)
+    assert seen == 1 and len(problems) == 1 and "in-flight" in problems[0]
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    with tempfile.TemporaryDirectory() as d:
+        asm = audit_isa.compile_to_asm(d)
+    seen, problems = audit_isa.audit(asm)
+    assert seen >= 18 and not problems, problems[:3]

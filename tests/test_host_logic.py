@@ -1,0 +1,114 @@
+"""Host logic of the engine on the CPU (stand-in device ops): round geometry, closed-form compaction
+targets, chunking, and the whole engine against the reference's golden vectors."""
+import random
+
+import pytest
+import torch
+
+from basq_amd._engine import EngineTrace, RecombinationEngine
+from basq_amd._partition import (RoundGeometry, choose_chunks, initial_shards, local_blocks, next_shard,
+                                 survivors_before)
+from tests.cases import BY_NAME, CASES, build_pool, build_product_kernel, has_golden, load_golden
+from tests.cpu_stand_in import CpuStandInOps
+
+ENGINE_CASES = [c["name"] for c in CASES if not c["slow"] and c["N"] <= 30_000 and c["kernel"]["warp"] != "wsabim"]
+
+
+def test_round_geometry_and_survivor_counts_brute_force():
+    rng = random.Random(0)
+    for _ in range(200):
+        S = rng.choice([4, 10, 22, 200])
+        R = rng.randint(S + 1, 40 * S)
+        geo = RoundGeometry.of(R, S)
+        kept = sorted(rng.sample(range(S), rng.randint(1, S // 2)))
+        # brute force: which positions survive, in order
+        surv = [p for p in range(R) if ((p % S if p < geo.n_full else S - 1) in kept)]
+        for P in [0, 1, S - 1, S, geo.n_full - 1, geo.n_full, R - 1, R, rng.randint(0, R)]:
+            assert survivors_before(P, geo, kept) == sum(1 for p in surv if p < P)
+        # any contiguous sharding tiles the survivors without gaps
+        cuts = sorted(rng.sample(range(R + 1), 3)) + [R]
+        off, acc = 0, 0
+        for c in cuts:
+            no, nr = next_shard(off, c - off, geo, kept)
+            assert no == acc
+            acc += nr
+            off = c
+        assert acc == len(surv)
+
+
+def test_initial_shards_tile_the_pool():
+    for N, w in [(10, 3), (1_000_000, 8), (7, 8), (100, 1)]:
+        sh = initial_shards(N, w)
+        assert sh[0][0] == 0 and sum(n for _, n in sh) == N
+        for (o1, n1), (o2, _) in zip(sh[:-1], sh[1:]):
+            assert o1 + n1 == o2
+
+
+def test_choose_chunks_bounds():
+    for nb, m, S in [(5000, 10000, 200), (3, 100, 200), (0, 100, 200), (40, 5000, 400)]:
+        c = choose_chunks(nb, m, S)
+        assert 1 <= c <= 32 and (nb == 0 or c <= max(1, nb // 4))
+    geo = RoundGeometry.of(1000, 200)
+    assert local_blocks(0, 1000, geo) == 5 and local_blocks(150, 300, geo) == 3 and local_blocks(1000, 0, geo) == 0
+
+
+@pytest.mark.parametrize("name", ENGINE_CASES)
+def test_engine_host_logic_reproduces_golden(name):
+    """Fused formulation (block sums -> contraction -> reduction -> closed-form compaction, posterior and
+    WSABI-L folded in by linearity) selects exactly the reference's points."""
+    if not has_golden(name):
+        pytest.skip("fixture not generated")
+    c, fx = BY_NAME[name], load_golden(name)
+    pts, nys = build_pool(c)
+    tr = EngineTrace()
+    torch.manual_seed(c["torch_seed"])
+    idx, w = RecombinationEngine(CpuStandInOps()).run(pts, 0, c["N"], nys, c["n"], build_product_kernel(c), tr)
+    assert idx.tolist() == fx["idx"]
+    gw = torch.tensor(fx["w"], dtype=torch.float64)
+    assert ((w - gw).abs() / gw).max().item() <= 1e-6 if len(gw) else True
+    assert [r["kept"] for r in tr.rounds] == [r["kept"] for r in fx["rounds"]]
+
+
+def test_gpu_range_finder_equals_host_householder():
+    """CholeskyQR2 range finder vs the reference-style host Householder path: same selection."""
+    import basq_amd._engine as E
+
+    c = BY_NAME["rbf_2e4_defaults"]
+    pts, nys = build_pool(c)
+    out = []
+    for flag in (True, False):
+        E.GPU_RANGE_FINDER = flag
+        try:
+            torch.manual_seed(c["torch_seed"])
+            out.append(RecombinationEngine(CpuStandInOps()).run(pts, 0, c["N"], nys, c["n"], build_product_kernel(c)))
+        finally:
+            E.GPU_RANGE_FINDER = True
+    assert out[0][0].tolist() == out[1][0].tolist()
+    assert ((out[0][1] - out[1][1]).abs() / out[1][1]).max().item() < 1e-8
+
+
+def test_rank_deficient_panel_falls_back():
+    """m < q: the Gaussian sketch has more columns than rows -> Cholesky pivot flag -> host QR path."""
+    c = BY_NAME["rbf_direct_car"]
+    fx = load_golden("rbf_direct_car")
+    pts, nys = build_pool(c)
+    tr = EngineTrace()
+    torch.manual_seed(c["torch_seed"])
+    idx, _ = RecombinationEngine(CpuStandInOps()).run(pts, 0, c["N"], nys, c["n"], build_product_kernel(c), tr)
+    assert idx.tolist() == fx["idx"]
+
+
+def test_wsabim_is_refused_loudly():
+    c = BY_NAME["wsabim_1e4"]
+    pts, nys = build_pool(c)
+    with pytest.raises(NotImplementedError):
+        RecombinationEngine(CpuStandInOps()).run(pts, 0, c["N"], nys, c["n"], build_product_kernel(c))
+
+
+def test_pool_generator_is_stable():
+    from basq_amd.pools import gmm_pool, pool_digest
+
+    assert pool_digest(gmm_pool(1000, 2, 0)) == "0ca4cf438cd9339c6c0ff0b20293140af7cac1ada050d2bfae7a01af912268f7"
+    a, b = gmm_pool(70_000, 3, 5), gmm_pool(70_000, 3, 5)
+    assert torch.equal(a, b) and a.dtype == torch.float64
+    assert abs(a.mean().item()) < 3.0 and 0.5 < a.std().item() < 4.0
