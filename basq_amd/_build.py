@@ -16,6 +16,7 @@ LIB = os.path.join(CSRC, "libbasq_hip.so")
 SOURCES = ["basq_hip.hip"]
 DEPS = ["exp_coeffs.inc", os.path.join("..", "..", "include", "basq_hip.h")]
 ARCH = "gfx950"
+EXTRA_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def hipcc_path() -> str:
@@ -37,8 +38,11 @@ def build(force: bool = False, verbose: bool = True, defines: dict | None = None
     target = out or LIB
     if not force and out is None and not needs_build():
         return LIB
+    # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (no v_accvgpr_read per kernel value; the block sums
+    # consume every MFMA result on the VALU right away and have registers to spare)
     cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-o", target] + [os.path.join(CSRC, s) for s in SOURCES]
+           "-Wall", "-Wno-unused-function", "-Wno-unused-const-variable"] + EXTRA_FLAGS + ["-o", target] + \
+          [os.path.join(CSRC, s) for s in SOURCES]
     for k, v in (defines or {}).items():
         cmd.append(f"-D{k}={v}")
     if verbose:

@@ -110,14 +110,18 @@ class _Timer:
 
 # Host LAPACK calls on small matrices (100 x 200 SVD, 1e4 x 99 QR) are slower, not faster, on a many-core
 # host with every core in the team (measured: 30 ms per 100x200 gesdd with 128 threads vs ~2 ms with 8).
-HOST_LAPACK_THREADS = 8
+HOST_LAPACK_THREADS = 8          # tall QR of the fallback path
+HOST_SVD_THREADS = 1             # 100x200 / 99x99 SVDs: fastest single-threaded (profiles/r01_host_lapack_threads.txt)
 
 
 class _lapack_threads:
+    def __init__(self, n=None):
+        self.n = n or HOST_LAPACK_THREADS
+
     def __enter__(self):
         self.prev = torch.get_num_threads()
-        if self.prev > HOST_LAPACK_THREADS:
-            torch.set_num_threads(HOST_LAPACK_THREADS)
+        if self.prev > self.n:
+            torch.set_num_threads(self.n)
         return self
 
     def __exit__(self, *exc):
@@ -136,13 +140,15 @@ def _host_qr_q(ops, X, trace=None):
         return ops.to_device(Qh)
 
 
-def _cholqr2(ops, X, flags):
-    """Orthonormal basis of range(X) ([m,k], k <= m) by two CholeskyQR passes, entirely on the GPU.
+def _cholqr(ops, X, flags, passes=2):
+    """Basis of range(X) ([m,k], k <= m) by CholeskyQR passes, entirely on the GPU.
 
-    ``X^T X = L L^T``, ``Q = X L^{-T}``; the second pass restores orthogonality to round-off whenever
-    cond(X) < ~1e7.  The pivot flags (device int32) are appended to ``flags`` and checked once, later.
+    ``X^T X = L L^T``, ``Q = X L^{-T}``; with two passes Q is orthonormal to round-off whenever
+    cond(X) < ~1e7 (needed for the final basis); one pass (orthonormal to ~cond^2 eps, i.e. perfectly
+    conditioned for the next multiplication by A) is enough for the intermediate subspace iterates, whose
+    only role is their range.  The pivot flags (device int32) are appended to ``flags`` and checked once, later.
     """
-    for _ in range(2):
+    for _ in range(passes):
         G = ops.matmul(X.t(), X)
         W, info = ops.chol_inv(G)
         flags.append(info)
@@ -176,10 +182,11 @@ def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None):
     if GPU_RANGE_FINDER and q_req <= m:
         with _Timer(ops, trace, "basis.gpu_range"):
             flags = []
-            Q = _cholqr2(ops, ops.matmul(A, R), flags)
-            for _ in range(2):
-                Q = _cholqr2(ops, ops.matmul(At, Q), flags)
-                Q = _cholqr2(ops, ops.matmul(A, Q), flags)
+            Q = _cholqr(ops, ops.matmul(A, R), flags, passes=1)
+            Q = _cholqr(ops, ops.matmul(At, Q), flags, passes=1)
+            Q = _cholqr(ops, ops.matmul(A, Q), flags, passes=1)
+            Q = _cholqr(ops, ops.matmul(At, Q), flags, passes=1)
+            Q = _cholqr(ops, ops.matmul(A, Q), flags, passes=2)      # the basis that is actually used
             B = ops.matmul(Q.t(), A)                           # [k, m]
             # LQ of B (CholeskyQR2 on its rows):  B = L1 L2 Qb^T  ->  left singular vectors of B = those of L
             G1 = ops.matmul(B, B.t())
@@ -193,7 +200,7 @@ def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None):
             Lh = L.cpu()                                       # one synchronisation for the whole range finder
             ok = int(bad.item()) == 0
             if ok:
-                with _lapack_threads():
+                with _lapack_threads(HOST_SVD_THREADS):
                     Ub = torch.linalg.svd(Lh)[0]
         if ok:
             with _Timer(ops, trace, "basis.gemm"):
@@ -248,47 +255,17 @@ class RecombinationEngine:
         t_all = time.perf_counter()
 
         center = ops.col_mean(pts_nys)
-
-        # ---- Nystrom basis: rank 0 computes, everyone receives (one randn draw, as in the reference) ----
-        t0 = time.perf_counter()
-        if comm.rank == 0:
-            with _Timer(ops, trace, "basis.gram"):
-                A = kernel.dense(ops, pts_nys, pts_nys, center)
-            U = nystrom_basis(ops, A, num_pts - 1, trace)
-            del A
-            qbuf = torch.tensor([U.shape[0]], dtype=torch.int64, device=U.device)
-        else:
-            qbuf = ops.zeros(1, dtype=torch.int64)
-        if comm.world > 1:
-            comm.broadcast(qbuf)
-            if comm.rank != 0:
-                U = ops.empty(int(qbuf.item()), m)
-            comm.broadcast(U)
-        q = U.shape[0]
+        q = min(num_pts - 1, m)                                 # rank of svd_lowrank's output (reduced QR clips at m)
         s = q + 1
         S = 2 * s                                               # :50
-        if trace is not None:
-            if trace.host_sync:
-                ops.synchronize()
-            trace.add_time("basis", time.perf_counter() - t0)
-            if trace.keep_tensors:
-                trace.U = U.clone()
 
-        # ---- extended operands: posterior correction / warping folded into the contraction -----------
+        # ---- Nystrom-side operands of the block sums (no dependence on the basis) ----------------------
+        t0 = time.perf_counter()
         nys_rows = [pts_nys]
-        Um = U
-        mu_pt = None
-        if warp != "none":
-            mu_pt = kernel.mean(ops, pts_nys, center)
-            Um = (U * mu_pt.unsqueeze(0)).contiguous()
-        U_cols = [Um]
         diag_noise, n_obs = 0.0, 0
         if post is not None:
             Xo = ops.to_device(post.Xobs, torch.float64)
-            W = ops.to_device(post.W, torch.float64)
             n_obs = Xo.shape[0]
-            Bmat = base.dense(ops, pts_nys, Xo, center) @ W      # [m, n_obs] (small rocBLAS GEMM)
-            U_cols.append(-(Um @ Bmat))
             nys_rows.append(Xo)
             diag_noise = post.noise
         m_ext = m + n_obs
@@ -307,6 +284,56 @@ class RecombinationEngine:
             nys_ext = torch.cat([nys_ext, ops.zeros(64, kp)], 0)
         if wrow:
             nys_ext[zero_row_idx].zero_()
+
+        # ---- candidate state ---------------------------------------------------------------------------
+        cand = ops.pack(spec, pts_local, center, ROLE_B)
+        mu, gid = ops.init_state(Rl, gid0, n_total)
+        wx = None
+        if warp != "none":
+            wx = kernel.mean(ops, pts_local, center) if Rl > 0 else ops.empty(1)
+        off, R = gid0, n_total
+
+        # ---- round-1 block sums are queued BEFORE the basis: they do not depend on U, and the ~12 ms CPU
+        #      randn of the range finder then overlaps with the largest kernel of the batch ----------------
+        pre = None
+        if R > S:
+            geo = RoundGeometry.of(R, S)
+            n_chunks = choose_chunks(local_blocks(off, Rl, geo), m_ext, S)
+            ev0 = ops.record_event() if (trace is not None and trace.time_kernels) else None
+            Xpart, totpart = ops.blocksum(spec, nys_ext, m_ext, cand, mu, wx, Rl, off, geo.n_full, S, n_chunks)
+            if ev0 is not None:
+                trace.kernel_events.append((ev0, ops.record_event(), dict(pairs=float(Rl) * m_ext, R=Rl, m=m_ext, S=S,
+                                                                         chunks=n_chunks)))
+            pre = (Xpart, totpart, n_chunks)
+
+        # ---- Nystrom basis: rank 0 computes, everyone receives (one randn draw, as in the reference) ----
+        if comm.rank == 0:
+            with _Timer(ops, trace, "basis.gram"):
+                A = kernel.dense(ops, pts_nys, pts_nys, center)
+            U = nystrom_basis(ops, A, num_pts - 1, trace)
+            del A
+            assert U.shape[0] == q
+        else:
+            U = ops.empty(q, m)
+        if comm.world > 1:
+            comm.broadcast(U)
+        if trace is not None:
+            if trace.host_sync:
+                ops.synchronize()
+            trace.add_time("basis", time.perf_counter() - t0)
+            if trace.keep_tensors:
+                trace.U = U.clone()
+
+        # ---- extended contraction matrix: posterior correction / warping folded in by linearity --------
+        Um = U
+        if warp != "none":
+            mu_pt = kernel.mean(ops, pts_nys, center)
+            Um = (U * mu_pt.unsqueeze(0)).contiguous()
+        U_cols = [Um]
+        if post is not None:
+            W = ops.to_device(post.W, torch.float64)
+            Bmat = base.dense(ops, pts_nys, Xo, center) @ W      # [m, n_obs] (small rocBLAS GEMM)
+            U_cols.append(-(Um @ Bmat))
         U_ext = torch.cat(U_cols, 1) if len(U_cols) > 1 else Um
         if wrow:
             sel = ops.zeros(1, m_ext)
@@ -314,14 +341,6 @@ class RecombinationEngine:
             U_ext[q, zero_row_idx] = 1.0 / spec.outputscale
         U_ext = U_ext.contiguous()
         diagU = Um if diag_noise != 0.0 else None
-
-        # ---- candidate state --------------------------------------------------------------------------
-        cand = ops.pack(spec, pts_local, center, ROLE_B)
-        mu, gid = ops.init_state(Rl, gid0, n_total)
-        wx = None
-        if warp != "none":
-            wx = kernel.mean(ops, pts_local, center) if Rl > 0 else ops.empty(1)
-        off, R = gid0, n_total
         if trace is not None:
             if trace.host_sync:
                 ops.synchronize()
@@ -338,13 +357,18 @@ class RecombinationEngine:
             S_r = R if final else S
             geo = RoundGeometry.of(R, S_r)
             t0 = time.perf_counter()
-            n_chunks = choose_chunks(local_blocks(off, Rl, geo), m_ext, S_r)
-            ev0 = ops.record_event() if (trace is not None and trace.time_kernels) else None
-            with _Timer(ops, trace, "blocksum"):
-                Xpart, totpart = ops.blocksum(spec, nys_ext, m_ext, cand, mu, wx, Rl, off, geo.n_full, S_r, n_chunks)
-            if ev0 is not None:
-                trace.kernel_events.append((ev0, ops.record_event(), dict(pairs=float(Rl) * m_ext, R=Rl, m=m_ext, S=S_r,
-                                                                         chunks=n_chunks)))
+            if pre is not None:
+                Xpart, totpart, n_chunks = pre
+                pre = None
+            else:
+                n_chunks = choose_chunks(local_blocks(off, Rl, geo), m_ext, S_r)
+                ev0 = ops.record_event() if (trace is not None and trace.time_kernels) else None
+                with _Timer(ops, trace, "blocksum"):
+                    Xpart, totpart = ops.blocksum(spec, nys_ext, m_ext, cand, mu, wx, Rl, off, geo.n_full, S_r,
+                                                  n_chunks)
+                if ev0 is not None:
+                    trace.kernel_events.append((ev0, ops.record_event(), dict(pairs=float(Rl) * m_ext, R=Rl, m=m_ext,
+                                                                             S=S_r, chunks=n_chunks)))
             with _Timer(ops, trace, "project"):
                 msg = ops.project(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S_r, spec.outputscale)
             if trace is not None:
@@ -359,7 +383,7 @@ class RecombinationEngine:
                 XcarT, tot = ops.finalize(parts, comm.world, q_ext + 1, q, S_r, diagU, m, min(m, S_r), diag_noise, wrow)
                 t1 = time.perf_counter()
                 Xh = XcarT.cpu()
-                with _lapack_threads():
+                with _lapack_threads(HOST_SVD_THREADS):
                     Vh = torch.linalg.svd(Xh)[2]                 # :140 full SVD of [s, M] on host LAPACK
                 PhiT = ops.to_device(Vh[-(M - s):, :])           # :143 (rows = null-space vectors)
                 if trace is not None:

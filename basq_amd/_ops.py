@@ -102,7 +102,7 @@ class HipOps:
                                               _ptr(out), self._stream()), "basq_kernel_matvec_f64")
         return out
 
-    def blocksum(self, spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, impl="valu"):
+    def blocksum(self, spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, impl="mfma"):
         Xpart = self.empty(n_chunks, m, S)
         totpart = self.empty(n_chunks, S)
         if Rl == 0:
@@ -110,7 +110,7 @@ class HipOps:
             totpart.zero_()
             return Xpart, totpart
         sc = self.spec_c(spec)
-        fn = self.lib.basq_blocksum_f64 if impl == "valu" else self.lib.basq_blocksum_mfma_f64
+        fn = self.lib.basq_blocksum_f64 if impl == "mfma" else self.lib.basq_blocksum_valu_f64
         check(fn(C.byref(sc), _ptr(nys), m, _ptr(cand), _ptr(mu), _ptr(wx), Rl, off, n_full, S, n_chunks, _ptr(Xpart),
                  _ptr(totpart), self._stream()), "basq_blocksum_f64")
         return Xpart, totpart
@@ -118,8 +118,8 @@ class HipOps:
     def project(self, U, q, m, Xpart, totpart, n_chunks, S, outputscale, ksplit=None):
         self._chk(U)
         if ksplit is None:
-            ksplit = max(1, min(64 // n_chunks, m // 128))
-        work = self.empty(n_chunks * ksplit, q, S)
+            ksplit = max(1, min(48, m // 128))
+        work = self.empty((m * S if n_chunks > 1 else 0) + ksplit * q * S)
         out = self.empty(q + 1, S)
         check(self.lib.basq_project_f64(_ptr(U), q, m, _ptr(Xpart), _ptr(totpart), n_chunks, S, float(outputscale),
                                         ksplit, _ptr(work), _ptr(out), self._stream()), "basq_project_f64")

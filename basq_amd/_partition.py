@@ -70,9 +70,9 @@ def local_blocks(off: int, Rl: int, geo: RoundGeometry) -> int:
     return (lim + geo.S - 1) // geo.S - off // geo.S
 
 
-# Launch geometry of the block-sum kernels (must mirror basq_hip.hip): a wave covers 64 Nystrom rows x
+# Launch geometry of the block-sum kernel (must mirror basq_hip.hip): a wave covers 64 Nystrom rows x
 # SETS_PER_WAVE sets, 4 waves per work-group; RESIDENT_WAVES = 256 CUs x 4 SIMDs x 3 waves (register-limited).
-SETS_PER_WAVE = 20
+SETS_PER_WAVE = 16
 RESIDENT_WAVES = 256 * 4 * 3
 
 

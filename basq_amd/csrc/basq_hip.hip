@@ -50,11 +50,26 @@ __device__ __forceinline__ double exp_nonpos(double x) {
     return __hiloint2double(hi, __double2loint(p));
 }
 
-// The same evaluation with every constant held in a VGPR (one copy per lane).  The blocksum kernel keeps
-// two candidate rows (2 x 26 SGPRs at d=10) in scalar registers; the 15 fp64 literals of exp would
-// otherwise claim 30 more SGPRs and push the rows into v_writelane spills.
+// Block-sum forms of exp (constants pinned in VGPRs: the scalar-broadcast kernel keeps two candidate rows,
+// 2 x 26 SGPRs at d = 10, in scalar registers; fp64 literals would claim 20-30 more SGPRs and push the rows
+// into v_writelane spills).  BASQ_EXP_MODE selects the evaluation (A/B-measured, tools/bench_blocksum.py):
+//   0  x = n ln2 + r, degree-10 polynomial, 2^n by ldexp                        (14 fp64 VALU, no memory)
+//   1  x = (32n + j) ln2/32 + r, T[j] = 2^(j/32) from a 256-B LDS table (one bank row: conflict-free),
+//      degree-5 polynomial                                                       (11 fp64 VALU + ds_read)
+//   2  the same with the table in global memory (L1-resident; vmcnt instead of lgkmcnt, so the wait for
+//      the table value does not drain the in-flight scalar loads of the next candidate row)
+#ifndef BASQ_EXP_MODE
+#define BASQ_EXP_MODE 1
+#endif
+
+__device__ const double basq_exp_tab_g[32] = BASQ_EXP_TAB;
+
 struct ExpK {
-    double log2e, nln2hi, nln2lo, magic, p[11];
+#if BASQ_EXP_MODE == 0
+    double log2e, nhi, nlo, magic, p[11];
+#else
+    double k32, nhi, nlo, magic, c5, c4, c3, c2, one;
+#endif
 };
 
 __device__ __forceinline__ double vgpr_const(double x) {
@@ -63,28 +78,63 @@ __device__ __forceinline__ double vgpr_const(double x) {
 }
 
 __device__ __forceinline__ void expk_init(ExpK& k) {
-    k.log2e = vgpr_const(BASQ_LOG2E);
-    k.nln2hi = vgpr_const(-BASQ_LN2_HI);
-    k.nln2lo = vgpr_const(-BASQ_LN2_LO);
     k.magic = vgpr_const(0x1.8p52);
+#if BASQ_EXP_MODE == 0
+    k.log2e = vgpr_const(BASQ_LOG2E);
+    k.nhi = vgpr_const(-BASQ_LN2_HI);
+    k.nlo = vgpr_const(-BASQ_LN2_LO);
     const double c[11] = {BASQ_EXP_P0, BASQ_EXP_P1, BASQ_EXP_P2, BASQ_EXP_P3, BASQ_EXP_P4, BASQ_EXP_P5,
                           BASQ_EXP_P6, BASQ_EXP_P7, BASQ_EXP_P8, BASQ_EXP_P9, BASQ_EXP_P10};
 #pragma unroll
     for (int i = 0; i < 11; ++i) k.p[i] = vgpr_const(c[i]);
+#else
+    k.k32 = vgpr_const(BASQ_32_OVER_LN2);
+    k.nhi = vgpr_const(-BASQ_LN2_32_HI);
+    k.nlo = vgpr_const(-BASQ_LN2_32_LO);
+    k.c5 = vgpr_const(BASQ_EXP_T5);
+    k.c4 = vgpr_const(BASQ_EXP_T4);
+    k.c3 = vgpr_const(BASQ_EXP_T3);
+    k.c2 = vgpr_const(BASQ_EXP_T2);
+    k.one = vgpr_const(1.0);
+#endif
 }
 
-__device__ __forceinline__ double exp_nonpos_k(double x, const ExpK& k) {
+// `tab` = LDS copy of the table (exp_table_init); valid for -1.4e9 < x <= ~1, exact 0 below ~-745.
+__device__ __forceinline__ double exp_nonpos_k(double x, const ExpK& k, const double* tab) {
+#if BASQ_EXP_MODE == 0
     const double t = __builtin_fma(x, k.log2e, k.magic);
     const double nf = t - k.magic;
-    double r = __builtin_fma(nf, k.nln2hi, x);
-    r = __builtin_fma(nf, k.nln2lo, r);
+    double r = __builtin_fma(nf, k.nhi, x);
+    r = __builtin_fma(nf, k.nlo, r);
     double p = k.p[10];
 #pragma unroll
     for (int i = 9; i >= 0; --i) p = __builtin_fma(p, r, k.p[i]);
-    const int n = __double2loint(t);
-    int hi = __double2hiint(p) + (n << 20);
-    hi = (n < -1021) ? 0 : hi;
-    return __hiloint2double(hi, __double2loint(p));
+    return ldexp(p, __double2loint(t));
+#else
+    const double t = __builtin_fma(x, k.k32, k.magic);
+    const int ti = __double2loint(t);                 // 32 n + j  (two's complement)
+#if BASQ_EXP_MODE == 1
+    const double T = tab[ti & 31];
+#else
+    const double T = basq_exp_tab_g[ti & 31];
+#endif
+    const double nf = t - k.magic;
+    double r = __builtin_fma(nf, k.nhi, x);
+    r = __builtin_fma(nf, k.nlo, r);
+    double w = __builtin_fma(k.c5, r, k.c4);
+    w = __builtin_fma(w, r, k.c3);
+    w = __builtin_fma(w, r, k.c2);
+    w = __builtin_fma(w, r, k.one);
+    const double e = __builtin_fma(T * r, w, T);      // T (1 + r w)
+    return ldexp(e, ti >> 5);
+#endif
+}
+
+__device__ __forceinline__ void exp_table_init(double* tab) {
+#if BASQ_EXP_MODE == 1
+    if (threadIdx.x < 32) tab[threadIdx.x] = basq_exp_tab_g[threadIdx.x];
+    __syncthreads();
+#endif
 }
 
 // Kernel value (without outputscale) from D = -1/2 |(x-y)/l|^2.
@@ -107,19 +157,19 @@ __device__ __forceinline__ double kernel_from_arg(double D) {
 }
 
 template <int FAM>
-__device__ __forceinline__ double kernel_from_arg_k(double D, const ExpK& k) {
+__device__ __forceinline__ double kernel_from_arg_k(double D, const ExpK& k, const double* tab) {
     if (FAM == BASQ_FAMILY_RBF) {
-        return exp_nonpos_k(D, k);
+        return exp_nonpos_k(D, k, tab);
     } else {
         const double r2 = fmax(-2.0 * D, 1e-30);
         const double r = sqrt(r2);
         if (FAM == BASQ_FAMILY_MATERN52) {
             const double a = 0x1.1e3779b97f4a8p+1 * r;
             const double poly = (a + 1.0) + (5.0 / 3.0) * r2;
-            return poly * exp_nonpos_k(-a, k);
+            return poly * exp_nonpos_k(-a, k, tab);
         } else {
             const double a = 0x1.bb67ae8584caap+0 * r;
-            return (a + 1.0) * exp_nonpos_k(-a, k);
+            return (a + 1.0) * exp_nonpos_k(-a, k, tab);
         }
     }
 }
@@ -221,14 +271,15 @@ __device__ __forceinline__ void load_cand(CandFrag<KK>& f, const BlocksumArgs& A
 }
 
 template <int KK, int FAM, int JT>
-__device__ __forceinline__ void tile_accumulate(const double (&a)[JT][KK], const CandFrag<KK>& f, double (&acc)[JT][4]) {
+__device__ __forceinline__ void tile_accumulate(const double (&a)[JT][KK], const CandFrag<KK>& f, double (&acc)[JT][4],
+                                                const ExpK& ek, const double* tab) {
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) {
         d4 D = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) D = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt][kk], f.b[kk], D, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[jt][r] = __builtin_fma(kernel_from_arg<FAM>(D[r]), f.w, acc[jt][r]);
+        for (int r = 0; r < 4; ++r) acc[jt][r] = __builtin_fma(kernel_from_arg_k<FAM>(D[r], ek, tab), f.w, acc[jt][r]);
     }
 }
 
@@ -243,8 +294,12 @@ __global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A) {
     const int chunk = b % A.n_chunks;
     const int jg = b / A.n_chunks;
     const int j0 = (jg * 4 + wave) * (16 * JT);
-    if (j0 >= A.m) return;   // wave-uniform; no barriers in this kernel
+    __shared__ double exp_tab[32];
+    exp_table_init(exp_tab);   // the only barrier of this kernel, before any early exit
+    if (j0 >= A.m) return;     // wave-uniform
     const int s0 = st * 16;
+    ExpK ek;
+    expk_init(ek);
 
     double a[JT][KK];
 #pragma unroll
@@ -273,7 +328,7 @@ __global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A) {
             pg += A.S;
             const bool more = (i + 1 < bB);
             load_cand<KK>(nxt, A, pg - A.off, more && col_ok && pg >= A.off && pg < lim, g);
-            tile_accumulate<KK, FAM, JT>(a, cur, acc);
+            tile_accumulate<KK, FAM, JT>(a, cur, acc, ek, exp_tab);
             tot += cur.wm;
             cur = nxt;
         }
@@ -292,7 +347,7 @@ __global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A) {
         for (long long p = t0; p < A.Rl; p += 16) {
             CandFrag<KK> f;
             load_cand<KK>(f, A, p + c, (p + c) < A.Rl, g);
-            tile_accumulate<KK, FAM, JT>(a, f, tacc);
+            tile_accumulate<KK, FAM, JT>(a, f, tacc, ek, exp_tab);
             ttot += f.wm;
         }
         const int c_last = (A.S - 1) - s0;
@@ -401,12 +456,12 @@ __device__ __forceinline__ void row_wait(CandRow<KK>& r) {
 
 template <int KK, int FAM, bool HAS_WX>
 __device__ __forceinline__ double pair_term(const double (&pt)[KK * 4 - 2], double hj, double onej,
-                                            const CandRow<KK>& r, const ExpK& ek, double acc) {
+                                            const CandRow<KK>& r, const ExpK& ek, const double* tab, double acc) {
     constexpr int KP = KK * 4, DIMS = KP - 2;
     double D = __builtin_fma(onej, r.v[KK - 1][3], hj);   // h_j + h_x  (onej = 1; 0 for the "all-ones" pseudo row)
 #pragma unroll
     for (int k = 0; k < DIMS; ++k) D = __builtin_fma(pt[k], r.v[k >> 2][k & 3], D);
-    double e = kernel_from_arg_k<FAM>(D, ek);
+    double e = kernel_from_arg_k<FAM>(D, ek, tab);
     if (HAS_WX) e *= r.x;
     return __builtin_fma(e, r.w, acc);
 }
@@ -423,21 +478,21 @@ struct LaneRows {
 // candidate t+1 are in flight during the TJ * ~27 VALU instructions of candidate t.
 template <int KK, int FAM, int ST, int TJ, bool HAS_WX, int T>
 struct BlockStep {
-    static __device__ __forceinline__ void run(const LaneRows<KK, TJ>& L, const ExpK& ek, CandRow<KK> (&rows)[2],
-                                               const double* cb, const double* mb, const double* xb,
-                                               double (&acc)[TJ][ST]) {
+    static __device__ __forceinline__ void run(const LaneRows<KK, TJ>& L, const ExpK& ek, const double* tab,
+                                               CandRow<KK> (&rows)[2], const double* cb, const double* mb,
+                                               const double* xb, double (&acc)[TJ][ST]) {
         row_wait<KK, HAS_WX>(rows[T & 1]);
         if (T + 1 < ST) row_issue<KK, T + 1, HAS_WX>(rows[(T + 1) & 1], cb, mb, xb);
 #pragma unroll
         for (int u = 0; u < TJ; ++u)
-            acc[u][T] = pair_term<KK, FAM, HAS_WX>(L.pt[u], L.hj[u], L.onej[u], rows[T & 1], ek, acc[u][T]);
-        BlockStep<KK, FAM, ST, TJ, HAS_WX, T + 1>::run(L, ek, rows, cb, mb, xb, acc);
+            acc[u][T] = pair_term<KK, FAM, HAS_WX>(L.pt[u], L.hj[u], L.onej[u], rows[T & 1], ek, tab, acc[u][T]);
+        BlockStep<KK, FAM, ST, TJ, HAS_WX, T + 1>::run(L, ek, tab, rows, cb, mb, xb, acc);
     }
 };
 template <int KK, int FAM, int ST, int TJ, bool HAS_WX>
 struct BlockStep<KK, FAM, ST, TJ, HAS_WX, ST> {
-    static __device__ __forceinline__ void run(const LaneRows<KK, TJ>&, const ExpK&, CandRow<KK> (&)[2], const double*,
-                                               const double*, const double*, double (&)[TJ][ST]) {}
+    static __device__ __forceinline__ void run(const LaneRows<KK, TJ>&, const ExpK&, const double*, CandRow<KK> (&)[2],
+                                               const double*, const double*, const double*, double (&)[TJ][ST]) {}
 };
 
 template <int KK, int FAM, int ST, int TJ, bool HAS_WX>
@@ -454,7 +509,9 @@ blocksum_valu_kernel(const double* __restrict__ nys, const double* __restrict__ 
     const int chunk = b % n_chunks;
     const int jg = b / n_chunks;
     const int jw = (jg * 4 + wave) * (64 * TJ);
-    if (jw >= m) return;                       // wave-uniform; no barriers in this kernel
+    __shared__ double exp_tab[32];
+    exp_table_init(exp_tab);                   // the only barrier of this kernel, before any early exit
+    if (jw >= m) return;                       // wave-uniform
     const int mrows = ((m + 63) / 64) * 64;    // rows the caller allocated (padded to a multiple of 64)
     LaneRows<KK, TJ> L;
 #pragma unroll
@@ -512,7 +569,7 @@ blocksum_valu_kernel(const double* __restrict__ nys, const double* __restrict__ 
             const double* mb = mu + base;
             const double* xb = HAS_WX ? (wx + base) : mu;
             row_issue<KK, 0, HAS_WX>(rows[0], cb, mb, xb);
-            BlockStep<KK, FAM, ST, TJ, HAS_WX, 0>::run(L, ek, rows, cb, mb, xb, acc);
+            BlockStep<KK, FAM, ST, TJ, HAS_WX, 0>::run(L, ek, exp_tab, rows, cb, mb, xb, acc);
         } else {
             // shard edges / ragged last set tile: candidate by candidate, wave-uniform branches
 #pragma unroll
@@ -524,7 +581,7 @@ blocksum_valu_kernel(const double* __restrict__ nys, const double* __restrict__ 
                     row_wait<KK, HAS_WX>(r);
 #pragma unroll
                     for (int u = 0; u < TJ; ++u)
-                        acc[u][t] = pair_term<KK, FAM, HAS_WX>(L.pt[u], L.hj[u], L.onej[u], r, ek, acc[u][t]);
+                        acc[u][t] = pair_term<KK, FAM, HAS_WX>(L.pt[u], L.hj[u], L.onej[u], r, ek, exp_tab, acc[u][t]);
                 }
             }
         }
@@ -543,7 +600,7 @@ blocksum_valu_kernel(const double* __restrict__ nys, const double* __restrict__ 
             row_issue<KK, 0, HAS_WX>(r, cand + pl * KP, mu + pl, HAS_WX ? (wx + pl) : mu);
             row_wait<KK, HAS_WX>(r);
 #pragma unroll
-            for (int u = 0; u < TJ; ++u) ta[u] = pair_term<KK, FAM, HAS_WX>(L.pt[u], L.hj[u], L.onej[u], r, ek, ta[u]);
+            for (int u = 0; u < TJ; ++u) ta[u] = pair_term<KK, FAM, HAS_WX>(L.pt[u], L.hj[u], L.onej[u], r, ek, exp_tab, ta[u]);
         }
 #pragma unroll
         for (int u = 0; u < TJ; ++u)
@@ -741,20 +798,28 @@ __global__ void __launch_bounds__(256) gemm_kernel(const double* __restrict__ A,
     d4 acc[JT];
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) acc[jt] = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int k = k0; k < k1; k += 4) {
-        const int kg = k + g;
-        const bool kin = kg < k1;
-        double b = 0.0;
-        if (kin) {
-            const double* bp = B + (long long)kg * ldb + col;
-            b = bp[0];
-            for (int u = 1; u < nsum; ++u) b += bp[(long long)u * bstride];
+    // four k-steps per trip: all A/B loads of the trip are issued before its MFMAs
+    for (int k = k0; k < k1; k += 16) {
+        double bv[4], av[4][JT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int kg = k + 4 * u + g;
+            const bool kin = kg < k1;
+            double b = 0.0;
+            if (kin) {
+                const double* bp = B + (long long)kg * ldb + col;
+                b = bp[0];
+                for (int v = 1; v < nsum; ++v) b += bp[(long long)v * bstride];
+            }
+            bv[u] = b;
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) av[u][jt] = kin ? A[arow[jt] + kg] : 0.0;
         }
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            const double a = kin ? A[arow[jt] + kg] : 0.0;
-            acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[jt], 0, 0, 0);
-        }
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+                acc[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][jt], bv[u], acc[jt], 0, 0, 0);
     }
     if (n0 + c < N) {
         double* Cz = C + (long long)blockIdx.z * cstride;
@@ -765,6 +830,24 @@ __global__ void __launch_bounds__(256) gemm_kernel(const double* __restrict__ A,
                 const int row = r0 + jt * 16 + g + 4 * r;
                 if (row < M) Cz[(long long)row * ldc + n0 + c] = alpha * acc[jt][r];
             }
+    }
+}
+
+// Xsum[e] = sum_c Xpart[c][e]  (chunk order): one streaming pass instead of one GEMM per chunk partial
+__global__ void chunk_sum_kernel(const double* __restrict__ Xpart, long long n, int n_chunks, double* __restrict__ Xsum) {
+    const long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (e + 1 < n) {
+        double2 v = *reinterpret_cast<const double2*>(Xpart + e);
+        for (int c = 1; c < n_chunks; ++c) {
+            const double2 u = *reinterpret_cast<const double2*>(Xpart + (long long)c * n + e);
+            v.x += u.x;
+            v.y += u.y;
+        }
+        *reinterpret_cast<double2*>(Xsum + e) = v;
+    } else if (e < n) {
+        double v = Xpart[e];
+        for (int c = 1; c < n_chunks; ++c) v += Xpart[(long long)c * n + e];
+        Xsum[e] = v;
     }
 }
 
@@ -808,6 +891,15 @@ __global__ void finalize_kernel(const double* __restrict__ parts, int n_parts, i
         v += diag_noise * wgt * diagU[(long long)(r - 1) * ld_diag + s];
     }
     XcarT[idx] = v / tot;
+}
+
+// Correctly rounded quotient a / b from rb = RN(1/b) with two FMAs (Markstein 1990: q0 = RN(a rb),
+// r = a - b q0 exactly (FMA), q = RN(q0 + r rb) = RN(a/b) for normal, finite operands).  The elimination
+// performs ~1e6 divisions by the SAME pivot per step; this keeps the reference's rounding at 1/6 of the cost.
+__device__ __forceinline__ double div_by_recip(double a, double b, double rb) {
+    const double q0 = a * rb;
+    const double r = __builtin_fma(-b, q0, a);
+    return __builtin_fma(r, rb, q0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -874,18 +966,112 @@ __global__ void __launch_bounds__(1024) car_eliminate_kernel(double* __restrict_
         for (int cc = k + 1 + tid; cc < nrows; cc += 1024) pc[cc] = PhiT[(long long)cc * M + j];
         __syncthreads();
         const double phij = sh_phij;
+        const double rphij = 1.0 / phij;                                     // correctly rounded reciprocal
         const double phi_i = col[my_i];
         if (upd) {
             for (int cc = k + 1 + my_r; cc < nrows; cc += rows_per_pass) {   // :165-171
                 double* p = PhiT + (long long)cc * M + my_i;
                 const double prod = pc[cc] * phi_i;
-                const double o = prod / phij;
+                const double o = div_by_recip(prod, phij, rphij);            // == prod / phij, bit for bit
                 *p = (my_i == j) ? 0.0 : (*p - o);
             }
         }
         __syncthreads();
     }
     // survivors: mu > 0 (:173-174), ascending
+    const bool keep = (tid < M) && (mu[tid] > 0.0);
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) wave_cnt[wv] = __popcll(bal);
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wv) base += wave_cnt[w];
+        total += wave_cnt[w];
+    }
+    const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
+    if (tid < M) {
+        keep_rank[tid] = keep ? rank : -1;
+        mu_g[tid] = mu[tid];
+        if (keep) { kept[rank] = tid; w_star[rank] = mu[tid]; }
+    }
+    if (tid == 0) { info[0] = total; info[1] = status; }
+}
+
+// LDS-resident form (used when (M-s)*M + M + (M-s) doubles fit in 160 KB, e.g. M = 200, s = 100): identical
+// arithmetic and pivot rule, but the null-space rows never leave the CU -- ~3 barriers per step, no L2 round trips.
+__global__ void __launch_bounds__(1024) car_eliminate_lds_kernel(const double* __restrict__ PhiT_g,
+                                                                 double* __restrict__ mu_g, int M, int s,
+                                                                 int* __restrict__ keep_rank, int* __restrict__ kept,
+                                                                 double* __restrict__ w_star, int* __restrict__ info) {
+#pragma clang fp contract(off)   // plain operators: the reference rounds after every mul / sub / div
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int nrows = M - s;
+    double* Phi = sm;                          // [nrows][M]
+    double* mu = sm + (size_t)nrows * M;       // [M]
+    double* pc = mu + M;                       // [nrows]
+    __shared__ double red_v[16];
+    __shared__ int red_i[16];
+    __shared__ double sh_alpha, sh_phij;
+    __shared__ int sh_j;
+    __shared__ int wave_cnt[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double INF = __builtin_huge_val();
+    for (int e = tid; e < nrows * M; e += 1024) Phi[e] = PhiT_g[e];
+    if (tid < M) mu[tid] = mu_g[tid];
+    int status = 0;
+    const int rows_per_pass = 1024 / M;
+    const int my_i = tid % M, my_r = tid / M;
+    const bool upd = my_r < rows_per_pass;
+    __syncthreads();
+    for (int k = 0; k < nrows; ++k) {
+        const double* col = Phi + (size_t)k * M;
+        const double phi = (tid < M) ? col[tid] : 0.0;
+        const bool pos = (tid < M) && (phi > 0.0);
+        double av = pos ? (mu[tid] / phi) : INF;
+        int ai = pos ? tid : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const double ov = __shfl_xor(av, o, 64);
+            const int oi = __shfl_xor(ai, o, 64);
+            if (ov < av || (ov == av && oi < ai)) { av = ov; ai = oi; }
+        }
+        if (lane == 0) { red_v[wv] = av; red_i[wv] = ai; }
+        __syncthreads();
+        if (wv == 0) {
+            double v = (lane < 16) ? red_v[lane] : INF;
+            int i = (lane < 16) ? red_i[lane] : 0x7fffffff;
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) {
+                const double ov = __shfl_xor(v, o, 64);
+                const int oi = __shfl_xor(i, o, 64);
+                if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+            }
+            if (lane == 0) { sh_j = i; sh_alpha = v; }
+        }
+        __syncthreads();
+        const int j = sh_j;
+        if (j == 0x7fffffff) { status = 1; break; }
+        if (tid == j) sh_phij = phi;
+        const double aj = sh_alpha;
+        if (tid < M) {
+            const double step = aj * phi;
+            mu[tid] = (tid == j) ? 0.0 : (mu[tid] - step);
+        }
+        for (int cc = k + 1 + tid; cc < nrows; cc += 1024) pc[cc] = Phi[(size_t)cc * M + j];
+        __syncthreads();
+        const double phij = sh_phij;
+        const double rphij = 1.0 / phij;                                     // correctly rounded reciprocal
+        const double phi_i = col[my_i];
+        if (upd) {
+            for (int cc = k + 1 + my_r; cc < nrows; cc += rows_per_pass) {
+                double* p = Phi + (size_t)cc * M + my_i;
+                const double prod = pc[cc] * phi_i;
+                const double o = div_by_recip(prod, phij, rphij);            // == prod / phij, bit for bit
+                *p = (my_i == j) ? 0.0 : (*p - o);
+            }
+        }
+        __syncthreads();
+    }
     const bool keep = (tid < M) && (mu[tid] > 0.0);
     const unsigned long long bal = __ballot(keep);
     if (lane == 0) wave_cnt[wv] = __popcll(bal);
@@ -1008,6 +1194,80 @@ __global__ void __launch_bounds__(1024) chol_inv_kernel(double* __restrict__ G, 
     }
 }
 
+// LDS-resident form of chol_inv_kernel for q*q doubles <= ~150 KB (q <= 136): the factor lives in LDS with an
+// odd leading dimension (column accesses conflict-free), 2 barriers per pivot and no global round trips.
+__global__ void __launch_bounds__(1024) chol_inv_lds_kernel(double* __restrict__ G, int q, double* __restrict__ W,
+                                                            int* __restrict__ info, double rel_tol) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int ld = q | 1;
+    double* Ls = sm;                  // [q][ld]
+    double* colj = sm + (size_t)q * ld;
+    __shared__ double red[16];
+    __shared__ double s_dmax;
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int e = tid; e < q * q; e += 1024) {
+        const int i = e / q, k = e - i * q;
+        Ls[i * ld + k] = G[e];
+        W[e] = 0.0;
+    }
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    double dm = (tid < q) ? Ls[tid * ld + tid] : 0.0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) dm = fmax(dm, __shfl_xor(dm, o, 64));
+    if (lane == 0) red[wv] = dm;
+    __syncthreads();
+    if (tid == 0) {
+        double v = red[0];
+        for (int w = 1; w < 16; ++w) v = fmax(v, red[w]);
+        s_dmax = v;
+    }
+    __syncthreads();
+    const double floor_ = rel_tol * s_dmax;
+    for (int j = 0; j < q; ++j) {
+        const double d = Ls[j * ld + j];
+        if (!(d > floor_)) {                                  // uniform: every thread reads the same pivot
+            if (tid == 0) s_bad = j + 1;
+            break;
+        }
+        const double piv = sqrt(d);
+        for (int i = j + 1 + tid; i < q; i += 1024) colj[i] = Ls[i * ld + j] / piv;
+        __syncthreads();
+        if (tid == 0) Ls[j * ld + j] = piv;
+        for (int i = j + 1 + tid; i < q; i += 1024) Ls[i * ld + j] = colj[i];
+        const int n = q - j - 1;
+        for (int idx = tid; idx < n * n; idx += 1024) {
+            const int a = idx / n, b = idx - a * n;
+            if (b <= a) Ls[(j + 1 + a) * ld + (j + 1 + b)] -= colj[j + 1 + a] * colj[j + 1 + b];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    const int bad = s_bad;
+    if (tid == 0) info[0] = bad;
+    // write L back (lower triangle incl. diagonal; the strict upper triangle of G is left untouched)
+    for (int e = tid; e < q * q; e += 1024) {
+        const int i = e / q, k = e - i * q;
+        if (k <= i) G[e] = Ls[i * ld + k];
+    }
+    if (bad || tid >= q) return;
+    // column c of Y = L^{-1} by forward substitution, kept in the (now free) upper triangle of Ls:
+    // Y[i][c] (i >= c) is stored at Ls[c][i] for i > c (strictly upper), and its diagonal in a register.
+    const int c = tid;
+    double* wrow = W + (long long)c * q;
+    const double ycc = 1.0 / Ls[c * ld + c];
+    wrow[c] = ycc;
+    for (int i = c + 1; i < q; ++i) {
+        const double* lrow = Ls + i * ld;
+        double acc = -lrow[c] * ycc;
+        for (int k = c + 1; k < i; ++k) acc -= lrow[k] * Ls[c * ld + k];
+        const double y = acc / lrow[i];
+        Ls[c * ld + i] = y;                                   // row c, column i > c: strictly upper, owned by thread c
+        wrow[i] = y;
+    }
+}
+
 __global__ void axpb_strided_kernel(const double* __restrict__ x, long long n, long long stride, double a, double b,
                                     double* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1104,10 +1364,11 @@ static int blocksum_impl(const basq_kernel_spec* spec, const double* nys, int32_
     const long long nblk = A.blk_hi - A.blk_lo;
     A.blk_per_chunk = (nblk + n_chunks - 1) / n_chunks;
     if (A.blk_per_chunk < 1) A.blk_per_chunk = 1;
-    // VALU form while two candidate rows fit the SGPR budget without spills (KP <= 12, i.e. d <= 10: audited by
-    // tools/audit_isa.py); the MFMA form (operands in VGPRs) beyond.
+    // The scalar-broadcast VALU form exists while two candidate rows fit the SGPR budget without spills
+    // (KP <= 12, i.e. d <= 10: audited by tools/audit_isa.py); the MFMA form (operands in VGPRs) serves every d.
     const int kk = basq_kp(spec->d) / 4;
-    if (use_mfma || kk > BASQ_VALU_MAX_KK) return dispatch_blocksum(kk, spec->family, A, (hipStream_t)stream);
+    if (use_mfma) return dispatch_blocksum(kk, spec->family, A, (hipStream_t)stream);
+    if (kk > BASQ_VALU_MAX_KK) return BASQ_EUNSUPPORTED;
     return dispatch_blocksum_valu(kk, spec->family, A, (hipStream_t)stream);
 }
 
@@ -1115,14 +1376,14 @@ int basq_blocksum_f64(const basq_kernel_spec* spec, const double* nys, int32_t m
                       const double* mu, const double* wx, int64_t Rl, int64_t off, int64_t n_full, int32_t S,
                       int32_t n_chunks, double* Xpart, double* totpart, void* stream) {
     if (!totpart) return BASQ_EINVAL;
-    return blocksum_impl(spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, Xpart, totpart, stream, false);
+    return blocksum_impl(spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, Xpart, totpart, stream, true);
 }
 
-int basq_blocksum_mfma_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
+int basq_blocksum_valu_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
                            const double* mu, const double* wx, int64_t Rl, int64_t off, int64_t n_full, int32_t S,
                            int32_t n_chunks, double* Xpart, double* totpart, void* stream) {
     if (!totpart) return BASQ_EINVAL;
-    return blocksum_impl(spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, Xpart, totpart, stream, true);
+    return blocksum_impl(spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, Xpart, totpart, stream, false);
 }
 
 int basq_kernel_matvec_f64(const basq_kernel_spec* spec, const double* packA, int64_t na, const double* packB,
@@ -1130,7 +1391,7 @@ int basq_kernel_matvec_f64(const basq_kernel_spec* spec, const double* packA, in
     // blocksum with a single set and everything in the "tail": out[i] = sum_j k(A_i, B_j) v_j.
     if (!spec_ok(spec) || !packA || !packB || !v || !out || na < 1 || nb < 1 || na > 0x7fffffffLL)
         return BASQ_EINVAL;
-    int rc = blocksum_impl(spec, packA, (int32_t)na, packB, v, nullptr, nb, 0, 0, 1, 1, out, nullptr, stream, false);
+    int rc = blocksum_impl(spec, packA, (int32_t)na, packB, v, nullptr, nb, 0, 0, 1, 1, out, nullptr, stream, true);
     if (rc != BASQ_OK) return rc;
     hipLaunchKernelGGL(axpb_strided_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out,
                        (long long)na, 1LL, spec->outputscale, bias, out);
@@ -1144,17 +1405,28 @@ int basq_project_f64(const double* U, int32_t q, int32_t m, const double* Xpart,
     if (!U || !Xpart || !totpart || !work || !out || q < 1 || m < 1 || S < 1 || n_chunks < 1 || ksplit < 1)
         return BASQ_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    // work = [ Xsum (m*S, only if n_chunks > 1) | ksplit slabs of q*S ]
+    const long long nX = (long long)m * S;
+    const double* X = Xpart;
+    double* slabs = work;
+    if (n_chunks > 1) {
+        if ((nX & 1) || (((uintptr_t)Xpart | (uintptr_t)work) & 15)) return BASQ_EINVAL;   // double2 path
+        hipLaunchKernelGGL(chunk_sum_kernel, dim3((unsigned)((nX / 2 + 255) / 256)), dim3(256), 0, st, Xpart, nX, n_chunks,
+                           work);
+        BASQ_CHECK_LAUNCH();
+        X = work;
+        slabs = work + nX;
+    }
     int kslice = (m + ksplit - 1) / ksplit;
-    kslice = ((kslice + 3) / 4) * 4;
-    const int nz = (m + kslice - 1) / kslice;          // <= ksplit slabs per chunk
-    // z = chunk * nz + K slice; slabs [chunk][slice] are contiguous in `work`
-    dim3 grid((unsigned)((q + 15) / 16), (unsigned)((S + 63) / 64), (unsigned)(nz * n_chunks));
-    hipLaunchKernelGGL((gemm_kernel<1>), grid, dim3(256), 0, st, U, (long long)m, Xpart, (long long)S, 0LL, 1, work,
-                       (long long)S, (long long)q * S, q, S, m, kslice, outputscale, nz, (long long)m * S);
+    kslice = ((kslice + 15) / 16) * 16;
+    const int nz = (m + kslice - 1) / kslice;          // <= ksplit slabs
+    dim3 grid((unsigned)((q + 15) / 16), (unsigned)((S + 63) / 64), (unsigned)nz);
+    hipLaunchKernelGGL((gemm_kernel<1>), grid, dim3(256), 0, st, U, (long long)m, X, (long long)S, 0LL, 1, slabs,
+                       (long long)S, (long long)q * S, q, S, m, kslice, outputscale, nz, 0LL);
     BASQ_CHECK_LAUNCH();
     const int tot = (q + 1) * S;
-    hipLaunchKernelGGL(project_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, work,
-                       nz * n_chunks, q, S, totpart, n_chunks, out);
+    hipLaunchKernelGGL(project_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, slabs, nz, q, S,
+                       totpart, n_chunks, out);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }
@@ -1176,6 +1448,16 @@ int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32
                            double* w_star, int32_t* info, void* stream) {
     if (!PhiT || !mu || !keep_rank || !kept || !w_star || !info || M < 1 || M > 1024 || s < 1 || s > M)
         return BASQ_EINVAL;
+    const size_t lds = ((size_t)(M - s) * M + M + (M - s)) * sizeof(double);
+    if (s < M && lds <= 162560) {      // 163840 B per CU minus the kernel's static LDS
+        if (hipFuncSetAttribute((const void*)car_eliminate_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return BASQ_ELAUNCH;
+        hipLaunchKernelGGL(car_eliminate_lds_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, PhiT, mu, M, s,
+                           keep_rank, kept, w_star, info);
+        BASQ_CHECK_LAUNCH();
+        return BASQ_OK;
+    }
     hipLaunchKernelGGL(car_eliminate_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, PhiT, mu, M, s, keep_rank,
                        kept, w_star, info);
     BASQ_CHECK_LAUNCH();
@@ -1211,6 +1493,15 @@ int basq_init_state_f64(double* mu, int64_t* gid, int64_t Rl, int64_t gid0, int6
 
 int basq_chol_inv_f64(double* G, int32_t q, double* W, int32_t* info, double rel_tol, void* stream) {
     if (!G || !W || !info || q < 1 || q > 1024 || !(rel_tol >= 0.0)) return BASQ_EINVAL;
+    const size_t lds = ((size_t)q * (q | 1) + 1024) * sizeof(double);
+    if (lds <= 150 * 1024) {
+        if (hipFuncSetAttribute((const void*)chol_inv_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return BASQ_ELAUNCH;
+        hipLaunchKernelGGL(chol_inv_lds_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, G, q, W, info, rel_tol);
+        BASQ_CHECK_LAUNCH();
+        return BASQ_OK;
+    }
     hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, G, q, W, info, rel_tol);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;

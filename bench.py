@@ -12,7 +12,7 @@ Rank 0 prints ONE JSON line.
               tensors; H2D of the pool is reported separately in DESIGN.md, never in ``value``);
 * N > 1     = the SAME batch with the pool sharded over the ranks (strong scaling; one small all-gather +
               broadcast per round);
-* roofline  = the dominant kernel (``blocksum_valu_kernel``): algorithmic flops = pairs * (3d + 3)
+* roofline  = the dominant kernel (``blocksum_kernel``): algorithmic flops = pairs * (3d + 3)
               (SURVEY §8d) over its HIP-event time on the launch stream, against the fp64 vector peak;
 * cpu_baseline = the oracle (= the reference's CPU op sequence) on this host's cores, bounded sample.
 """
@@ -119,6 +119,15 @@ def main():
     bytes_alg = sum(info["R"] * (8 * d + 16) + 8 * info["m"] * d for _, _, info in tr.kernel_events)
     achieved_tf = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
 
+    # HBM bytes of the largest block-sum launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in separate runs, KiB units; 8-B-per-lane loads, so the gfx950 16-B half-count does not apply)
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(pmc) and N == WORKLOAD["N"] and d == WORKLOAD["d"] and world == 1:
+        with open(pmc) as f:
+            rec = json.load(f)
+        traffic, traffic_src = rec["bytes_per_launch"], rec["source"]
+
     if args.breakdown:
         tb = basq_amd.EngineTrace(time_kernels=False, host_sync=True)
         one_batch(tb)
@@ -162,11 +171,11 @@ def main():
                                    f"float64, pool sharded over {world} GPU(s)",
                        "N": N, "d": d, "n": n, "m": m, "kernel": "rbf", "parallelism": f"pool-sharded x{world}"},
             "roofline": {
-                "bound": "valu_f64",
-                "kernel": "blocksum_valu_kernel (fused pairwise-kernel block sums, BASQ/_rchq.py:79-99)",
+                "bound": "mfma",
+                "kernel": "blocksum_kernel (fused pairwise-kernel block sums, BASQ/_rchq.py:79-99)",
                 "achieved": achieved_tf, "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tf / PEAK_FP64_VECTOR_TFLOPS,
-                "traffic": None,
+                "traffic": traffic,
                 "launches_per_batch": k_launches, "kernel_ms_per_batch": k_ms, "pairs_per_batch": k_pairs,
                 "flops_per_pair": 3 * d + 3,
                 "hbm_algorithmic_GBs": bytes_alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,

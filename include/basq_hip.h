@@ -104,18 +104,20 @@ int basq_blocksum_f64(const basq_kernel_spec* spec, const double* nys, int32_t m
                       int32_t n_chunks, double* Xpart, double* totpart, void* stream);
 
 /*
- * Same contract as basq_blocksum_f64, exponent arguments on the f64 matrix cores.  Kept for A/B
- * measurement: on gfx950 it is the slower form, the product path does not use it.
+ * Same contract as basq_blocksum_f64 in the scalar-broadcast VALU form (candidate rows through the scalar
+ * cache, d FMAs per pair instead of MFMAs), d <= 10 only (BASQ_EUNSUPPORTED beyond).  Kept for A/B
+ * measurement: on gfx950 it is within 7 % of the default form, which the product path uses.
  */
-int basq_blocksum_mfma_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
+int basq_blocksum_valu_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
                            const double* mu, const double* wx, int64_t Rl, int64_t off, int64_t n_full, int32_t S,
                            int32_t n_chunks, double* Xpart, double* totpart, void* stream);
 
 /*
  * Nystrom-feature contraction BASQ/_rchq.py:88-90:  out[0][s] = sum_c totpart[c][s];
  *     out[1+r][s] = outputscale * sum_j U[r][j] * (sum_c Xpart[c][j][s])        r < q
- * on the f64 matrix cores (v_mfma_f64_16x16x4_f64); every chunk partial is split `ksplit` ways along K
- * through `work` ([n_chunks * ksplit, q, S] doubles) and the slabs are re-added in index order.  `out` is [(q+1), S]: the per-rank message
+ * on the f64 matrix cores (v_mfma_f64_16x16x4_f64): the chunk partials are first added in chunk order
+ * (one streaming pass), then ONE GEMM split `ksplit` ways along K whose slabs are re-added in index order.
+ * `work` holds (n_chunks > 1 ? m*S : 0) + ksplit*q*S doubles, 16-byte aligned; m*S must be even if n_chunks > 1.  `out` is [(q+1), S]: the per-rank message
  * of the multi-GPU all-gather; it is NOT yet divided by the set weights.
  */
 int basq_project_f64(const double* U, int32_t q, int32_t m, const double* Xpart, const double* totpart,

@@ -77,11 +77,13 @@ def test_blocksum_vs_standin(hip_ops, family, d, m, S, Rl, off, n_full, n_chunks
     dev = hip_ops.to_device
     A_g = hip_ops.pack(spec, dev(nys), dev(center), 0, pad_rows_to=64)
     B_g = hip_ops.pack(spec, dev(cand), dev(center), 1)
-    Xg, tg = hip_ops.blocksum(spec, A_g, m, B_g, dev(mu), dev(wx) if use_wx else None, Rl, off, n_full, S, n_chunks)
-    Xg, tg = Xg.cpu(), tg.cpu()
     scale = Xc.abs().max().item()
-    assert (Xg - Xc).abs().max().item() <= 1e-12 * scale
-    assert (tg - tc).abs().max().item() <= 1e-13 * tc.abs().max().item()
+    for impl in (("mfma", "valu") if d <= 10 else ("mfma",)):     # default (MFMA) form and the scalar-broadcast form
+        Xg, tg = hip_ops.blocksum(spec, A_g, m, B_g, dev(mu), dev(wx) if use_wx else None, Rl, off, n_full, S, n_chunks,
+                                  impl=impl)
+        Xg, tg = Xg.cpu(), tg.cpu()
+        assert (Xg - Xc).abs().max().item() <= 1e-12 * scale, impl
+        assert (tg - tc).abs().max().item() <= 1e-13 * tc.abs().max().item(), impl
 
 
 def test_matvec_vs_standin(hip_ops):

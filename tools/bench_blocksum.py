@@ -38,7 +38,8 @@ def main():
     nch = args.chunks or choose_chunks(local_blocks(0, args.R, geo), args.m, S)
     pairs = float(args.R) * args.m
     out = {}
-    for impl in ("valu", "mfma"):
+    impls = ("mfma", "valu") if args.d <= 10 else ("mfma",)
+    for impl in impls:
         X, t = ops.blocksum(spec, A, args.m, B, mu, None, args.R, 0, geo.n_full, S, nch, impl=impl)   # warm-up
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -51,8 +52,9 @@ def main():
         out[impl] = X.sum(0)
         flops = pairs * (3 * args.d + 3)
         print(f"{impl:5s} chunks={nch} {ms:9.3f} ms  {pairs / ms / 1e6:8.2f} Gpair/s  {flops / ms / 1e9:7.2f} TFLOP/s(3d+3)")
-    rel = ((out["valu"] - out["mfma"]).abs().max() / out["mfma"].abs().max()).item()
-    print(f"valu vs mfma max rel diff {rel:.2e}")
+    if "valu" in out:
+        rel = ((out["valu"] - out["mfma"]).abs().max() / out["mfma"].abs().max()).item()
+        print(f"valu vs mfma max rel diff {rel:.2e}")
 
 
 if __name__ == "__main__":
