@@ -6,6 +6,7 @@ Public surface (mirrors the reference's names):
     BASQ(batch_size, device).run_rchq(pts_nys, pts_rec, w_IS, kernel) -> (x, w)
     KernelQuadrature(...).rchq / .quadrature
     kernels.StationaryKernel / PosteriorKernel / WsabiKernel / from_gpytorch_model
+    GaussianCalc(prior, device).unimodal_approximation / uniform_transformation
 
 Importing the package does not touch the GPU; the HIP library is loaded on first use and its
 absence is an error (there is no CPU fallback).
@@ -13,6 +14,8 @@ absence is an error (there is no CPU fallback).
 from . import kernels, pools                                  # noqa: F401
 from ._basq import BASQ, KernelQuadrature                      # noqa: F401
 from ._engine import EngineTrace                               # noqa: F401
+from ._gaussian_calc import GaussianCalc                       # noqa: F401
 from ._rchq import recombination, recombination_sharded        # noqa: F401
 
-__all__ = ["recombination", "recombination_sharded", "BASQ", "KernelQuadrature", "EngineTrace", "kernels", "pools"]
+__all__ = ["recombination", "recombination_sharded", "BASQ", "KernelQuadrature", "GaussianCalc", "EngineTrace", "kernels",
+           "pools"]

@@ -241,8 +241,6 @@ class RecombinationEngine:
         Returns ``(idx int64[<=num_pts] ascending, w float64)`` on the ops device (identical on every rank).
         """
         ops, comm = self.ops, self.comm
-        if kernel.warp == "wsabim":
-            raise NotImplementedError("WSABI-M (0.5 cov^2 term) is not linear in the block sums: not built yet")
         if n_total >= 2 ** 31:
             raise ValueError("pool sizes >= 2^31 are not supported")
         pts_nys = ops.to_device(pts_nys, torch.float64)
@@ -287,6 +285,7 @@ class RecombinationEngine:
 
         # ---- candidate state ---------------------------------------------------------------------------
         cand = ops.pack(spec, pts_local, center, ROLE_B)
+        cand_raw = pts_local if warp == "wsabim" else None      # WSABI-M needs dense kernel blocks of the survivors
         mu, gid = ops.init_state(Rl, gid0, n_total)
         wx = None
         if warp != "none":
@@ -371,6 +370,12 @@ class RecombinationEngine:
                                                                              S=S_r, chunks=n_chunks)))
             with _Timer(ops, trace, "project"):
                 msg = ops.project(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S_r, spec.outputscale)
+            if warp == "wsabim":
+                # + U @ (0.5 sum mu cov^2): the one term of wsabim_kernel that is not linear in the block sums
+                with _Timer(ops, trace, "wsabim_sq"):
+                    E = self._wsabim_square_term(base, spec, pts_nys, Xo, Bmat, center, cand_raw, mu, Rl, off,
+                                                 geo.n_full, S_r, m)
+                    msg[1:q + 1] += ops.matmul(U, E)
             if trace is not None:
                 if trace.host_sync:
                     ops.synchronize()
@@ -427,6 +432,8 @@ class RecombinationEngine:
             new_off, new_Rl = next_shard(off, Rl, geo, kept_list)
             cand, mu, gid, wx = ops.reweight_compact(cand, mu, gid, wx, Rl, off, geo.n_full, S_r, kp, keep_rank, w_star,
                                                      tot, n_keep, new_off, new_Rl)
+            if cand_raw is not None:
+                cand_raw = pts_local[(gid[:new_Rl] - gid0)]
             R = survivors_before(R, geo, kept_list)
             off, Rl = new_off, new_Rl
             if trace is not None:
@@ -438,6 +445,29 @@ class RecombinationEngine:
                 ops.synchronize()
             trace.add_time("total", time.perf_counter() - t_all)
         return idx, w
+
+    # ------------------------------------------------------------------------------------------------
+    def _wsabim_square_term(self, base, spec, pts_nys, Xo, Bmat, center, cand_raw, mu, Rl, off, n_full, S, m,
+                            chunk_bytes=256 << 20):
+        """E[j, s] = 0.5 * sum_{p in set s} mu_p * cov(pt_j, x_p)^2  with cov = k - K(pt,X) W K(X, x)  (_wsabi.py:240).
+
+        Dense in chunks of candidates: two HIP Gram blocks, one rocBLAS GEMM for the posterior correction and the
+        HIP squared block sum; the chunk partials are accumulated in position order (fixed summation order).
+        """
+        ops = self.ops
+        E = ops.zeros(m, S)
+        if Rl == 0:
+            return E
+        nc_max = max(S, min(Rl, chunk_bytes // (8 * m)))
+        pa = ops.pack(spec, pts_nys, center, ROLE_A)
+        po = ops.pack(spec, Xo, center, ROLE_A)
+        for p0 in range(0, Rl, nc_max):
+            nc = min(nc_max, Rl - p0)
+            pb = ops.pack(spec, cand_raw[p0:p0 + nc].contiguous(), center, ROLE_B)
+            cov = ops.gram(spec, pa, m, pb, nc)
+            cov -= Bmat @ ops.gram(spec, po, Xo.shape[0], pb, nc)
+            ops.dense_sq_blocksum(cov, mu[p0:p0 + nc], off + p0, n_full, S, 0.5, E)
+        return E
 
     # ------------------------------------------------------------------------------------------------
     def _gather_survivors(self, gid, mu, Rl, R, off, cap):

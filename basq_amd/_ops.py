@@ -165,6 +165,14 @@ class HipOps:
               "basq_init_state_f64")
         return mu, gid
 
+    def dense_sq_blocksum(self, Cmat, mu_chunk, pg0, n_full, S, scale, E):
+        """E[j, s] += scale * sum_{p in chunk, set(p)=s} mu_p * C[j, p]^2  (in place on E)."""
+        self._chk(Cmat)
+        self._chk(E)
+        m, nc = Cmat.shape
+        check(self.lib.basq_dense_sq_blocksum_f64(_ptr(Cmat), m, nc, nc, _ptr(mu_chunk), pg0, n_full, S, float(scale),
+                                                  _ptr(E), self._stream()), "basq_dense_sq_blocksum_f64")
+
     def chol_inv(self, G, rel_tol=1e-12):
         """In place: G -> L (lower).  Returns (W = L^{-T}, info[1] int32 on device)."""
         self._chk(G)

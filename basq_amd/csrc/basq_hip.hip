@@ -1268,6 +1268,38 @@ __global__ void __launch_bounds__(1024) chol_inv_lds_kernel(double* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Block sums of the SQUARE of a dense per-pair matrix (WSABI-M's 0.5 cov^2 term, BASQ/_wsabi.py:240-242):
+//     E[j][s] += scale * sum_{p in chunk, set(p) = s} mu_p * C[j][p]^2
+// C [m, nc] holds the posterior covariances of the Nystrom rows against nc consecutive candidates whose
+// first global position is pg0.  One thread per (j, s): candidates of a set are visited in position order,
+// chunks are launched in order, so the sum has a fixed order.  Reads of C are coalesced along s.
+// ------------------------------------------------------------------------------------------------
+__global__ void dense_sq_blocksum_kernel(const double* __restrict__ C, int m, long long nc, long long ldc,
+                                         const double* __restrict__ mu, long long pg0, long long n_full, int S,
+                                         double scale, double* __restrict__ E) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (s >= S || j >= m) return;
+    const double* row = C + (long long)j * ldc;
+    double acc = 0.0;
+    // block positions of set s inside [pg0, pg0 + nc)
+    const long long blk_end = (pg0 + nc < n_full) ? (pg0 + nc) : n_full;
+    long long p = pg0 + ((s - pg0 % S) % S + S) % S;          // first global position >= pg0 congruent to s
+    for (; p < blk_end; p += S) {
+        const double c = row[p - pg0];
+        acc = __builtin_fma(mu[p - pg0] * c, c, acc);
+    }
+    if (s == S - 1) {                                           // ragged tail: positions >= n_full
+        long long t = (n_full > pg0) ? n_full : pg0;
+        for (; t < pg0 + nc; ++t) {
+            const double c = row[t - pg0];
+            acc = __builtin_fma(mu[t - pg0] * c, c, acc);
+        }
+    }
+    E[(long long)j * S + s] += scale * acc;
+}
+
 __global__ void axpb_strided_kernel(const double* __restrict__ x, long long n, long long stride, double a, double b,
                                     double* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1487,6 +1519,18 @@ int basq_init_state_f64(double* mu, int64_t* gid, int64_t Rl, int64_t gid0, int6
     // torch.ones(N) / N (BASQ/_rchq.py:53): one correctly rounded division
     hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((Rl + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mu,
                        (long long*)gid, (long long)Rl, (long long)gid0, 1.0 / (double)n_total);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_dense_sq_blocksum_f64(const double* C, int32_t m, int64_t nc, int64_t ldc, const double* mu, int64_t pg0,
+                               int64_t n_full, int32_t S, double scale, double* E, void* stream) {
+    if (!C || !mu || !E || m < 1 || nc < 0 || ldc < nc || pg0 < 0 || n_full < 0 || S < 1 || n_full % S != 0)
+        return BASQ_EINVAL;
+    if (nc == 0) return BASQ_OK;
+    dim3 grid((unsigned)((S + 63) / 64), (unsigned)m);
+    hipLaunchKernelGGL(dense_sq_blocksum_kernel, grid, dim3(64), 0, (hipStream_t)stream, C, m, (long long)nc,
+                       (long long)ldc, mu, (long long)pg0, (long long)n_full, S, scale, E);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }

@@ -171,6 +171,17 @@ int basq_reweight_compact_f64(const double* cand, const double* mu, const int64_
 int basq_init_state_f64(double* mu, int64_t* gid, int64_t Rl, int64_t gid0, int64_t n_total, void* stream);
 
 /*
+ * WSABI-M extra term (BASQ/_wsabi.py:227-249: CLy = mu_x cov mu_y + 0.5 cov^2; the first product is linear in
+ * the block sums and runs through basq_blocksum_f64, the square is not):
+ *     E[j][s] += scale * sum over the nc candidates p of this chunk with set(p) = s of  mu[p] * C[j][p]^2
+ * C [m, nc] (row stride ldc) = posterior covariances of the Nystrom rows against nc consecutive candidates
+ * whose first GLOBAL position is pg0 (set(p) = p % S below n_full, S-1 from n_full on); mu is indexed from
+ * the chunk start.  E [m, S] is accumulated into (zero it first); chunks must be submitted in position order.
+ */
+int basq_dense_sq_blocksum_f64(const double* C, int32_t m, int64_t nc, int64_t ldc, const double* mu, int64_t pg0,
+                               int64_t n_full, int32_t S, double scale, double* E, void* stream);
+
+/*
  * CholeskyQR building block of the randomised range finder behind torch.svd_lowrank (BASQ/_rchq.py:29):
  * G [q,q] (symmetric positive definite, = X^T X) is overwritten by its Cholesky factor L (lower triangle;
  * the strict upper triangle is left as it was) and W [q,q] receives L^{-T} (upper triangular), so that

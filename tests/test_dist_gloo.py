@@ -43,7 +43,7 @@ def _worker(rank, world, port, name, q):
 
 
 @pytest.mark.parametrize("name,world", [("rbf_ragged", 2), ("rbf_1e4", 2), ("cfg1_posterior_1e4", 2), ("wsabil_2e4", 2),
-                                        ("rbf_ragged", 3), ("rbf_tiny_final", 2)])
+                                        ("rbf_ragged", 3), ("rbf_tiny_final", 2), ("wsabim_1e4", 2)])
 def test_sharded_engine_matches_golden(name, world):
     fx = load_golden(name)
     ctx = mp.get_context("spawn")

@@ -11,7 +11,7 @@ from basq_amd._partition import (RoundGeometry, choose_chunks, initial_shards, l
 from tests.cases import BY_NAME, CASES, build_pool, build_product_kernel, has_golden, load_golden
 from tests.cpu_stand_in import CpuStandInOps
 
-ENGINE_CASES = [c["name"] for c in CASES if not c["slow"] and c["N"] <= 30_000 and c["kernel"]["warp"] != "wsabim"]
+ENGINE_CASES = [c["name"] for c in CASES if not c["slow"] and c["N"] <= 30_000]
 
 
 def test_round_geometry_and_survivor_counts_brute_force():
@@ -96,13 +96,6 @@ def test_rank_deficient_panel_falls_back():
     torch.manual_seed(c["torch_seed"])
     idx, _ = RecombinationEngine(CpuStandInOps()).run(pts, 0, c["N"], nys, c["n"], build_product_kernel(c), tr)
     assert idx.tolist() == fx["idx"]
-
-
-def test_wsabim_is_refused_loudly():
-    c = BY_NAME["wsabim_1e4"]
-    pts, nys = build_pool(c)
-    with pytest.raises(NotImplementedError):
-        RecombinationEngine(CpuStandInOps()).run(pts, 0, c["N"], nys, c["n"], build_product_kernel(c))
 
 
 def test_pool_generator_is_stable():

@@ -219,3 +219,19 @@ def test_chol_inv_flags_rank_deficiency(hip_ops):
     X[:, 7] = X[:, 0] + X[:, 1]              # exactly dependent column
     _, info = hip_ops.chol_inv(hip_ops.to_device(X.T @ X))
     assert int(info.cpu()[0]) == 8
+
+
+@pytest.mark.parametrize("m,nc,pg0,n_full,S", [(70, 1000, 0, 1000, 50), (70, 777, 1234, 1800, 60), (33, 150, 4003, 4000, 40),
+                                               (10, 500, 100, 396, 22)])
+def test_dense_sq_blocksum_vs_standin(hip_ops, m, nc, pg0, n_full, S):
+    """WSABI-M's squared block sums, incl. a chunk that starts mid-block and one that lies wholly in the tail."""
+    cpu = CpuStandInOps()
+    Cm = _rand(m, nc, 31)
+    g = torch.Generator().manual_seed(2)
+    mu = torch.rand(nc, generator=g, dtype=torch.float64) + 0.1
+    E0 = _rand(m, S, 32)
+    Ec = E0.clone()
+    cpu.dense_sq_blocksum(Cm, mu, pg0, n_full, S, 0.5, Ec)
+    Eg = hip_ops.to_device(E0.clone())
+    hip_ops.dense_sq_blocksum(hip_ops.to_device(Cm), hip_ops.to_device(mu), pg0, n_full, S, 0.5, Eg)
+    assert (Eg.cpu() - Ec).abs().max().item() <= 1e-12 * Ec.abs().max().item()
