@@ -35,7 +35,7 @@ class BASQ:
 
 
 class KernelQuadrature:
-    def __init__(self, n_rec, n_nys, n_quad, batch_size, sampler, kernel, device, mean_predict):
+    def __init__(self, n_rec, n_nys, n_quad, batch_size, sampler, kernel, device, mean_predict=None):
         self.n_rec = n_rec
         self.n_nys = n_nys
         self.n_quad = n_quad
@@ -43,7 +43,8 @@ class KernelQuadrature:
         self.sampler = sampler
         self.kernel = kernel
         self.device = torch.device(device)
-        self.mean_predict = mean_predict
+        # reference: ``self.predict_mean`` of the GP wrapper (_parameters.py:174-190); structured kernels carry it
+        self.mean_predict = mean_predict if mean_predict is not None else getattr(kernel, "predict_mean", None)
 
     def rchq(self, pts_nys, pts_rec, w_IS, batch_size, kernel):
         idx, w = recombination(pts_rec, pts_nys, batch_size, kernel, self.device, init_weights=w_IS)

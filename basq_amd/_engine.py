@@ -383,35 +383,41 @@ class RecombinationEngine:
                 t0 = time.perf_counter()
             parts = comm.all_gather(msg) if comm.world > 1 else msg.unsqueeze(0)
             M = S_r
-            res = ops.empty(2 + 2 * s + 2 * M)                   # info | kept | w_star | keep_rank | tot
             if comm.rank == 0:
                 XcarT, tot = ops.finalize(parts, comm.world, q_ext + 1, q, S_r, diagU, m, min(m, S_r), diag_noise, wrow)
                 t1 = time.perf_counter()
-                Xh = XcarT.cpu()
+                Xh = ops.to_host(XcarT, "xcar")
                 with _lapack_threads(HOST_SVD_THREADS):
                     Vh = torch.linalg.svd(Xh)[2]                 # :140 full SVD of [s, M] on host LAPACK
-                PhiT = ops.to_device(Vh[-(M - s):, :])           # :143 (rows = null-space vectors)
+                PhiT = ops.from_host(Vh[-(M - s):, :], "phit")   # :143 (rows = null-space vectors)
                 if trace is not None:
                     trace.add_time("host_svd", time.perf_counter() - t1)
                 mu_car = tot.clone()
                 with _Timer(ops, trace, "eliminate"):
                     keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, mu_car, M, s)
-                res[0:2] = info.to(torch.float64)
-                res[2:2 + s] = kept.to(torch.float64)
-                res[2 + s:2 + 2 * s] = w_star
-                res[2 + 2 * s:2 + 2 * s + M] = keep_rank.to(torch.float64)
-                res[2 + 2 * s + M:] = tot
             if comm.world > 1:
+                # one broadcast of the (tiny) reduction result: info | kept | w_star | keep_rank | tot
+                res = ops.empty(2 + 2 * s + 2 * M)
+                if comm.rank == 0:
+                    res[0:2] = info.to(torch.float64)
+                    res[2:2 + s] = kept.to(torch.float64)
+                    res[2 + s:2 + 2 * s] = w_star
+                    res[2 + 2 * s:2 + 2 * s + M] = keep_rank.to(torch.float64)
+                    res[2 + 2 * s + M:] = tot
                 comm.broadcast(res)
-            head = res[:2 + s].cpu()
-            n_keep, status = int(head[0]), int(head[1])
+                head = ops.to_host(res[:2 + s], "head")
+                n_keep, status = int(head[0]), int(head[1])
+                kept_list = [int(v) for v in head[2:2 + n_keep]]
+                w_star = res[2 + s:2 + 2 * s].contiguous()
+                keep_rank = res[2 + 2 * s:2 + 2 * s + M].to(torch.int32)
+                tot = res[2 + 2 * s + M:].contiguous()
+            else:
+                head = ops.to_host(torch.cat([info, kept]), "head")     # one D2H for status + survivor list
+                n_keep, status = int(head[0]), int(head[1])
+                kept_list = [int(v) for v in head[2:2 + n_keep]]
             if status != 0:
                 raise RuntimeError("Caratheodory elimination: a null vector has no positive entry "
                                    "(the reference fails here too: argmin of an empty tensor, _rchq.py:152)")
-            kept_list = [int(v) for v in head[2:2 + n_keep]]
-            w_star = res[2 + s:2 + 2 * s].contiguous()
-            keep_rank = res[2 + 2 * s:2 + 2 * s + M].to(torch.int32)
-            tot = res[2 + 2 * s + M:].contiguous()
             if trace is not None:
                 if trace.host_sync:
                     ops.synchronize()

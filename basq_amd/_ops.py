@@ -139,9 +139,9 @@ class HipOps:
         self._chk(PhiT)
         self._chk(mu)
         keep_rank = self.empty(M, dtype=torch.int32)
-        kept = self.empty(max(s, 1), dtype=torch.int32)
+        ik = self.empty(2 + max(s, 1), dtype=torch.int32)      # [info(2) | kept(s)]: one D2H copy reads both
+        info, kept = ik[:2], ik[2:]
         w_star = self.empty(max(s, 1))
-        info = self.empty(2, dtype=torch.int32)
         check(self.lib.basq_car_eliminate_f64(_ptr(PhiT), _ptr(mu), M, s, _ptr(keep_rank), _ptr(kept), _ptr(w_star),
                                               _ptr(info), self._stream()), "basq_car_eliminate_f64")
         return keep_rank, kept, w_star, info
@@ -198,6 +198,30 @@ class HipOps:
     # -- plumbing (library GEMMs of the randomised SVD; rocBLAS via torch) ---------------------
     def matmul(self, A, B):
         return torch.matmul(A, B)
+
+    # -- host <-> device staging through cached pinned buffers (per-round 160 KB / 80 KB / 0.4 KB copies) ---------
+    def _pinned(self, shape, dtype, tag):
+        cache = self.__dict__.setdefault("_pin_cache", {})
+        key = (tag, tuple(shape), dtype)
+        buf = cache.get(key)
+        if buf is None:
+            buf = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
+            cache[key] = buf
+        return buf
+
+    def to_host(self, t, tag="d2h"):
+        """Device -> pinned host tensor (synchronises the stream).  The buffer is reused by the next call with
+        the same tag and shape: consume it before then."""
+        buf = self._pinned(t.shape, t.dtype, tag)
+        buf.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return buf
+
+    def from_host(self, t, tag="h2d"):
+        """Host tensor -> device through a pinned staging buffer (asynchronous on the current stream)."""
+        buf = self._pinned(t.shape, t.dtype, tag)
+        buf.copy_(t)
+        return buf.to(self.device, non_blocking=True)
 
     def synchronize(self):
         torch.cuda.current_stream(self.device).synchronize()

@@ -83,11 +83,14 @@ class PosteriorKernel:
 
     warp = "none"
 
-    def __init__(self, base: StationaryKernel, Xobs, woodbury_inv, noise: float):
+    def __init__(self, base: StationaryKernel, Xobs, woodbury_inv, noise: float, mean_const: float | None = None,
+                 mean_cache=None):
         self.base = base
         self.Xobs = Xobs
         self.W = woodbury_inv
         self.noise = float(noise)
+        self.mean_const = None if mean_const is None else float(mean_const)   # for predict_mean (quadrature)
+        self.mean_cache = mean_cache
 
     @property
     def posterior(self):
@@ -111,12 +114,39 @@ class PosteriorKernel:
         y = y.to(torch.float64).contiguous()
         return self.dense(_ops_for(x), x, y)
 
+    def gp_mean(self, ops, x, center=None):
+        """GP posterior mean ``predict(x, model)[0]`` (``BASQ/_gp.py:213-230``) through the HIP kernel mat-vec."""
+        if self.mean_cache is None or self.mean_const is None:
+            raise ValueError("PosteriorKernel was built without the GP mean (mean_const / mean_cache)")
+        spec = self.base.spec(x.shape[1])
+        Xo = ops.to_device(self.Xobs, torch.float64)
+        v = ops.to_device(self.mean_cache, torch.float64)
+        if center is None:
+            center = ops.col_mean(x)
+        pa = ops.pack(spec, x, center, ROLE_A, pad_rows_to=64)
+        pb = ops.pack(spec, Xo, center, ROLE_B)
+        return ops.matvec(spec, pa, x.shape[0], pb, Xo.shape[0], v, self.mean_const)
+
+    def gp_variance(self, ops, x, center=None):
+        """Predictive variance of ``predict`` (``model.likelihood(model(x)).variance``): diag of the posterior + noise."""
+        Xo = ops.to_device(self.Xobs, torch.float64)
+        W = ops.to_device(self.W, torch.float64)
+        if center is None:
+            center = ops.col_mean(x)
+        KxX = self.base.dense(ops, x, Xo, center)
+        return self.base.outputscale - ((KxX @ W) * KxX).sum(1) + self.noise
+
+    def predict_mean(self, x):
+        """``VanillaGP.predict_mean`` (``BASQ/_vbq.py:141-151``): the ``mean_predict`` of the quadrature."""
+        x = x.to(torch.float64).contiguous()
+        return self.gp_mean(_ops_for(x), x)
+
 
 class WsabiKernel:
     """``mu(x) cov(x,y) mu(y)`` (+ ``0.5 cov^2`` for WSABI-M), ``mu`` = warped-GP posterior mean."""
 
     def __init__(self, post: PosteriorKernel, mean_const: float, mean_cache, label: str = "wsabil",
-                 jitter: float = 0.0):
+                 jitter: float = 0.0, alpha: float = 0.0):
         if label not in ("wsabil", "wsabim"):
             raise ValueError(label)
         self.posterior = post
@@ -125,6 +155,7 @@ class WsabiKernel:
         self.mean_cache = mean_cache
         self.warp = label
         self.jitter = float(jitter)
+        self.alpha = float(alpha)          # WSABI offset: l = alpha + 0.5 l~^2  (BASQ/_wsabi.py:102-121)
 
     def mean(self, ops, x, center=None):
         """``predict(x, model)[0]`` (``BASQ/_gp.py:213-230``) = const + k(x, Xobs) @ mean_cache, via the HIP mat-vec."""
@@ -153,8 +184,18 @@ class WsabiKernel:
         y = y.to(torch.float64).contiguous()
         return self.dense(_ops_for(x), x, y)
 
+    def predict_mean(self, x):
+        """``wsabil_mean_predict`` / ``wsabim_mean_predict`` (``BASQ/_wsabi.py:278-300``)."""
+        x = x.to(torch.float64).contiguous()
+        ops = _ops_for(x)
+        center = ops.col_mean(x)
+        mu_w = self.mean(ops, x, center)
+        if self.warp == "wsabil":
+            return self.alpha + 0.5 * mu_w ** 2
+        return self.alpha + 0.5 * (mu_w ** 2 + self.posterior.gp_variance(ops, x, center))
 
-def from_gpytorch_model(model, kind: str = "predictive", wsabi_label: str = "wsabil"):
+
+def from_gpytorch_model(model, kind: str = "predictive", wsabi_label: str = "wsabil", wsabi_alpha: float = 0.0):
     """Build a kernel object from a fitted gpytorch ``ExactGP`` (duck-typed; gpytorch is not imported).
 
     ``kind``: ``"prior"`` -> ``model.covar_module.forward`` (``_quadrature.py:101``);
@@ -182,11 +223,11 @@ def from_gpytorch_model(model, kind: str = "predictive", wsabi_label: str = "wsa
     Xobs = model.train_inputs[0].detach()
     noise = float(model.likelihood.noise.detach().reshape(-1)[0])
     S = model.prediction_strategy.covar_cache.detach()
-    post = PosteriorKernel(base, Xobs, S @ S.T, noise)       # _gp.py:255
+    mean_cache = model.prediction_strategy.mean_cache.detach()
+    const = float(model.mean_module.constant.detach().reshape(-1)[0])
+    post = PosteriorKernel(base, Xobs, S @ S.T, noise, const, mean_cache)       # _gp.py:255
     if kind == "predictive":
         return post
     if kind == "wsabi":
-        mean_cache = model.prediction_strategy.mean_cache.detach()
-        const = float(model.mean_module.constant.detach().reshape(-1)[0])
-        return WsabiKernel(post, const, mean_cache, wsabi_label)
+        return WsabiKernel(post, const, mean_cache, wsabi_label, alpha=wsabi_alpha)
     raise ValueError(kind)

@@ -213,6 +213,12 @@ class CpuStandInOps:
     def gemm(self, A, B, alpha=1.0):
         return alpha * (A @ B)
 
+    def to_host(self, t, tag="d2h"):
+        return t
+
+    def from_host(self, t, tag="h2d"):
+        return t.contiguous()
+
     def synchronize(self):
         pass
 

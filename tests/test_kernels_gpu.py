@@ -235,3 +235,48 @@ def test_dense_sq_blocksum_vs_standin(hip_ops, m, nc, pg0, n_full, S):
     Eg = hip_ops.to_device(E0.clone())
     hip_ops.dense_sq_blocksum(hip_ops.to_device(Cm), hip_ops.to_device(mu), pg0, n_full, S, 0.5, Eg)
     assert (Eg.cpu() - Ec).abs().max().item() <= 1e-12 * Ec.abs().max().item()
+
+
+def test_quadrature_step_vs_oracle(hip_ops):
+    """EZy = w . mean_predict(X), VarZy = w^T K(X, X) w with the structured kernels' own mean
+    (BASQ/_quadrature.py:53-64), against the oracle's CPU kernels."""
+    import basq_amd
+    from basq_amd.pools import gmm_pool, prior_sampler_split
+    from oracle.kernels_oracle import PosteriorOracle, StationaryOracle, WsabiOracle, synthetic_gp_state
+    from oracle.rchq_oracle import recombination_oracle
+
+    d, n_obs, N, n = 5, 60, 6000, 30
+    Xobs = gmm_pool(n_obs, d, 41)
+    base_o = StationaryOracle("rbf", 1.8, 1.1)
+    W, const, mc, _ = synthetic_gp_state(Xobs, base_o, 1e-8, 3)
+    alpha = 0.4
+    K = basq_amd.kernels
+    post = K.PosteriorKernel(K.StationaryKernel("rbf", 1.8, 1.1), Xobs, W, 1e-8, const, mc)
+    for label in ("wsabil", "wsabim"):
+        kern = K.WsabiKernel(post, const, mc, label, alpha=alpha)
+        kern_o = WsabiOracle(PosteriorOracle(base_o, Xobs, W, 1e-8), const, mc, label)
+        pool = gmm_pool(N, d, 42)
+
+        def sampler(k):
+            return prior_sampler_split(pool[:k], n_nys=60)
+
+        kq = basq_amd.KernelQuadrature(N, 60, N, n, sampler, kern, "cuda:0")
+        torch.manual_seed(5)
+        EZy, VarZy = kq.quadrature()
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float64)
+        try:
+            torch.manual_seed(5)
+            idx, w = recombination_oracle(pool, pool[:60], n, kern_o)
+        finally:
+            torch.set_default_dtype(prev)
+        X = pool[idx]
+        mu_w = kern_o.mean(X)
+        if label == "wsabil":
+            mean = alpha + 0.5 * mu_w ** 2
+        else:
+            kxX = base_o(X, Xobs)
+            var = 1.1 - ((kxX @ W) * kxX).sum(1) + 1e-8
+            mean = alpha + 0.5 * (mu_w ** 2 + var)
+        assert EZy == pytest.approx(float(w @ mean), rel=1e-8)
+        assert VarZy == pytest.approx(float(w @ kern_o(X, X) @ w), rel=1e-6, abs=1e-14)
