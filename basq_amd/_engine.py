@@ -297,7 +297,7 @@ class RecombinationEngine:
         pre = None
         if R > S:
             geo = RoundGeometry.of(R, S)
-            n_chunks = choose_chunks(local_blocks(off, Rl, geo), m_ext, S)
+            n_chunks = choose_chunks(local_blocks(off, Rl, geo), m_ext, S, kp // 4)
             ev0 = ops.record_event() if (trace is not None and trace.time_kernels) else None
             Xpart, totpart = ops.blocksum(spec, nys_ext, m_ext, cand, mu, wx, Rl, off, geo.n_full, S, n_chunks)
             if ev0 is not None:
@@ -360,7 +360,7 @@ class RecombinationEngine:
                 Xpart, totpart, n_chunks = pre
                 pre = None
             else:
-                n_chunks = choose_chunks(local_blocks(off, Rl, geo), m_ext, S_r)
+                n_chunks = choose_chunks(local_blocks(off, Rl, geo), m_ext, S_r, kp // 4)
                 ev0 = ops.record_event() if (trace is not None and trace.time_kernels) else None
                 with _Timer(ops, trace, "blocksum"):
                     Xpart, totpart = ops.blocksum(spec, nys_ext, m_ext, cand, mu, wx, Rl, off, geo.n_full, S_r,

@@ -70,29 +70,35 @@ def local_blocks(off: int, Rl: int, geo: RoundGeometry) -> int:
     return (lim + geo.S - 1) // geo.S - off // geo.S
 
 
-# Launch geometry of the block-sum kernel (must mirror basq_hip.hip): a wave covers 64 Nystrom rows x
-# SETS_PER_WAVE sets, 4 waves per work-group; RESIDENT_WAVES = 256 CUs x 4 SIMDs x 3 waves (register-limited).
+# Launch geometry of the block-sum kernel (must mirror basq_hip.hip): a wave covers rows_per_wave(kk) Nystrom rows
+# x SETS_PER_WAVE sets, 4 waves per work-group; RESIDENT_WAVES = 256 CUs x 4 SIMDs x 3 waves (register-limited).
 SETS_PER_WAVE = 16
 RESIDENT_WAVES = 256 * 4 * 3
 
 
-def choose_chunks(n_local_blocks: int, m: int, S: int, max_chunks: int = 32, min_blocks: int = 4,
-                  sets_per_wave: int = SETS_PER_WAVE, resident: int = RESIDENT_WAVES) -> int:
+def rows_per_wave(kk: int) -> int:
+    """BASQ_JT_FOR(KK) * 16 in basq_hip.hip: 64 rows per wave up to KP = 20, 32 beyond."""
+    return 32 if kk >= 6 else 64
+
+
+def choose_chunks(n_local_blocks: int, m: int, S: int, kk: int = 3, max_chunks: int = 32, min_blocks: int = 4,
+                  resident: int = RESIDENT_WAVES) -> int:
     """Number of chunks the block loop is split into.
 
     All waves of a launch do the same amount of work, so the launch takes ``ceil(waves / resident)``
     "rounds": 4800 waves on 3072 resident slots cost 2 rounds for 1.56 rounds of work (measured: 22 % of
     the kernel time).  Pick the smallest chunk count whose efficiency ``(waves/resident) /
-    ceil(waves/resident)`` reaches 95 % (fewer chunks = less partial-sum traffic for the projection), else
-    the most efficient one.
+    ceil(waves/resident)`` reaches 96 % (fewer chunks = less partial-sum traffic for the projection), else
+    the most efficient one.  ``kk`` = packed row length / 4.
     """
-    per_chunk = ((m + 255) // 256) * 4 * ((S + sets_per_wave - 1) // sets_per_wave)
+    rows_per_block = 4 * rows_per_wave(kk)
+    per_chunk = ((m + rows_per_block - 1) // rows_per_block) * 4 * ((S + SETS_PER_WAVE - 1) // SETS_PER_WAVE)
     cap = max(1, min(max_chunks, n_local_blocks // min_blocks))
     best, best_eff = 1, -1.0
     for c in range(1, cap + 1):
         rounds = per_chunk * c / resident
         eff = rounds / max(1.0, float(-(-per_chunk * c // resident)))
-        if eff >= 0.95:
+        if eff >= 0.96:
             return c
         if eff > best_eff + 1e-9:
             best, best_eff = c, eff

@@ -58,15 +58,24 @@ __device__ __forceinline__ double exp_nonpos(double x) {
 //      degree-5 polynomial                                                       (11 fp64 VALU + ds_read)
 //   2  the same with the table in global memory (L1-resident; vmcnt instead of lgkmcnt, so the wait for
 //      the table value does not drain the in-flight scalar loads of the next candidate row)
+//   3  x = (2048n + j) ln2/2048 + r, 16-KB LDS table, degree-3 polynomial          (9 fp64 VALU + ds_read)
 #ifndef BASQ_EXP_MODE
-#define BASQ_EXP_MODE 1
+#define BASQ_EXP_MODE 3
 #endif
 
+#if BASQ_EXP_MODE == 3
+#define BASQ_TAB_N 2048
+__device__ const double basq_exp_tab_g[2048] = BASQ_EXP_TAB2048;
+#else
+#define BASQ_TAB_N 32
 __device__ const double basq_exp_tab_g[32] = BASQ_EXP_TAB;
+#endif
 
 struct ExpK {
 #if BASQ_EXP_MODE == 0
     double log2e, nhi, nlo, magic, p[11];
+#elif BASQ_EXP_MODE == 3
+    double k32, nhi, nlo, magic, c3, c2, one;
 #else
     double k32, nhi, nlo, magic, c5, c4, c3, c2, one;
 #endif
@@ -87,6 +96,13 @@ __device__ __forceinline__ void expk_init(ExpK& k) {
                           BASQ_EXP_P6, BASQ_EXP_P7, BASQ_EXP_P8, BASQ_EXP_P9, BASQ_EXP_P10};
 #pragma unroll
     for (int i = 0; i < 11; ++i) k.p[i] = vgpr_const(c[i]);
+#elif BASQ_EXP_MODE == 3
+    k.k32 = vgpr_const(BASQ_2048_OVER_LN2);
+    k.nhi = vgpr_const(-BASQ_LN2_2048_HI);
+    k.nlo = vgpr_const(-BASQ_LN2_2048_LO);
+    k.c3 = vgpr_const(BASQ_EXP_U3);
+    k.c2 = vgpr_const(BASQ_EXP_U2);
+    k.one = vgpr_const(1.0);
 #else
     k.k32 = vgpr_const(BASQ_32_OVER_LN2);
     k.nhi = vgpr_const(-BASQ_LN2_32_HI);
@@ -113,14 +129,20 @@ __device__ __forceinline__ double exp_nonpos_k(double x, const ExpK& k, const do
 #else
     const double t = __builtin_fma(x, k.k32, k.magic);
     const int ti = __double2loint(t);                 // 32 n + j  (two's complement)
-#if BASQ_EXP_MODE == 1
-    const double T = tab[ti & 31];
-#else
+#if BASQ_EXP_MODE == 2
     const double T = basq_exp_tab_g[ti & 31];
+#else
+    const double T = tab[ti & (BASQ_TAB_N - 1)];
 #endif
     const double nf = t - k.magic;
     double r = __builtin_fma(nf, k.nhi, x);
     r = __builtin_fma(nf, k.nlo, r);
+#if BASQ_EXP_MODE == 3
+    double w = __builtin_fma(k.c3, r, k.c2);
+    w = __builtin_fma(w, r, k.one);
+    const double e = __builtin_fma(T * r, w, T);      // T (1 + r w)
+    return ldexp(e, ti >> 11);
+#else
     double w = __builtin_fma(k.c5, r, k.c4);
     w = __builtin_fma(w, r, k.c3);
     w = __builtin_fma(w, r, k.c2);
@@ -128,11 +150,12 @@ __device__ __forceinline__ double exp_nonpos_k(double x, const ExpK& k, const do
     const double e = __builtin_fma(T * r, w, T);      // T (1 + r w)
     return ldexp(e, ti >> 5);
 #endif
+#endif
 }
 
 __device__ __forceinline__ void exp_table_init(double* tab) {
-#if BASQ_EXP_MODE == 1
-    if (threadIdx.x < 32) tab[threadIdx.x] = basq_exp_tab_g[threadIdx.x];
+#if BASQ_EXP_MODE == 1 || BASQ_EXP_MODE == 3
+    for (int i = threadIdx.x; i < BASQ_TAB_N; i += blockDim.x) tab[i] = basq_exp_tab_g[i];
     __syncthreads();
 #endif
 }
@@ -294,7 +317,7 @@ __global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A) {
     const int chunk = b % A.n_chunks;
     const int jg = b / A.n_chunks;
     const int j0 = (jg * 4 + wave) * (16 * JT);
-    __shared__ double exp_tab[32];
+    __shared__ double exp_tab[BASQ_TAB_N];
     exp_table_init(exp_tab);   // the only barrier of this kernel, before any early exit
     if (j0 >= A.m) return;     // wave-uniform
     const int s0 = st * 16;
@@ -321,16 +344,63 @@ __global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A) {
     if (bB > A.blk_hi) bB = A.blk_hi;
 
     if (bA < bB) {
-        long long pg = bA * A.S + s0 + c;   // global position of this lane's column in block bA
-        CandFrag<KK> cur, nxt;
-        load_cand<KK>(cur, A, pg - A.off, col_ok && pg >= A.off && pg < lim, g);
-        for (long long i = bA; i < bB; ++i) {
-            pg += A.S;
-            const bool more = (i + 1 < bB);
-            load_cand<KK>(nxt, A, pg - A.off, more && col_ok && pg >= A.off && pg < lim, g);
-            tile_accumulate<KK, FAM, JT>(a, cur, acc, ek, exp_tab);
-            tot += cur.wm;
-            cur = nxt;
+        // Blocks whose 16 columns all lie inside this rank's block positions take the fast path: the lane's
+        // row pointer just advances by S rows per block (no masks, no 64-bit index arithmetic).  [bF0, bF1) is
+        // that wave-uniform range; the (at most two) edge blocks before/after it use the masked path.
+        const long long first_ok = (A.off - s0 + A.S - 1) / A.S;                 // smallest i with i*S + s0 >= off
+        const long long last_ok = (lim - s0 - 16 >= 0) ? ((lim - s0 - 16) / A.S) : -1;   // largest i with i*S+s0+15 < lim
+        const bool tile_full = (s0 + 16) <= A.S;
+        long long bF0 = tile_full ? (first_ok > bA ? first_ok : bA) : bB;
+        long long bF1 = tile_full ? ((last_ok + 1 < bB) ? (last_ok + 1) : bB) : bB;
+        if (bF1 < bF0) bF1 = bF0;
+        if (bF0 > bB) bF0 = bF1 = bB;
+        // masked prologue blocks [bA, bF0)
+        for (long long i = bA; i < bF0; ++i) {
+            const long long pg = i * A.S + s0 + c;
+            CandFrag<KK> f;
+            load_cand<KK>(f, A, pg - A.off, col_ok && pg >= A.off && pg < lim, g);
+            tile_accumulate<KK, FAM, JT>(a, f, acc, ek, exp_tab);
+            tot += f.wm;
+        }
+        if (bF0 < bF1) {
+            const long long p0 = bF0 * A.S + s0 + c - A.off;                     // local row of this lane, block bF0
+            const double* rp = A.cand + p0 * KP + g;
+            const double* mp = A.mu + p0;
+            const double* xp = A.wx ? (A.wx + p0) : nullptr;
+            const long long rstep = (long long)A.S * KP;
+            CandFrag<KK> cur, nxt;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) cur.b[kk] = rp[kk * 4];
+            cur.wm = mp[0];
+            cur.w = xp ? cur.wm * xp[0] : cur.wm;
+            for (long long i = bF0; i < bF1; ++i) {
+                const bool more = (i + 1 < bF1);
+                const double* rn = more ? (rp + rstep) : rp;                     // last trip re-reads its own row
+                const double* mn = more ? (mp + A.S) : mp;
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) nxt.b[kk] = rn[kk * 4];
+                nxt.wm = mn[0];
+                if (xp) {
+                    const double* xn = more ? (xp + A.S) : xp;
+                    nxt.w = nxt.wm * xn[0];
+                    xp = xn;
+                } else {
+                    nxt.w = nxt.wm;
+                }
+                tile_accumulate<KK, FAM, JT>(a, cur, acc, ek, exp_tab);
+                tot += cur.wm;
+                cur = nxt;
+                rp = rn;
+                mp = mn;
+            }
+        }
+        // masked epilogue blocks [bF1, bB)
+        for (long long i = bF1; i < bB; ++i) {
+            const long long pg = i * A.S + s0 + c;
+            CandFrag<KK> f;
+            load_cand<KK>(f, A, pg - A.off, col_ok && pg >= A.off && pg < lim, g);
+            tile_accumulate<KK, FAM, JT>(a, f, acc, ek, exp_tab);
+            tot += f.wm;
         }
     }
 
@@ -375,10 +445,14 @@ __global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A) {
     }
 }
 
+// Row tiles per wave: 4 (64 Nystrom rows) while the A fragments fit comfortably; 2 for KP >= 24 (d >= 21), where
+// 4 x KP/4 fragment registers would push the kernel to one wave per SIMD.  basq_amd/_partition.py mirrors this.
+#define BASQ_JT_FOR(KK) ((KK) >= 6 ? 2 : 4)
+
 template <int KK, int FAM>
 static int launch_blocksum(const BlocksumArgs& A, hipStream_t st) {
-    constexpr int JT = 4;
-    const int jgroups = (A.m + 64 * JT - 1) / (64 * JT);   // 4 waves x 64 rows per block
+    constexpr int JT = BASQ_JT_FOR(KK);
+    const int jgroups = (A.m + 64 * JT - 1) / (64 * JT);   // 4 waves x 16*JT rows per block
     const long long nblk = (long long)A.n_stiles * A.n_chunks * jgroups;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return BASQ_EINVAL;
     hipLaunchKernelGGL((blocksum_kernel<KK, FAM, JT>), dim3((unsigned)nblk), dim3(256), 0, st, A);
@@ -509,7 +583,7 @@ blocksum_valu_kernel(const double* __restrict__ nys, const double* __restrict__ 
     const int chunk = b % n_chunks;
     const int jg = b / n_chunks;
     const int jw = (jg * 4 + wave) * (64 * TJ);
-    __shared__ double exp_tab[32];
+    __shared__ double exp_tab[BASQ_TAB_N];
     exp_table_init(exp_tab);                   // the only barrier of this kernel, before any early exit
     if (jw >= m) return;                       // wave-uniform
     const int mrows = ((m + 63) / 64) * 64;    // rows the caller allocated (padded to a multiple of 64)

@@ -35,7 +35,7 @@ def main():
     B = ops.pack(spec, pts, c, 1)
     mu, _ = ops.init_state(args.R, 0, args.R)
     geo = RoundGeometry.of(args.R, S)
-    nch = args.chunks or choose_chunks(local_blocks(0, args.R, geo), args.m, S)
+    nch = args.chunks or choose_chunks(local_blocks(0, args.R, geo), args.m, S, ops.kp(args.d) // 4)
     pairs = float(args.R) * args.m
     out = {}
     impls = ("mfma", "valu") if args.d <= 10 else ("mfma",)
