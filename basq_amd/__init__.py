@@ -7,15 +7,16 @@ Public surface (mirrors the reference's names):
     KernelQuadrature(...).rchq / .quadrature
     kernels.StationaryKernel / PosteriorKernel / WsabiKernel / from_gpytorch_model
     GaussianCalc(prior, device).unimodal_approximation / uniform_transformation
+    sober.recombination(pts_rec, pts_nys, num_pts, kernel, device, dtype, init_weights)   (SOBER/_rchq.py flavour)
 
 Importing the package does not touch the GPU; the HIP library is loaded on first use and its
 absence is an error (there is no CPU fallback).
 """
-from . import kernels, pools                                  # noqa: F401
+from . import kernels, pools, sober                           # noqa: F401
 from ._basq import BASQ, KernelQuadrature                      # noqa: F401
 from ._engine import EngineTrace                               # noqa: F401
 from ._gaussian_calc import GaussianCalc                       # noqa: F401
 from ._rchq import recombination, recombination_sharded        # noqa: F401
 
 __all__ = ["recombination", "recombination_sharded", "BASQ", "KernelQuadrature", "GaussianCalc", "EngineTrace", "kernels",
-           "pools"]
+           "pools", "sober"]

@@ -229,18 +229,55 @@ def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None):
         return (-1 * U.t()).contiguous()                       # :30
 
 
+def _make_cov_psd(A, max_iter: int = 10):
+    """``SafeTensorOperator.make_cov_psd`` (``SOBER/_utils.py:128-154``) for the Nystrom Gram, on the device.
+
+    The reference tests exact symmetry + Cholesky + ``eig >= 0``; a kernel Gram computed in floating point
+    is never bitwise symmetric, so its repair branch ``cov <- sqrt(cov * cov.T)`` always runs: that is done here
+    unconditionally.  The follow-up PSD test uses Cholesky only (an O(m^3) ``eig`` of a 1e4 x 1e4 matrix is
+    not affordable); when it fails, the reference's diagonal-jitter loop is reproduced.
+    """
+    A = torch.sqrt(torch.nan_to_num(A) * torch.nan_to_num(A).T)
+
+    def psd(M_):
+        return int(torch.linalg.cholesky_ex(M_).info.item()) == 0
+
+    if not psd(A):
+        n = A.shape[0]
+        jitter = torch.full((n,), 1e-5, dtype=A.dtype, device=A.device)
+        it = 0
+        while not psd(A):
+            A.diagonal().add_(jitter)
+            jitter = jitter * 2
+            it += 1
+            if it > max_iter:
+                A = torch.diag(torch.diagonal(A))
+                break
+    return A
+
+
 class RecombinationEngine:
     def __init__(self, ops, comm=None):
         self.ops = ops
         self.comm = comm or LocalComm()
 
     # ------------------------------------------------------------------------------------------------
-    def run(self, pts_local, gid0: int, n_total: int, pts_nys, num_pts: int, kernel, trace: EngineTrace | None = None):
+    def run(self, pts_local, gid0: int, n_total: int, pts_nys, num_pts: int, kernel, trace: EngineTrace | None = None,
+            variant: str = "basq", init_weights=None):
         """Recombine.  ``pts_local`` = this rank's contiguous slice ``[gid0, gid0 + len)`` of the pool.
+
+        ``variant="basq"`` follows ``BASQ/_rchq.py`` (uniform start weights, ``init_weights`` ignored);
+        ``variant="sober"`` follows ``SOBER/_rchq.py``: ``init_weights`` (this rank's slice of them)
+        are honoured and zero-weight points dropped, the Nystrom Gram goes through ``make_cov_psd``, the ragged
+        remainder is additionally added to sets ``0..N_rest-1`` (:127-135), and an elimination that finds no
+        positive entry stops early instead of failing (:240-242).
 
         Returns ``(idx int64[<=num_pts] ascending, w float64)`` on the ops device (identical on every rank).
         """
         ops, comm = self.ops, self.comm
+        if variant not in ("basq", "sober"):
+            raise ValueError(variant)
+        sober = variant == "sober"
         if n_total >= 2 ** 31:
             raise ValueError("pool sizes >= 2^31 are not supported")
         pts_nys = ops.to_device(pts_nys, torch.float64)
@@ -291,6 +328,25 @@ class RecombinationEngine:
         if warp != "none":
             wx = kernel.mean(ops, pts_local, center) if Rl > 0 else ops.empty(1)
         off, R = gid0, n_total
+        if sober and init_weights is not None:
+            # SOBER/_rchq.py:60-64: start from the given weights, drop the zero-weight points up front
+            w0 = ops.to_device(init_weights, torch.float64)
+            if w0.shape[0] != Rl:
+                raise ValueError("init_weights must have one entry per local candidate")
+            nz = torch.nonzero(w0 != 0).reshape(-1)
+            cand, mu, gid = cand[nz].contiguous(), w0[nz].contiguous(), gid[:Rl][nz].contiguous()
+            if wx is not None:
+                wx = wx[nz].contiguous()
+            if cand_raw is not None:
+                cand_raw = cand_raw[nz].contiguous()
+            Rl = int(nz.numel())
+            counts = torch.tensor([float(Rl)], dtype=torch.float64, device=mu.device)
+            if comm.world > 1:
+                counts = comm.all_gather(counts).reshape(-1)
+            counts = [int(v) for v in counts.cpu()]
+            off, R = sum(counts[:comm.rank]), sum(counts)
+            if Rl == 0:                                         # keep pointers valid for empty shards
+                cand, mu, gid = ops.zeros(1, kp), ops.zeros(1), ops.zeros(1, dtype=torch.int64)
 
         # ---- round-1 block sums are queued BEFORE the basis: they do not depend on U, and the ~12 ms CPU
         #      randn of the range finder then overlaps with the largest kernel of the batch ----------------
@@ -309,6 +365,8 @@ class RecombinationEngine:
         if comm.rank == 0:
             with _Timer(ops, trace, "basis.gram"):
                 A = kernel.dense(ops, pts_nys, pts_nys, center)
+                if sober:
+                    A = _make_cov_psd(A)
             U = nystrom_basis(ops, A, num_pts - 1, trace)
             del A
             assert U.shape[0] == q
@@ -368,6 +426,15 @@ class RecombinationEngine:
                 if ev0 is not None:
                     trace.kernel_events.append((ev0, ops.record_event(), dict(pairs=float(Rl) * m_ext, R=Rl, m=m_ext,
                                                                              S=S_r, chunks=n_chunks)))
+            if sober and not final and geo.n_tail > 0:
+                # SOBER/_rchq.py:127-135: the remainder's kernel columns also go to sets 0..N_rest-1 (no weight added)
+                t0l = max(geo.n_full - off, 0)                   # first local tail position
+                if t0l < Rl:
+                    Xt, _ = ops.blocksum(spec, nys_ext, m_ext, cand[t0l:], mu[t0l:], None if wx is None else wx[t0l:],
+                                         Rl - t0l, off + t0l - geo.n_full, S_r, S_r, 1)
+                    Xpart = torch.cat([Xpart, Xt], 0)
+                    totpart = torch.cat([totpart, ops.zeros(1, S_r)], 0)
+                    n_chunks += 1
             with _Timer(ops, trace, "project"):
                 msg = ops.project(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S_r, spec.outputscale)
             if warp == "wsabim":
@@ -397,25 +464,25 @@ class RecombinationEngine:
                     keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, mu_car, M, s)
             if comm.world > 1:
                 # one broadcast of the (tiny) reduction result: info | kept | w_star | keep_rank | tot
-                res = ops.empty(2 + 2 * s + 2 * M)
+                res = ops.empty(2 + 4 * M)
                 if comm.rank == 0:
                     res[0:2] = info.to(torch.float64)
-                    res[2:2 + s] = kept.to(torch.float64)
-                    res[2 + s:2 + 2 * s] = w_star
-                    res[2 + 2 * s:2 + 2 * s + M] = keep_rank.to(torch.float64)
-                    res[2 + 2 * s + M:] = tot
+                    res[2:2 + M] = kept.to(torch.float64)
+                    res[2 + M:2 + 2 * M] = w_star
+                    res[2 + 2 * M:2 + 3 * M] = keep_rank.to(torch.float64)
+                    res[2 + 3 * M:] = tot
                 comm.broadcast(res)
-                head = ops.to_host(res[:2 + s], "head")
+                head = ops.to_host(res[:2 + M], "head")
                 n_keep, status = int(head[0]), int(head[1])
                 kept_list = [int(v) for v in head[2:2 + n_keep]]
-                w_star = res[2 + s:2 + 2 * s].contiguous()
-                keep_rank = res[2 + 2 * s:2 + 2 * s + M].to(torch.int32)
-                tot = res[2 + 2 * s + M:].contiguous()
+                w_star = res[2 + M:2 + 2 * M].contiguous()
+                keep_rank = res[2 + 2 * M:2 + 3 * M].to(torch.int32)
+                tot = res[2 + 3 * M:].contiguous()
             else:
                 head = ops.to_host(torch.cat([info, kept]), "head")     # one D2H for status + survivor list
                 n_keep, status = int(head[0]), int(head[1])
                 kept_list = [int(v) for v in head[2:2 + n_keep]]
-            if status != 0:
+            if status != 0 and not sober:
                 raise RuntimeError("Caratheodory elimination: a null vector has no positive entry "
                                    "(the reference fails here too: argmin of an empty tensor, _rchq.py:152)")
             if trace is not None:

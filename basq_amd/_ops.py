@@ -139,9 +139,9 @@ class HipOps:
         self._chk(PhiT)
         self._chk(mu)
         keep_rank = self.empty(M, dtype=torch.int32)
-        ik = self.empty(2 + max(s, 1), dtype=torch.int32)      # [info(2) | kept(s)]: one D2H copy reads both
-        info, kept = ik[:2], ik[2:]
-        w_star = self.empty(max(s, 1))
+        ik = self.empty(2 + M, dtype=torch.int32)              # [info(2) | kept(<=M)]  (<= s unless the elimination
+        info, kept = ik[:2], ik[2:]                             #  stopped early, status 1)
+        w_star = self.empty(M)
         check(self.lib.basq_car_eliminate_f64(_ptr(PhiT), _ptr(mu), M, s, _ptr(keep_rank), _ptr(kept), _ptr(w_star),
                                               _ptr(info), self._stream()), "basq_car_eliminate_f64")
         return keep_rank, kept, w_star, info

@@ -203,3 +203,133 @@ def recombination_oracle(pts_rec, pts_nys, num_pts, kernel, trace: Trace | None 
             trace.U = U.clone()
     w, idx = divide_and_recombine(pts_rec, U, pts_nys, kernel, trace)  # :37-39
     return idx, w
+
+
+# ----------------------------------------------------------------------------------------------------
+# SOBER-flavoured variant (``SOBER/_rchq.py``) -- calc_obj=None path only.
+# Differences from ``BASQ/_rchq.py`` restated here, each with its line:
+#   * the Nystrom Gram goes through ``make_cov_psd`` (SOBER/_rchq.py:36, SOBER/_utils.py:128-154);
+#   * ``init_weights`` are honoured and zero-weight points dropped up front (:60-64);
+#   * block sums come from ONE batched kernel call summed over the block axis (:121-125);
+#   * the ragged remainder is counted TWICE: its kernel columns are added to sets 0..N_rest-1 (:127-135, no
+#     weight added there) and, as in BASQ, to the last set with its weight (:155-166);
+#   * the elimination stops early when a null vector has no positive entry (:236-242).
+# ----------------------------------------------------------------------------------------------------
+def _is_psd_sober(mat):
+    try:
+        torch.linalg.cholesky(mat)
+        return bool((mat == mat.T).all() and (torch.linalg.eig(mat)[0].real >= 0).all())
+    except Exception:
+        return False
+
+
+def make_cov_psd_sober(cov, max_iter=10):
+    """``SafeTensorOperator.make_cov_psd`` (SOBER/_utils.py:128-154)."""
+    if _is_psd_sober(cov):
+        return cov
+    cov = torch.nan_to_num(cov)
+    cov = torch.sqrt(cov * cov.T)
+    if not _is_psd_sober(cov):
+        n = cov.size(0)
+        jitter = torch.ones(n) * 1e-5
+        it = 0
+        while not _is_psd_sober(cov):
+            cov[range(n), range(n)] += jitter
+            jitter *= 2
+            it += 1
+            if it > max_iter:
+                cov = cov.diag().diag()
+                break
+    return cov
+
+
+def caratheodory_reduce_sober(X, mu):
+    """``Tchernychova_Lyons_CAR`` of SOBER (:222-270): as BASQ's, plus the early exit (:240-242)."""
+    X = torch.cat([torch.ones(X.size(0)).unsqueeze(0).T, X], dim=1)
+    M, s = X.shape
+    _, _, Vh = torch.linalg.svd(X.T)
+    Phi = Vh[-(M - s):, :].T
+    for _ in range(M - s):
+        col = Phi[:, 0]
+        pos = col > 0
+        if pos.sum() == 0:
+            break
+        alpha = torch.zeros(len(mu))
+        alpha[pos] = mu[pos] / col[pos]
+        j = torch.arange(len(mu))[pos][torch.argmin(alpha[pos])]
+        mu[:] = mu - alpha[j] * col
+        mu[j] = 0.0
+        Phi = Phi[:, 1:]
+        Phi = Phi - torch.matmul(Phi[j].unsqueeze(1), col.unsqueeze(1).T).T / col[j]
+        Phi[j, :] = 0.0
+    keep = mu > 0
+    return mu[keep], torch.arange(M)[keep]
+
+
+def divide_and_recombine_sober(samp, U, pt, kernel, mu=None, trace: Trace | None = None):
+    """``Mod_Tchernychova_Lyons`` of SOBER (:53-219) without an objective.  ``kernel`` must accept a batched
+    second argument ``[nb, S, d]`` (gpytorch semantics) -> ``[nb, m, S]``."""
+    N = len(samp)
+    q, m = U.shape
+    S = 2 * (q + 1)
+    if mu is None:
+        mu = torch.ones(N) / N
+    live = torch.arange(N)[mu != 0]
+    R = len(live)
+    while True:
+        if R <= q + 1:
+            sel = torch.arange(len(mu))[mu > 0]
+            return mu[sel], sel
+        if R <= S:
+            F = U @ kernel(pt, samp[live])
+            w, keep = caratheodory_reduce_sober(F.T, torch.clone(mu[live]))
+            live = live[keep]
+            mu[:] = 0.0
+            mu[live] = w
+            return mu[mu > 0], live
+        nb = int(R / S)
+        grid = live[: nb * S].reshape(nb, -1)
+        K = kernel(pt, samp[grid]) * mu[grid].unsqueeze(1)                     # :123-124  [nb, m, S]
+        acc = torch.zeros(m, S)
+        acc += K.sum(axis=0)
+        n_rest = len(live) - nb * S
+        if n_rest > 0:                                                          # :127-135 (first count)
+            rest = live[nb * S: nb * S + n_rest]
+            Kr = kernel(pt, samp[rest]) * mu[rest].unsqueeze(0)
+            acc += torch.cat((Kr, torch.zeros(m, S - n_rest)), dim=1)
+        feat = (U @ acc).T
+        tot = torch.sum(mu[grid], 0)
+        tail = live[nb * S:]
+        if len(tail):                                                           # :155-166 (second count)
+            Ft = U @ kernel(pt, samp[tail])
+            feat[-1] += torch.multiply(Ft.T, mu[tail].unsqueeze(1)).sum(axis=0)
+            tot[-1] += torch.sum(mu[tail], 0)
+        feat = torch.divide(feat, tot.unsqueeze(0).T)
+        w, keep = caratheodory_reduce_sober(feat, torch.clone(tot))
+        if trace is not None:
+            trace.rounds.append(RoundTrace(R, nb, len(tail), kept_sets=keep.clone(), kept_weights=w.clone()))
+        survivors = grid[:, keep].reshape(-1)
+        drop = torch.ones(grid.shape[1]).to(torch.bool)
+        drop[keep] = 0
+        mu[grid[:, drop].reshape(-1)] = 0.0
+        scaled = torch.divide(torch.multiply(mu[grid[:, keep]], w), tot[keep])
+        mu[survivors] = scaled.reshape(-1)
+        hit = torch.arange(len(keep))[(keep == S - 1) != 0]
+        if len(hit) > 0:
+            t_mu = torch.divide(torch.multiply(mu[tail], w[hit]), tot[keep[hit]])
+            mu[tail] = t_mu
+            survivors = torch.cat([survivors, tail])
+        else:
+            mu[tail] = 0.0
+        live = torch.clone(survivors)
+        R = len(live)
+
+
+def recombination_sober_oracle(pts_rec, pts_nys, num_pts, kernel, init_weights=None, trace: Trace | None = None):
+    """``SOBER/_rchq.py:recombination`` (:6-31) with ``calc_obj=None`` -> ``(idx, w)``."""
+    mat = make_cov_psd_sober(kernel(pts_nys, pts_nys))                          # :35-36
+    Uq, _, _ = torch.svd_lowrank(mat, q=num_pts - 1)                            # :37
+    U = -1 * Uq.T
+    mu = None if init_weights is None else init_weights.clone()
+    w, idx = divide_and_recombine_sober(pts_rec, U, pts_nys, kernel, mu, trace)
+    return idx, w

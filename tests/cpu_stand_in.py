@@ -149,9 +149,9 @@ class CpuStandInOps:
         n_keep = int(keep.sum())
         keep_rank = torch.full((M,), -1, dtype=torch.int32)
         keep_rank[keep] = torch.arange(n_keep, dtype=torch.int32)
-        kept = torch.zeros(max(s, 1), dtype=torch.int32)
+        kept = torch.zeros(M, dtype=torch.int32)
         kept[:n_keep] = torch.arange(M, dtype=torch.int32)[keep]
-        w_star = torch.zeros(max(s, 1), dtype=torch.float64)
+        w_star = torch.zeros(M, dtype=torch.float64)
         w_star[:n_keep] = mu[keep]
         info = torch.tensor([n_keep, status], dtype=torch.int32)
         return keep_rank, kept, w_star, info

@@ -20,6 +20,32 @@ def _free_port():
     return p
 
 
+def _sober_worker(rank, world, port, i, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from basq_amd._engine import RecombinationEngine, TorchDistComm
+        from basq_amd._partition import initial_shards
+        from basq_amd.kernels import StationaryKernel
+        from basq_amd.pools import gmm_pool
+        from oracle.make_golden_sober import CASES, case_weights
+        from tests.cpu_stand_in import CpuStandInOps
+
+        c = CASES[i]
+        pts = gmm_pool(c["N"], c["d"], c["pool_seed"])
+        w0 = case_weights(c)
+        off, n = initial_shards(c["N"], world)[rank]
+        torch.manual_seed(1)
+        idx, w = RecombinationEngine(CpuStandInOps(), TorchDistComm()).run(
+            pts[off:off + n].clone(), off, c["N"], pts[: c["m"]], c["n"], StationaryKernel(c["family"], c["lengthscale"], 1.0),
+            variant="sober", init_weights=None if w0 is None else w0[off:off + n].clone())
+        q.put((rank, idx.tolist(), w.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, name, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -63,3 +89,26 @@ def test_sharded_engine_matches_golden(name, world):
         assert kept == [r["kept"] for r in fx["rounds"]]
     # every rank returns the identical result
     assert all(r[1] == res[0][1] and r[2] == res[0][2] for r in res)
+
+
+@pytest.mark.parametrize("i,world", [(1, 2), (2, 3)])
+def test_sharded_sober_variant_matches_golden(i, world):
+    """SOBER flavour (importance weights with zeros, remainder double count) sharded over ranks."""
+    import json
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sober.json")) as f:
+        fx = json.load(f)[i]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sober_worker, args=(r, world, port, i, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    gw = torch.tensor(fx["w"], dtype=torch.float64)
+    for rank, idx, w in res:
+        assert idx == fx["idx"], f"rank {rank}"
+        assert ((torch.tensor(w, dtype=torch.float64) - gw).abs() / gw).max().item() <= 1e-6
