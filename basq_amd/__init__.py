@@ -15,8 +15,10 @@ absence is an error (there is no CPU fallback).
 from . import kernels, pools, sober                           # noqa: F401
 from ._basq import BASQ, KernelQuadrature                      # noqa: F401
 from ._engine import EngineTrace                               # noqa: F401
+from ._acquisition_function import SquareRootAcquisitionFunction   # noqa: F401
 from ._gaussian_calc import GaussianCalc                       # noqa: F401
+from ._sampler import PriorSampler                             # noqa: F401
 from ._rchq import recombination, recombination_sharded        # noqa: F401
 
-__all__ = ["recombination", "recombination_sharded", "BASQ", "KernelQuadrature", "GaussianCalc", "EngineTrace", "kernels",
+__all__ = ["recombination", "recombination_sharded", "BASQ", "KernelQuadrature", "GaussianCalc", "SquareRootAcquisitionFunction", "PriorSampler", "EngineTrace", "kernels",
            "pools", "sober"]
