@@ -140,6 +140,30 @@ def _host_qr_q(ops, X, trace=None):
         return ops.to_device(Qh)
 
 
+def _splits_for(K: int, want: int) -> int:
+    for c in range(min(want, K), 0, -1):
+        if K % c == 0:
+            return c
+    return 1
+
+
+def _mm_splitk(ops, A, B, want: int = 8):
+    """``A @ B`` for a long contraction with a skinny output, as ONE batched library GEMM over K slices.
+
+    rocBLAS tiles the output only (no split-K): ``[1e4,1e4] @ [1e4,99]`` is 79 work-groups on 256 CUs and
+    ``[99,1e4] @ [1e4,99]`` a single one.  Viewing the K dimension as (splits, K/splits) -- strided views, no
+    copies -- runs ``splits`` times more work-groups concurrently; the partial products are added in slice order.
+    """
+    M, K = A.shape
+    N = B.shape[1]
+    c = _splits_for(K, want)
+    if c == 1 or not hasattr(ops, "device") or getattr(ops, "name", "") != "hip":
+        return ops.matmul(A, B)
+    Ab = A.unflatten(1, (c, K // c)).permute(1, 0, 2)          # [c, M, K/c]  (view)
+    Bb = B.unflatten(0, (c, K // c))                            # [c, K/c, N]  (view)
+    return torch.bmm(Ab, Bb).sum(0)
+
+
 def _cholqr(ops, X, flags, passes=2):
     """Basis of range(X) ([m,k], k <= m) by CholeskyQR passes, entirely on the GPU.
 
@@ -149,7 +173,7 @@ def _cholqr(ops, X, flags, passes=2):
     only role is their range.  The pivot flags (device int32) are appended to ``flags`` and checked once, later.
     """
     for _ in range(passes):
-        G = ops.matmul(X.t(), X)
+        G = _mm_splitk(ops, X.t(), X, 32)
         W, info = ops.chol_inv(G)
         flags.append(info)
         X = ops.matmul(X, W)
@@ -182,17 +206,17 @@ def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None):
     if GPU_RANGE_FINDER and q_req <= m:
         with _Timer(ops, trace, "basis.gpu_range"):
             flags = []
-            Q = _cholqr(ops, ops.matmul(A, R), flags, passes=1)
-            Q = _cholqr(ops, ops.matmul(At, Q), flags, passes=1)
-            Q = _cholqr(ops, ops.matmul(A, Q), flags, passes=1)
-            Q = _cholqr(ops, ops.matmul(At, Q), flags, passes=1)
-            Q = _cholqr(ops, ops.matmul(A, Q), flags, passes=2)      # the basis that is actually used
-            B = ops.matmul(Q.t(), A)                           # [k, m]
+            Q = _cholqr(ops, _mm_splitk(ops, A, R), flags, passes=1)
+            Q = _cholqr(ops, _mm_splitk(ops, At, Q), flags, passes=1)
+            Q = _cholqr(ops, _mm_splitk(ops, A, Q), flags, passes=1)
+            Q = _cholqr(ops, _mm_splitk(ops, At, Q), flags, passes=1)
+            Q = _cholqr(ops, _mm_splitk(ops, A, Q), flags, passes=2)      # the basis that is actually used
+            B = _mm_splitk(ops, Q.t(), A)                      # [k, m]
             # LQ of B (CholeskyQR2 on its rows):  B = L1 L2 Qb^T  ->  left singular vectors of B = those of L
-            G1 = ops.matmul(B, B.t())
+            G1 = _mm_splitk(ops, B, B.t(), 32)
             W1, i1 = ops.chol_inv(G1)
             Bq = ops.matmul(W1.t(), B)
-            G2 = ops.matmul(Bq, Bq.t())
+            G2 = _mm_splitk(ops, Bq, Bq.t(), 32)
             _, i2 = ops.chol_inv(G2)
             L = ops.matmul(torch.tril(G1), torch.tril(G2))
             bad = torch.stack([f.reshape(()) for f in flags + [i1, i2]]).max()
