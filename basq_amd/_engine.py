@@ -180,6 +180,24 @@ def _cholqr(ops, X, flags, passes=2):
     return X
 
 
+def _gaussian_test_matrix(ops, m, q):
+    """``R = torch.randn(m, q)`` of ``torch._lowrank.get_approximate_basis`` with the reference's RNG consumption.
+
+    torch's CPU ``normal_`` first fills the tensor with mt19937 uniforms and then applies Box-Muller in blocks of
+    16 (scalar libm, ~12 ms for 1e4 x 99).  ``torch.rand`` makes exactly the same draws (the generator ends in
+    the same state: ``test_rand_consumes_like_randn``), so only the uniforms are produced on the host and the
+    transform runs on the GPU; values agree with ``torch.randn`` to 1 ulp (device vs host libm), far inside the
+    stability margin of the selection.
+    """
+    n = m * q
+    if n < 16:
+        return ops.to_device(torch.randn(m, q, dtype=torch.float64))
+    u = torch.rand(n, dtype=torch.float64)                       # CPU global generator
+    ut = torch.rand(16, dtype=torch.float64) if n % 16 else None
+    R = ops.box_muller(ops.from_host(u, "rand_u"), None if ut is None else ops.from_host(ut, "rand_ut"))
+    return R.view(m, q)
+
+
 # The GPU range finder may be switched off (tests compare both paths).
 GPU_RANGE_FINDER = True
 
@@ -201,7 +219,7 @@ def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None):
     """
     m = A.shape[0]
     with _Timer(ops, trace, "basis.randn"):
-        R = ops.to_device(torch.randn(m, q_req, dtype=torch.float64))   # CPU generator (reference: CPU tensor A)
+        R = _gaussian_test_matrix(ops, m, q_req)
     At = A.t()
     if GPU_RANGE_FINDER and q_req <= m:
         with _Timer(ops, trace, "basis.gpu_range"):

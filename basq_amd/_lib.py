@@ -47,6 +47,7 @@ SIGNATURES = {
                                             _i64, _vp, _vp, _vp, _vp, _vp]),
     "basq_init_state_f64": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
     "basq_dense_sq_blocksum_f64": (C.c_int, [_vp, _i32, _i64, _i64, _vp, _i64, _i64, _i32, _f64, _vp, _vp]),
+    "basq_box_muller_f64": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "basq_chol_inv_f64": (C.c_int, [_vp, _i32, _vp, _vp, _f64, _vp]),
     "basq_gemm_f64": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _f64, _vp]),
 }

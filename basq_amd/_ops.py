@@ -173,6 +173,14 @@ class HipOps:
         check(self.lib.basq_dense_sq_blocksum_f64(_ptr(Cmat), m, nc, nc, _ptr(mu_chunk), pg0, n_full, S, float(scale),
                                                   _ptr(E), self._stream()), "basq_dense_sq_blocksum_f64")
 
+    def box_muller(self, u, u_tail=None):
+        """Normals from torch's uniforms (see basq_box_muller_f64); u on the device, n >= 16."""
+        self._chk(u)
+        out = self.empty(u.shape[0])
+        check(self.lib.basq_box_muller_f64(_ptr(u), u.shape[0], _ptr(u_tail), _ptr(out), self._stream()),
+              "basq_box_muller_f64")
+        return out
+
     def chol_inv(self, G, rel_tol=1e-12):
         """In place: G -> L (lower).  Returns (W = L^{-T}, info[1] int32 on device)."""
         self._chk(G)

@@ -1378,6 +1378,29 @@ __global__ void dense_sq_blocksum_kernel(const double* __restrict__ C, int m, lo
     E[(long long)j * S + s] += scale * acc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Box-Muller transform of torch's CPU ``normal_fill`` (aten/native/cpu/DistributionTemplates.h): blocks of 16
+// uniforms -> 16 normals (u1 = 1 - u[j], u2 = u[j+8]; r = sqrt(-2 log u1), t = 2 pi u2; out[j] = r cos t,
+// out[j+8] = r sin t).  The Gaussian test matrix of torch.svd_lowrank is one ``torch.randn`` from the CPU
+// generator; drawing the SAME uniforms with ``torch.rand`` (identical generator consumption, verified by
+// tests/test_host_logic.py) and transforming them here takes the ~12 ms of scalar libm calls off the host.
+// When n % 16 != 0 torch recomputes the last 16 values from 16 fresh uniforms (u_tail).
+// ------------------------------------------------------------------------------------------------
+__global__ void box_muller_kernel(const double* __restrict__ u, long long nblk, double* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // one (block of 16, j < 8) pair per thread
+    if (t >= nblk * 8) return;
+    const long long blk = t >> 3;
+    const int j = (int)(t & 7);
+    const double* src = u + blk * 16;
+    double* dst = out + blk * 16;
+    const double u1 = 1.0 - src[j];
+    const double u2 = src[j + 8];
+    const double radius = sqrt(-2.0 * log(u1));
+    const double theta = 2.0 * 3.14159265358979323846 * u2;
+    dst[j] = radius * cos(theta);
+    dst[j + 8] = radius * sin(theta);
+}
+
 __global__ void axpb_strided_kernel(const double* __restrict__ x, long long n, long long stride, double a, double b,
                                     double* __restrict__ out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1600,6 +1623,19 @@ int basq_init_state_f64(double* mu, int64_t* gid, int64_t Rl, int64_t gid0, int6
     hipLaunchKernelGGL(init_state_kernel, dim3((unsigned)((Rl + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mu,
                        (long long*)gid, (long long)Rl, (long long)gid0, 1.0 / (double)n_total);
     BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_box_muller_f64(const double* u, int64_t n, const double* u_tail, double* out, void* stream) {
+    if (!u || !out || n < 16 || ((n % 16 != 0) != (u_tail != nullptr))) return BASQ_EINVAL;
+    const long long nblk = n / 16;
+    hipLaunchKernelGGL(box_muller_kernel, dim3((unsigned)((nblk * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u,
+                       nblk, out);
+    BASQ_CHECK_LAUNCH();
+    if (u_tail) {   // torch recomputes the LAST 16 values from fresh uniforms; launched second: it overwrites
+        hipLaunchKernelGGL(box_muller_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, u_tail, 1LL, out + (n - 16));
+        BASQ_CHECK_LAUNCH();
+    }
     return BASQ_OK;
 }
 

@@ -182,6 +182,15 @@ int basq_dense_sq_blocksum_f64(const double* C, int32_t m, int64_t nc, int64_t l
                                int64_t n_full, int32_t S, double scale, double* E, void* stream);
 
 /*
+ * Gaussian test matrix of torch.svd_lowrank (BASQ/_rchq.py:29 -> torch._lowrank: R = torch.randn(m, q)): the
+ * Box-Muller half of torch's CPU normal_fill.  u [n] are the uniforms torch.rand(n, float64) draws from the CPU
+ * generator (the same mt19937 consumption as torch.randn(n)); out[16b + j] = sqrt(-2 log(1 - u[16b+j])) *
+ * cos(2 pi u[16b+j+8]), out[16b+j+8] = ... sin(...), j < 8.  If n % 16 != 0, u_tail [16] (16 further draws)
+ * regenerates the last 16 outputs, as torch does; otherwise u_tail must be NULL.  n >= 16.
+ */
+int basq_box_muller_f64(const double* u, int64_t n, const double* u_tail, double* out, void* stream);
+
+/*
  * CholeskyQR building block of the randomised range finder behind torch.svd_lowrank (BASQ/_rchq.py:29):
  * G [q,q] (symmetric positive definite, = X^T X) is overwritten by its Cholesky factor L (lower triangle;
  * the strict upper triangle is left as it was) and W [q,q] receives L^{-T} (upper triangular), so that

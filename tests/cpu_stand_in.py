@@ -192,6 +192,20 @@ class CpuStandInOps:
         sets = torch.where(pg < n_full, pg % S, torch.full_like(pg, S - 1))
         E.index_add_(1, sets, scale * (Cmat * Cmat) * mu_chunk[:nc].unsqueeze(0))
 
+    def box_muller(self, u, u_tail=None):
+        def bm(v):
+            blk = v.view(-1, 16)
+            r = torch.sqrt(-2 * torch.log(1 - blk[:, :8]))
+            th = 2.0 * math.pi * blk[:, 8:]
+            return torch.cat([r * torch.cos(th), r * torch.sin(th)], 1).reshape(-1)
+
+        n = u.shape[0]
+        out = torch.empty(n, dtype=torch.float64)
+        out[: n // 16 * 16] = bm(u[: n // 16 * 16])
+        if u_tail is not None:
+            out[n - 16:] = bm(u_tail)
+        return out
+
     def chol_inv(self, G, rel_tol=1e-12):
         self._count("chol_inv")
         q = G.shape[0]

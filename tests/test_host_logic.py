@@ -105,3 +105,19 @@ def test_pool_generator_is_stable():
     a, b = gmm_pool(70_000, 3, 5), gmm_pool(70_000, 3, 5)
     assert torch.equal(a, b) and a.dtype == torch.float64
     assert abs(a.mean().item()) < 3.0 and 0.5 < a.std().item() < 4.0
+
+
+@pytest.mark.parametrize("n", [990_000, 99_000, 4_428, 450, 16, 31])
+def test_rand_consumes_like_randn(n):
+    """torch.rand (+16 tail draws if n % 16) leaves the CPU generator exactly where torch.randn(n) leaves it, and
+    Box-Muller of those uniforms reproduces torch.randn to round-off -- what _gaussian_test_matrix relies on."""
+    torch.manual_seed(123)
+    a = torch.randn(n, dtype=torch.float64)
+    s1 = torch.get_rng_state()
+    torch.manual_seed(123)
+    u = torch.rand(n, dtype=torch.float64)
+    ut = torch.rand(16, dtype=torch.float64) if n % 16 else None
+    s2 = torch.get_rng_state()
+    assert torch.equal(s1, s2)
+    b = CpuStandInOps().box_muller(u, ut)
+    assert (a - b).abs().max().item() <= 4e-15

@@ -280,3 +280,15 @@ def test_quadrature_step_vs_oracle(hip_ops):
             mean = alpha + 0.5 * (mu_w ** 2 + var)
         assert EZy == pytest.approx(float(w @ mean), rel=1e-8)
         assert VarZy == pytest.approx(float(w @ kern_o(X, X) @ w), rel=1e-6, abs=1e-14)
+
+
+@pytest.mark.parametrize("n", [990_000, 4_428, 16, 31])
+def test_box_muller_vs_torch_randn(hip_ops, n):
+    """Device Box-Muller of torch.rand's uniforms == torch.randn from the same generator state, to round-off."""
+    torch.manual_seed(77)
+    ref = torch.randn(n, dtype=torch.float64)
+    torch.manual_seed(77)
+    u = torch.rand(n, dtype=torch.float64)
+    ut = torch.rand(16, dtype=torch.float64) if n % 16 else None
+    out = hip_ops.box_muller(hip_ops.to_device(u), None if ut is None else hip_ops.to_device(ut)).cpu()
+    assert (out - ref).abs().max().item() <= 1e-14
