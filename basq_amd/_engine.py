@@ -13,9 +13,11 @@ Gram ``kernel(pt, pt)`` (:29)            ``basq_gram_f64`` (+ small rocBLAS GEMM
 hot loop + tail + tot (:79-99)           ``basq_blocksum_f64`` (fused, nothing materialised)
 ``U_svd @ X_for_nys`` (:88)              ``basq_project_f64`` (f64 MFMA)
 divide, ones column (:101, :138)         ``basq_finalize_f64``
-full SVD -> null space (:140-143)        host LAPACK ``torch.linalg.svd`` (gesdd): the null-space basis
-                                         is algorithm-specific, any other SVD changes the selection
-                                         (SURVEY finding 3) -- 160 KB D2H + 160 KB H2D per round
+full SVD -> null space (:140-143)        ``basq_nullspace_f64``: the right Householder reflectors of gesdd's
+                                         bidiagonal reduction, i.e. LAPACK's own null-space rows (host
+                                         ``torch.linalg.svd`` kept behind ``GPU_NULLSPACE = False``): the basis
+                                         is algorithm-specific, any other orthonormal null-space basis
+                                         changes the selection (SURVEY finding 3)
 elimination loop (:146-175)              ``basq_car_eliminate_f64``
 re-weight + compaction (:107-130)        ``basq_reweight_compact_f64`` (closed-form destinations)
 =======================================  ==========================================================
@@ -200,6 +202,9 @@ def _gaussian_test_matrix(ops, m, q):
 
 # The GPU range finder may be switched off (tests compare both paths).
 GPU_RANGE_FINDER = True
+# Per-round null space (:140-143) from the bidiagonalisation's right reflectors on the GPU (basq_nullspace_f64)
+# instead of a host LAPACK SVD; False restores the host path (same rows to ~1e-13, see tests).
+GPU_NULLSPACE = True
 
 
 def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None):
@@ -494,13 +499,17 @@ class RecombinationEngine:
             M = S_r
             if comm.rank == 0:
                 XcarT, tot = ops.finalize(parts, comm.world, q_ext + 1, q, S_r, diagU, m, min(m, S_r), diag_noise, wrow)
-                t1 = time.perf_counter()
-                Xh = ops.to_host(XcarT, "xcar")
-                with _lapack_threads(HOST_SVD_THREADS):
-                    Vh = torch.linalg.svd(Xh)[2]                 # :140 full SVD of [s, M] on host LAPACK
-                PhiT = ops.from_host(Vh[-(M - s):, :], "phit")   # :143 (rows = null-space vectors)
-                if trace is not None:
-                    trace.add_time("host_svd", time.perf_counter() - t1)
+                if GPU_NULLSPACE:
+                    with _Timer(ops, trace, "nullspace"):
+                        PhiT = ops.nullspace(XcarT, s, M)        # :140-143 (rows = null-space vectors)
+                else:
+                    t1 = time.perf_counter()
+                    Xh = ops.to_host(XcarT, "xcar")
+                    with _lapack_threads(HOST_SVD_THREADS):
+                        Vh = torch.linalg.svd(Xh)[2]             # :140 full SVD of [s, M] on host LAPACK
+                    PhiT = ops.from_host(Vh[-(M - s):, :], "phit")
+                    if trace is not None:
+                        trace.add_time("host_svd", time.perf_counter() - t1)
                 mu_car = tot.clone()
                 with _Timer(ops, trace, "eliminate"):
                     keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, mu_car, M, s)

@@ -134,6 +134,16 @@ class HipOps:
               "basq_finalize_f64")
         return XcarT, tot
 
+    def nullspace(self, XcarT, s, M):
+        """Rows s..M-1 of the full ``Vh`` of ``svd(XcarT [s, M])`` (``_rchq.py:140-143``) -> PhiT [M-s, M]."""
+        self._chk(XcarT)
+        V = self.empty(s, M)
+        tau = self.empty(s)
+        PhiT = self.empty(M - s, M)
+        check(self.lib.basq_nullspace_f64(_ptr(XcarT), s, M, _ptr(V), _ptr(tau), _ptr(PhiT), self._stream()),
+              "basq_nullspace_f64")
+        return PhiT
+
     def car_eliminate(self, PhiT, mu, M, s):
         """In place on PhiT/mu.  -> (keep_rank[M] i32, kept[s] i32, w_star[s] f64, info[2] i32)."""
         self._chk(PhiT)

@@ -1169,6 +1169,264 @@ __global__ void __launch_bounds__(1024) car_eliminate_lds_kernel(const double* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// Null space of the wide [m, n] Caratheodory matrix (BASQ/_rchq.py:140-143) without an SVD iteration.
+//
+// The reference takes Phi = Vh[-(n-m):].T from torch.linalg.svd(X) (LAPACK gesdd).  gesdd first reduces X to
+// lower-bidiagonal form B = Q^T X P with Householder reflectors (dgebrd, m < n), then diagonalises B by rotations
+// that only mix the FIRST m rows of P^T; rows m..n-1 of Vh are therefore rows m..n-1 of
+//     P^T = (G_0 G_1 ... G_{m-1})^T,   G_i = I - tau_i v_i v_i^T   (dlarfg convention, v_i = [0.., 1, x/(alpha-beta)])
+// -- signs included.  The elimination's pivots depend on this very basis (not just on the null space), so the
+// same reflectors are generated here, in LAPACK's order (dgebd2: right reflector from row i, apply to the rows
+// below; left reflector from column i, apply to the trailing block), and tests pin the result to the host SVD.
+//
+// bidiag_reflectors_kernel: one work-group.  Rows have FIXED owners (row r -> wave r % NW), lanes own the columns
+// c = lane + 64k, so a row never leaves its wave: the right reflector's A v and rank-1 update are wave-local
+// (registers + shuffles), only the left reflector's u^T A needs a cross-wave sum (NW partial rows in LDS, summed
+// in wave order).  The first NREG*NW rows live in registers, the rest in LDS (or in the V buffer in global memory
+// when they do not fit); 4 barriers per step.  Outputs V[i, :] = v_i and tau[i].
+// nullspace_apply_kernel: one wave per null vector c: y = e_{m+c}; for i = m-1..0: y -= tau_i (v_i . y) v_i.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// dlarfg: reflector for (alpha, x) from alpha and |x|^2; returns tau, scale = 1/(alpha - beta) (0, 0 if x == 0)
+__device__ __forceinline__ void householder_params(double alpha, double ss, double& tau, double& scale) {
+    if (ss == 0.0) { tau = 0.0; scale = 0.0; return; }
+    const double nrm = __builtin_sqrt(alpha * alpha + ss);
+    const double beta = (alpha >= 0.0) ? -nrm : nrm;
+    tau = (beta - alpha) / beta;
+    scale = 1.0 / (alpha - beta);
+}
+
+template <int NV, int NREG, int NW, bool ROWS_IN_LDS>
+__global__ void __launch_bounds__(NW * 64) bidiag_reflectors_kernel(const double* __restrict__ X, int m, int n,
+                                                                    double* __restrict__ V, double* __restrict__ tau_g) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ double tau_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double* vsh = sm;                          // [n]  current right reflector
+    double* wsh = vsh + n;                     // [n]  u^T A
+    double* ush = wsh + n;                     // [m]  column i below the diagonal
+    double* wpart = ush + m;                   // [NW][n] per-wave partials of u^T A
+    double* lrows = wpart + (size_t)NW * n;    // rows r >= NREG*NW (ROWS_IN_LDS) at (r - NREG*NW) * n
+    constexpr int RBASE = NREG * NW;
+    double reg[NREG > 0 ? NREG : 1][NV];
+
+#define BASQ_ROW_LD(r, c) (ROWS_IN_LDS ? lrows[(size_t)((r) - RBASE) * n + (c)] : V[(size_t)(r) * n + (c)])
+#define BASQ_ROW_ST(r, c, val)                                                     \
+    do {                                                                           \
+        if (ROWS_IN_LDS) lrows[(size_t)((r) - RBASE) * n + (c)] = (val);           \
+        else V[(size_t)(r) * n + (c)] = (val);                                     \
+    } while (0)
+// BODY sees (int r, double a[NV]); rows r >= r0 owned by this wave; memory rows are written back when WRITE
+#define BASQ_OWN_ROWS(r0, WRITE, BODY)                                             \
+    do {                                                                           \
+        _Pragma("unroll") for (int jr = 0; jr < NREG; ++jr) {                      \
+            const int r = wv + jr * NW;                                            \
+            if (r >= (r0) && r < m) {                                              \
+                double(&a)[NV] = reg[jr];                                          \
+                BODY                                                               \
+            }                                                                      \
+        }                                                                          \
+        for (int r = wv + RBASE; r < m; r += NW) {                                 \
+            if (r < (r0)) continue;                                                \
+            double a[NV];                                                          \
+            _Pragma("unroll") for (int k = 0; k < NV; ++k) {                       \
+                const int c = lane + 64 * k;                                       \
+                a[k] = (c < n) ? BASQ_ROW_LD(r, c) : 0.0;                          \
+            }                                                                      \
+            BODY                                                                   \
+            if (WRITE) {                                                           \
+                _Pragma("unroll") for (int k = 0; k < NV; ++k) {                   \
+                    const int c = lane + 64 * k;                                   \
+                    if (c < n) BASQ_ROW_ST(r, c, a[k]);                            \
+                }                                                                  \
+            }                                                                      \
+        }                                                                          \
+    } while (0)
+
+    // load: every wave fetches its own rows (no other wave ever touches them)
+#pragma unroll
+    for (int jr = 0; jr < NREG; ++jr) {
+        const int r = wv + jr * NW;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = lane + 64 * k;
+            reg[jr][k] = (r < m && c < n) ? X[(size_t)r * n + c] : 0.0;
+        }
+    }
+    for (int r = wv + RBASE; r < m; r += NW)
+        for (int c = lane; c < n; c += 64) BASQ_ROW_ST(r, c, X[(size_t)r * n + c]);
+
+    for (int i = 0; i < m; ++i) {
+        const int ik = i >> 6, il = i & 63;
+        // ---- S1: right reflector G_i from row i (owner wave only) ----
+        if (wv == i % NW) {
+            double a[NV];
+            if (i < RBASE) {
+#pragma unroll
+                for (int jr = 0; jr < NREG; ++jr)
+                    if (i == wv + jr * NW) {
+#pragma unroll
+                        for (int k = 0; k < NV; ++k) a[k] = reg[jr][k];
+                    }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const int c = lane + 64 * k;
+                    a[k] = (c < n) ? BASQ_ROW_LD(i, c) : 0.0;
+                }
+            }
+            double ss = 0.0, al = 0.0;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int c = lane + 64 * k;
+                if (c > i && c < n) ss += a[k] * a[k];
+                if (k == ik) al = a[k];
+            }
+            ss = wave_sum(ss);
+            const double alpha = __shfl(al, il, 64);
+            double tau, scale;
+            householder_params(alpha, ss, tau, scale);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int c = lane + 64 * k;
+                if (c < n) {
+                    const double v = (c < i) ? 0.0 : ((c == i) ? 1.0 : a[k] * scale);
+                    vsh[c] = v;
+                    V[(size_t)i * n + c] = v;
+                }
+            }
+            if (lane == 0) { tau_sh = tau; tau_g[i] = tau; }
+        }
+        if (i == m - 1) break;
+        __syncthreads();
+        // ---- S2: A[i+1:, i:] -= tau (A v) v^T, wave-local per row; publish column i ----
+        {
+            const double tau = tau_sh;
+            double vr[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int c = lane + 64 * k;
+                vr[k] = (c < n) ? vsh[c] : 0.0;
+            }
+            BASQ_OWN_ROWS(i + 1, true, {
+                double dot = 0.0;
+                _Pragma("unroll") for (int k = 0; k < NV; ++k) dot += a[k] * vr[k];
+                dot = wave_sum(dot);
+                const double t = tau * dot;
+                double ci = 0.0;
+                _Pragma("unroll") for (int k = 0; k < NV; ++k) {
+                    a[k] -= t * vr[k];
+                    if (k == ik) ci = a[k];
+                }
+                if (lane == il) ush[r] = ci;
+            });
+        }
+        __syncthreads();
+        // ---- S3: left reflector H_i from column i (rows i+1..), partial u^T A per wave ----
+        double tauq, scale2;
+        {
+            double ss = 0.0;
+            for (int r = i + 2 + lane; r < m; r += 64) ss += ush[r] * ush[r];
+            ss = wave_sum(ss);
+            householder_params(ush[i + 1], ss, tauq, scale2);
+            double pw[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) pw[k] = 0.0;
+            BASQ_OWN_ROWS(i + 1, false, {
+                const double ur = (r == i + 1) ? 1.0 : ush[r] * scale2;
+                _Pragma("unroll") for (int k = 0; k < NV; ++k) pw[k] += ur * a[k];
+            });
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int c = lane + 64 * k;
+                if (c < n) wpart[(size_t)wv * n + c] = pw[k];
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < n; c += NW * 64) {
+            double acc = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) acc += wpart[(size_t)w * n + c];
+            wsh[c] = acc;
+        }
+        __syncthreads();
+        // ---- S5: A[i+1:, i+1:] -= tauq u (u^T A) ----
+        {
+            double wc[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int c = lane + 64 * k;
+                wc[k] = (c > i && c < n) ? wsh[c] : 0.0;
+            }
+            BASQ_OWN_ROWS(i + 1, true, {
+                const double ur = (r == i + 1) ? 1.0 : ush[r] * scale2;
+                const double t = tauq * ur;
+                _Pragma("unroll") for (int k = 0; k < NV; ++k) a[k] -= t * wc[k];
+            });
+        }
+        // no barrier: the next step's S1 touches only vsh / tau_sh / its own row; ush, wpart and wsh are rewritten
+        // after the next barriers, when every wave has left S5.
+    }
+#undef BASQ_OWN_ROWS
+#undef BASQ_ROW_ST
+#undef BASQ_ROW_LD
+}
+
+template <int NV>
+__global__ void __launch_bounds__(256) nullspace_apply_kernel(const double* __restrict__ V,
+                                                              const double* __restrict__ tau, int m, int n,
+                                                              double* __restrict__ PhiT) {
+    const int lane = threadIdx.x & 63;
+    const int c0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c0 >= n - m) return;                              // wave-uniform
+    double y[NV], v[NV], vn[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = lane + 64 * k;
+        y[k] = (c == m + c0) ? 1.0 : 0.0;
+        v[k] = (c < n) ? V[(size_t)(m - 1) * n + c] : 0.0;
+    }
+    for (int i = m - 1; i >= 0; --i) {
+        const int inext = (i > 0) ? i - 1 : 0;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {                    // prefetch the next reflector behind the reduction
+            const int c = lane + 64 * k;
+            vn[k] = (c < n) ? V[(size_t)inext * n + c] : 0.0;
+        }
+        double dot = 0.0;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) dot += v[k] * y[k];
+        dot = wave_sum(dot);
+        const double t = tau[i] * dot;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            y[k] -= t * v[k];
+            v[k] = vn[k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int c = lane + 64 * k;
+        if (c < n) PhiT[(size_t)c0 * n + c] = y[k];
+    }
+}
+
+template <int NV, int NREG, int NW, bool ROWS_IN_LDS>
+static int launch_bidiag(const double* X, int m, int n, double* V, double* tau, size_t lds, hipStream_t st) {
+    auto kern = bidiag_reflectors_kernel<NV, NREG, NW, ROWS_IN_LDS>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return BASQ_ELAUNCH;
+    hipLaunchKernelGGL(kern, dim3(1), dim3(NW * 64), lds, st, X, m, n, V, tau);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Survivor re-weighting + order-preserving compaction (BASQ/_rchq.py:107-130).
 // ------------------------------------------------------------------------------------------------
 __global__ void reweight_compact_kernel(const double* __restrict__ cand, const double* __restrict__ mu,
@@ -1595,6 +1853,31 @@ int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32
     }
     hipLaunchKernelGGL(car_eliminate_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, PhiT, mu, M, s, keep_rank,
                        kept, w_star, info);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_nullspace_f64(const double* X, int32_t s, int32_t M, double* V, double* tau, double* PhiT, void* stream) {
+    if (!X || !V || !tau || !PhiT || s < 1 || M <= s || M > 1024) return BASQ_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t LDS_MAX = 163840 - 64;                         // per-CU LDS minus the kernel's static scalar
+    int rc;
+    if (M <= 256) {
+        const size_t fixed = (size_t)(2 * M + s + 16 * M) * sizeof(double);
+        const size_t rows = (size_t)(s > 32 ? s - 32 : 0) * M * sizeof(double);
+        if (fixed + rows <= LDS_MAX) rc = launch_bidiag<4, 2, 16, true>(X, s, M, V, tau, fixed + rows, st);
+        else rc = launch_bidiag<4, 2, 16, false>(X, s, M, V, tau, fixed, st);
+    } else if (M <= 512) {
+        rc = launch_bidiag<8, 0, 16, false>(X, s, M, V, tau, (size_t)(2 * M + s + 16 * M) * sizeof(double), st);
+    } else {
+        rc = launch_bidiag<16, 0, 8, false>(X, s, M, V, tau, (size_t)(2 * M + s + 8 * M) * sizeof(double), st);
+    }
+    if (rc != BASQ_OK) return rc;
+    const int nvec = M - s;
+    const dim3 grid((nvec + 3) / 4), block(256);
+    if (M <= 256) hipLaunchKernelGGL(nullspace_apply_kernel<4>, grid, block, 0, st, V, tau, s, M, PhiT);
+    else if (M <= 512) hipLaunchKernelGGL(nullspace_apply_kernel<8>, grid, block, 0, st, V, tau, s, M, PhiT);
+    else hipLaunchKernelGGL(nullspace_apply_kernel<16>, grid, block, 0, st, V, tau, s, M, PhiT);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }

@@ -139,6 +139,20 @@ int basq_finalize_f64(const double* parts, int32_t n_parts, int32_t msg_rows, in
                       double* XcarT, double* tot_out, void* stream);
 
 /*
+ * Null-space basis of the wide [s, M] matrix XcarT, replacing the full SVD of BASQ/_rchq.py:140-143
+ * (`u, _, _ = torch.linalg.svd(X.T)`, `Phi = u[:, -(M-s):]`).  The elimination's pivots depend on the basis
+ * LAPACK returns, not only on the null space; that basis is rows s..M-1 of P^T, P = G_0 ... G_{s-1} the product
+ * of the right Householder reflectors of gesdd's bidiagonal reduction (dgebrd, m < n, dlarfg sign convention) --
+ * the rotations that follow never touch those rows.  This entry generates the same reflectors on the GPU
+ * (one work-group, rows resident in registers/LDS) and applies them to the unit vectors e_s..e_{M-1}:
+ *     PhiT [M-s, M]  (rows = null vectors, what basq_car_eliminate_f64 consumes).
+ * Scratch: V [s, M] (reflector vectors; also row storage when s*M exceeds the LDS), tau [s].
+ * Agreement with the host LAPACK rows is at rounding level (~1e-13); 1 <= s < M <= 1024.
+ */
+int basq_nullspace_f64(const double* XcarT, int32_t s, int32_t M, double* V, double* tau, double* PhiT,
+                       void* stream);
+
+/*
  * Caratheodory elimination -- the loop of Tchernychova_Lyons_CAR, BASQ/_rchq.py:146-175, in the
  * reference's floating-point op order (separate multiply / subtract, outer product then divide).
  * PhiT is the null-space basis as ROWS: PhiT[k][i] = Phi[i][k], [M-s, M] (the last M-s rows of the

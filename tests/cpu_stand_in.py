@@ -13,9 +13,51 @@ from __future__ import annotations
 
 import math
 
+import numpy as np
 import torch
 
 ROLE_A, ROLE_B = 0, 1
+
+
+def _dlarfg(alpha, x):
+    """LAPACK dlarfg: H = I - tau [1; v][1; v]^T maps (alpha, x) to (beta, 0).  -> (tau, v)."""
+    ss = float(np.dot(x, x))
+    if ss == 0.0:
+        return 0.0, np.zeros_like(x)
+    beta = -math.copysign(math.sqrt(alpha * alpha + ss), alpha)
+    return (beta - alpha) / beta, x / (alpha - beta)
+
+
+def householder_nullspace(X):
+    """Rows m..n-1 of the full ``Vh`` of ``torch.linalg.svd(X)`` for wide X [m, n], with no SVD iteration.
+
+    gesdd reduces X to lower-bidiagonal form with Householder reflectors (dgebd2 order: right reflector from
+    row i, applied to the rows below; left reflector from column i, applied to the trailing block); the
+    rotations that follow only mix the first m rows of P^T, so the null-space rows are rows m.. of
+    (G_0 ... G_{m-1})^T -- signs included.  Same algorithm as ``basq_nullspace_f64`` (host restatement, tests only).
+    """
+    A = X.detach().cpu().to(torch.float64).numpy().copy() if torch.is_tensor(X) else np.array(X, dtype=np.float64)
+    m, n = A.shape
+    taus = np.zeros(m)
+    for i in range(m):
+        taus[i], v = _dlarfg(A[i, i], A[i, i + 1:])
+        A[i, i + 1:] = v
+        if i < m - 1:
+            vf = np.concatenate([[1.0], v])
+            sub = A[i + 1:, i:]
+            sub -= taus[i] * np.outer(sub @ vf, vf)
+            tq, u = _dlarfg(A[i + 1, i], A[i + 2:, i])
+            uf = np.concatenate([[1.0], u])
+            sub = A[i + 1:, i + 1:]
+            sub -= tq * np.outer(uf, uf @ sub)
+    N = np.zeros((n, n - m))
+    N[m:, :] = np.eye(n - m)
+    for i in range(m - 1, -1, -1):
+        v = np.zeros(n)
+        v[i] = 1.0
+        v[i + 1:] = A[i, i + 1:]
+        N -= taus[i] * np.outer(v, v @ N)
+    return torch.from_numpy(np.ascontiguousarray(N.T))
 
 
 class CpuStandInOps:
@@ -126,6 +168,10 @@ class CpuStandInOps:
             feat[:, :n_diag] += diag_noise * wgt[:n_diag].unsqueeze(0) * diagU[:, :n_diag]
         XcarT = torch.cat([torch.ones(1, S, dtype=torch.float64), feat / tot.unsqueeze(0)], 0)
         return XcarT, tot
+
+    def nullspace(self, XcarT, s, M):
+        self._count("nullspace")
+        return householder_nullspace(XcarT)
 
     def car_eliminate(self, PhiT, mu, M, s):
         self._count("car")

@@ -69,6 +69,41 @@ def test_engine_host_logic_reproduces_golden(name):
     assert [r["kept"] for r in tr.rounds] == [r["kept"] for r in fx["rounds"]]
 
 
+@pytest.mark.parametrize("m,n", [(100, 200), (100, 150), (100, 101), (37, 74), (31, 57), (10, 20), (1, 2), (2, 5),
+                                 (200, 400), (64, 128)])
+def test_reflector_nullspace_equals_lapack_svd_rows(m, n):
+    """The rows gesdd returns for the null space (``Vh[m:]`` of the full SVD, ``_rchq.py:140-143``) ARE rows m.. of
+    (G_0...G_{m-1})^T, the right Householder reflectors of its bidiagonal reduction -- signs included.  This is
+    what lets ``basq_nullspace_f64`` drop the SVD iteration; pinned here against LAPACK itself."""
+    from tests.cpu_stand_in import householder_nullspace
+
+    g = torch.Generator().manual_seed(m * 1000 + n)
+    X = torch.randn(m, n, generator=g, dtype=torch.float64)
+    X[0] = 1.0                                                  # the Caratheodory matrix has a ones row
+    ref = torch.linalg.svd(X)[2][m:]
+    got = householder_nullspace(X)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 1e-11            # no sign freedom, no rotation within the null space
+    assert (X @ got.T).abs().max().item() <= 1e-12 * n
+    assert (got @ got.T - torch.eye(n - m, dtype=torch.float64)).abs().max().item() <= 1e-13 * n
+
+
+def test_reflector_nullspace_on_real_round_matrices():
+    """Same identity on the matrices an actual run decomposes (barycentres of kernel features, ill-conditioned)."""
+    from tests.cpu_stand_in import householder_nullspace
+
+    c = BY_NAME["rbf_ragged"]
+    pts, nys = build_pool(c)
+    tr = EngineTrace(keep_tensors=True)
+    torch.manual_seed(c["torch_seed"])
+    RecombinationEngine(CpuStandInOps()).run(pts, 0, c["N"], nys, c["n"], build_product_kernel(c), tr)
+    assert tr.rounds
+    for r in tr.rounds:
+        X = r["XcarT"]
+        s = X.shape[0]
+        assert (householder_nullspace(X) - torch.linalg.svd(X)[2][s:]).abs().max().item() <= 1e-10
+
+
 def test_gpu_range_finder_equals_host_householder():
     """CholeskyQR2 range finder vs the reference-style host Householder path: same selection."""
     import basq_amd._engine as E

@@ -141,6 +141,61 @@ def test_car_eliminate_bit_exact(hip_ops, M, s, seed):
     assert n <= s
 
 
+# dispatch paths of basq_nullspace_f64: rows in registers+LDS (100x200 ...), rows in global memory with register
+# rows (128x256), 8 columns per lane (200x400), 16 columns per lane / 8 waves (300x600), degenerate sizes.
+NULLSPACE_SHAPES = [(100, 200), (100, 150), (100, 101), (37, 74), (31, 57), (10, 20), (1, 2), (2, 5), (33, 66),
+                    (128, 256), (200, 400), (150, 500), (300, 600), (100, 1024)]
+
+
+@pytest.mark.parametrize("s,M", NULLSPACE_SHAPES)
+def test_nullspace_equals_lapack_svd_rows(hip_ops, s, M):
+    """``basq_nullspace_f64`` returns the very rows ``torch.linalg.svd`` returns (``_rchq.py:140-143``): no sign or
+    rotation freedom, agreement at rounding level."""
+    from tests.cpu_stand_in import householder_nullspace
+
+    g = torch.Generator().manual_seed(s * 1000 + M)
+    X = torch.randn(s, M, generator=g, dtype=torch.float64)
+    X[0] = 1.0
+    ref = torch.linalg.svd(X)[2][s:]
+    got = hip_ops.nullspace(hip_ops.to_device(X), s, M).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 1e-11
+    assert (got - householder_nullspace(X)).abs().max().item() <= 1e-12
+    assert (X @ got.T).abs().max().item() <= 1e-12 * M
+
+
+def test_nullspace_zero_tail_row(hip_ops):
+    """A row whose tail is exactly zero gives tau = 0 (dlarfg's early exit), not a NaN."""
+    s, M = 4, 8
+    X = torch.zeros(s, M, dtype=torch.float64)
+    X[0, 0] = 2.0
+    X[1, 1] = -3.0
+    X[2, 2] = 1.0
+    X[3, 3] = 5.0
+    got = hip_ops.nullspace(hip_ops.to_device(X), s, M).cpu()
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, torch.eye(M, dtype=torch.float64)[s:])
+
+
+@pytest.mark.parametrize("M,s,seed", [(200, 100, 0), (400, 200, 2), (150, 100, 3), (62, 31, 5)])
+def test_nullspace_then_eliminate_matches_host_svd_route(hip_ops, M, s, seed):
+    """GPU null space + GPU elimination keeps the same sets as host LAPACK SVD + the CPU elimination."""
+    cpu = CpuStandInOps()
+    g = torch.Generator().manual_seed(seed)
+    X = torch.randn(s, M, generator=g, dtype=torch.float64)
+    X[0] = 1.0
+    PhiT = torch.linalg.svd(X)[2][-(M - s):, :].contiguous()
+    mu = torch.rand(M, generator=g, dtype=torch.float64) + 0.05
+    mu = mu / mu.sum()
+    _, kept_c, w_c, info_c = cpu.car_eliminate(PhiT.clone(), mu.clone(), M, s)
+    Pg = hip_ops.nullspace(hip_ops.to_device(X), s, M)
+    _, kept_g, w_g, info_g = hip_ops.car_eliminate(Pg, hip_ops.to_device(mu.clone()), M, s)
+    n = int(info_c[0])
+    assert info_g.cpu().tolist() == info_c.tolist()
+    assert torch.equal(kept_g.cpu()[:n], kept_c[:n])
+    assert ((w_g.cpu()[:n] - w_c[:n]).abs() / w_c[:n]).max().item() <= 1e-8
+
+
 def test_car_eliminate_degenerate_flag(hip_ops):
     """A null vector without a positive entry sets status=1 (the reference raises at _rchq.py:152)."""
     M, s = 8, 4
