@@ -1186,10 +1186,47 @@ __global__ void __launch_bounds__(1024) car_eliminate_lds_kernel(const double* _
 // when they do not fit); 4 barriers per step.  Outputs V[i, :] = v_i and tau[i].
 // nullspace_apply_kernel: one wave per null vector c: y = e_{m+c}; for i = m-1..0: y -= tau_i (v_i . y) v_i.
 // ------------------------------------------------------------------------------------------------
+#ifndef BASQ_WAVE_SUM_DPP
+#define BASQ_WAVE_SUM_DPP 1
+#endif
+// v shifted across lanes by a DPP control (row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143);
+// lanes without a source (or masked off) receive 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_shift_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Sum over the 64 lanes, same value returned to every lane, fixed association.  DPP form: prefix sums inside
+// each row of 16 lanes (row_shr 1,2,4,8), row totals forwarded (row_bcast 15 / 31), lane 63 read back through
+// an SGPR -- ~20 VALU instructions instead of six dependent ds_bpermute round trips.
 __device__ __forceinline__ double wave_sum(double v) {
+#if BASQ_WAVE_SUM_DPP
+    v += dpp_shift_f64<0x111, 0xf>(v);
+    v += dpp_shift_f64<0x112, 0xf>(v);
+    v += dpp_shift_f64<0x114, 0xf>(v);
+    v += dpp_shift_f64<0x118, 0xf>(v);
+    v += dpp_shift_f64<0x142, 0xa>(v);
+    v += dpp_shift_f64<0x143, 0xc>(v);
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, 63);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+#else
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+#endif
+}
+
+// value of lane `src` (wave-uniform index) delivered through SGPRs
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, src);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
 // dlarfg: reflector for (alpha, x) from alpha and |x|^2; returns tau, scale = 1/(alpha - beta) (0, 0 if x == 0)
@@ -1375,6 +1412,235 @@ __global__ void __launch_bounds__(NW * 64) bidiag_reflectors_kernel(const double
 #undef BASQ_OWN_ROWS
 #undef BASQ_ROW_ST
 #undef BASQ_ROW_LD
+}
+
+// 1/d to ~1 ulp without the scaling / fix-up of an IEEE divide (d is a normal, finite reflector norm here)
+__device__ __forceinline__ double recip_nr(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+#pragma unroll
+    for (int it = 0; it < 3; ++it) y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+    return y;
+}
+
+// householder_params with the two quotients as independent reciprocal chains (serial section of the kernel below)
+__device__ __forceinline__ void householder_params_fast(double alpha, double ss, double& tau, double& scale) {
+    if (ss == 0.0) { tau = 0.0; scale = 0.0; return; }
+    const double nrm = __builtin_sqrt(alpha * alpha + ss);
+    const double beta = (alpha >= 0.0) ? -nrm : nrm;
+    tau = (beta - alpha) * recip_nr(beta);
+    scale = recip_nr(alpha - beta);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_perm_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Four 64-lane sums for the price of one (gfx950 v_permlane32_swap / v_permlane16_swap): fold the wave in half
+// with x0,x1 (resp. x2,x3) sharing a register, fold the 16-lane rows with the two pairs sharing a register, then
+// an xor-butterfly inside each row of 16.  Totals come back wave-uniform (SGPRs).
+__device__ __forceinline__ void wave_sum4(double& x0, double& x1, double& x2, double& x3) {
+    auto fold32 = [](double a, double b) {     // lanes 0-31: a[l] + a[l+32];  lanes 32-63: b[l-32] + b[l]
+        const long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
+        const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)ba, (unsigned)bb, false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)(ba >> 32), (unsigned)(bb >> 32), false, false);
+        const double a2 = __longlong_as_double(((long long)hi[0] << 32) | lo[0]);
+        const double b2 = __longlong_as_double(((long long)hi[1] << 32) | lo[1]);
+        return a2 + b2;
+    };
+    auto fold16 = [](double a, double b) {     // rows of 16: [a r0 + a r1, b r0 + b r1, a r2 + a r3, b r2 + b r3]
+        const long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
+        const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)ba, (unsigned)bb, false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(ba >> 32), (unsigned)(bb >> 32), false, false);
+        const double a2 = __longlong_as_double(((long long)hi[0] << 32) | lo[0]);
+        const double b2 = __longlong_as_double(((long long)hi[1] << 32) | lo[1]);
+        return a2 + b2;
+    };
+    double v = fold16(fold32(x0, x1), fold32(x2, x3));   // rows: x0 | x2 | x1 | x3
+    v += dpp_perm_f64<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_perm_f64<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_perm_f64<0x141>(v);    // row_half_mirror
+    v += dpp_perm_f64<0x140>(v);    // row_mirror
+    x0 = readlane_f64(v, 0);
+    x2 = readlane_f64(v, 16);
+    x1 = readlane_f64(v, 32);
+    x3 = readlane_f64(v, 48);
+}
+
+// Register-resident form for m <= 16*NREG rows, n <= 64*NV columns (the headline 100 x 200 fits NREG = 7, NV = 4):
+// the whole matrix lives in VGPRs (row r -> wave r % 16, slot r / 16; lanes own column PAIRS, so the broadcast
+// vectors move as 16-byte LDS accesses), LDS carries only those vectors.  Two barriers per step t:
+//   phase A (all waves, live rows r > t only): apply the PREVIOUS left reflector H_{t-1} (deferred), apply G_t
+//       (row dots reduced four at a time, rank-1 update), read column t of the updated rows back through SGPRs,
+//       accumulate this wave's share of column_t^T A and |column_t|^2; the owner of row t+1 publishes that row;
+//   phase B (wave 0): sum the 16 partials, form H_t (tauq, u scale, w = u^T A), update row t+1 with it and form
+//       G_{t+1} from the result -> v_{t+1}, tau_{t+1}.
+// Same reflectors as dgebd2; only the association of the sums differs (agreement with LAPACK ~1e-14).
+// optional in-kernel phase stamps (tools/ns_prof.hip): wave w, lane 0 -> g_ns_prof[(t * 8 + slot) * 16 + w]
+#ifdef BASQ_NS_PROF
+__device__ long long* g_ns_prof;
+#define BASQ_NS_STAMP(t, slot)                                                                     \
+    do {                                                                                           \
+        if ((threadIdx.x & 63) == 0) g_ns_prof[((t) * 8 + (slot)) * 16 + (threadIdx.x >> 6)] = clock64(); \
+    } while (0)
+#else
+#define BASQ_NS_STAMP(t, slot) do { } while (0)
+#endif
+
+template <int NV, int NREG>
+__global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const double* __restrict__ X, int m, int n,
+                                                                     double* __restrict__ V,
+                                                                     double* __restrict__ tau_g) {
+    static_assert(NV % 2 == 0, "lanes own column pairs");
+    constexpr int NW = 16, NC = NV * 64, NG = (NREG + 3) / 4;
+    __shared__ __attribute__((aligned(16))) double vsh[NC];          // v_t
+    __shared__ __attribute__((aligned(16))) double wsh[NC];          // w of H_{t-1}, zero for c < t
+    __shared__ __attribute__((aligned(16))) double r1sh[NC];         // row t+1 after G_t
+    __shared__ __attribute__((aligned(16))) double wpart[NW * NC];   // per-wave partials of column_t^T A
+    __shared__ double sspart[NW];
+    __shared__ double par[4];             // tau_t, tauq_{t-1}, u-scale_{t-1}, alpha of H_t
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // slot k of this lane holds column COL(k); column c sits in lane (c & 127) >> 1, slot (c & 1) + 2 (c >> 7)
+#define BASQ_COL(k) (2 * lane + ((k) & 1) + 128 * ((k) >> 1))
+    double a[NG * 4][NV], cprev[NG * 4];
+#pragma unroll
+    for (int jr = 0; jr < NG * 4; ++jr) {
+        const int r = wv + NW * jr;
+        cprev[jr] = 0.0;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = BASQ_COL(k);
+            a[jr][k] = (jr < NREG && r < m && c < n) ? X[(size_t)r * n + c] : 0.0;
+        }
+    }
+    // right reflector G_t from the row held in rn[] (lanes own columns); publishes v_t, tau_t
+    auto make_right = [&](const double (&rn)[NV], int t) {
+        const int tk = (t & 1) + 2 * (t >> 7), tl = (t & 127) >> 1;
+        double ss = 0.0, al = 0.0;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = BASQ_COL(k);
+            if (c > t) ss += rn[k] * rn[k];
+            if (k == tk) al = rn[k];
+        }
+        ss = wave_sum(ss);
+        const double alpha = readlane_f64(al, tl);
+        double tau, scale;
+        householder_params_fast(alpha, ss, tau, scale);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = BASQ_COL(k);
+            const double v = (c < t) ? 0.0 : ((c == t) ? 1.0 : rn[k] * scale);
+            vsh[c] = v;
+            if (c < n) V[(size_t)t * n + c] = v;
+        }
+        if (lane == 0) { par[0] = tau; tau_g[t] = tau; }
+    };
+    if (wv == 0) {
+        make_right(a[0], 0);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) wsh[BASQ_COL(k)] = 0.0;
+        if (lane == 0) { par[1] = 0.0; par[2] = 0.0; }
+    }
+    __syncthreads();
+    for (int t = 0; t + 1 < m; ++t) {
+        const int tk = (t & 1) + 2 * (t >> 7), tl = (t & 127) >> 1;
+        BASQ_NS_STAMP(t, 0);
+        {   // ---- phase A ----
+            const double tau = par[0], kappa = par[1] * par[2];     // tauq * u-scale of H_{t-1}
+            double vr[NV], wc[NV], pw[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                vr[k] = vsh[BASQ_COL(k)];
+                wc[k] = wsh[BASQ_COL(k)];
+                pw[k] = 0.0;
+            }
+            double ssp = 0.0;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (wv + NW * (4 * g + 3) <= t) continue;           // wave-uniform: the whole group is dead
+                double dot[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int jr = 4 * g + j, r = wv + NW * jr;
+                    dot[j] = 0.0;
+                    if (jr < NREG && r > t && r < m) {              // wave-uniform
+                        const double tu = kappa * cprev[jr];        // H_{t-1}: tauq u_r, u_r = column_{t-1}[r] * scale
+#pragma unroll
+                        for (int k = 0; k < NV; ++k) {
+                            a[jr][k] -= tu * wc[k];
+                            dot[j] += a[jr][k] * vr[k];
+                        }
+                    }
+                }
+                wave_sum4(dot[0], dot[1], dot[2], dot[3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int jr = 4 * g + j, r = wv + NW * jr;
+                    if (jr < NREG && r > t && r < m) {
+                        const double td = tau * dot[j];             // G_t
+                        double colv = 0.0;
+#pragma unroll
+                        for (int k = 0; k < NV; ++k) {
+                            a[jr][k] -= td * vr[k];
+                            if (k == tk) colv = a[jr][k];
+                        }
+                        const double cr = readlane_f64(colv, tl);   // A[r][t] after G_t
+                        cprev[jr] = cr;
+                        if (r == t + 1) {
+#pragma unroll
+                            for (int k = 0; k < NV; ++k) r1sh[BASQ_COL(k)] = a[jr][k];
+                            if (lane == 0) par[3] = cr;
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < NV; ++k) pw[k] += cr * a[jr][k];
+                            ssp += cr * cr;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) wpart[wv * NC + BASQ_COL(k)] = pw[k];
+            if (lane == 0) sspart[wv] = ssp;
+        }
+        BASQ_NS_STAMP(t, 1);
+        __syncthreads();
+        BASQ_NS_STAMP(t, 2);
+        if (wv == 0) {   // ---- phase B ----
+            double ss2 = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) ss2 += sspart[w];
+            double tauq, uscale;
+            BASQ_NS_STAMP(t, 4);
+            householder_params_fast(par[3], ss2, tauq, uscale);
+            BASQ_NS_STAMP(t, 5);
+            double rn[NV], accs[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) accs[k] = 0.0;
+#pragma unroll 8
+            for (int w = 0; w < NW; ++w) {       // 8 partial rows (16 x 16-byte reads) in flight per batch
+#pragma unroll
+                for (int k = 0; k < NV; ++k) accs[k] += wpart[w * NC + BASQ_COL(k)];
+            }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int c = BASQ_COL(k);
+                const double r1 = r1sh[c];
+                const double wv_c = (c > t) ? (r1 + uscale * accs[k]) : 0.0;   // u^T A with u = [1, column * scale]
+                wsh[c] = wv_c;
+                rn[k] = r1 - tauq * wv_c;                                       // row t+1 after H_t
+            }
+            if (lane == 0) { par[1] = tauq; par[2] = uscale; }
+            BASQ_NS_STAMP(t, 6);
+            make_right(rn, t + 1);
+        }
+        BASQ_NS_STAMP(t, 3);
+        __syncthreads();
+    }
+#undef BASQ_COL
 }
 
 template <int NV>
@@ -1862,7 +2128,12 @@ int basq_nullspace_f64(const double* X, int32_t s, int32_t M, double* V, double*
     hipStream_t st = (hipStream_t)stream;
     const size_t LDS_MAX = 163840 - 64;                         // per-CU LDS minus the kernel's static scalar
     int rc;
-    if (M <= 256) {
+    if (M <= 256 && s <= 112) {                                 // whole matrix in registers
+        if (s <= 32) hipLaunchKernelGGL((bidiag_reflectors_reg_kernel<4, 2>), dim3(1), dim3(1024), 0, st, X, s, M, V, tau);
+        else if (s <= 64) hipLaunchKernelGGL((bidiag_reflectors_reg_kernel<4, 4>), dim3(1), dim3(1024), 0, st, X, s, M, V, tau);
+        else hipLaunchKernelGGL((bidiag_reflectors_reg_kernel<4, 7>), dim3(1), dim3(1024), 0, st, X, s, M, V, tau);
+        rc = (hipGetLastError() == hipSuccess) ? BASQ_OK : BASQ_ELAUNCH;
+    } else if (M <= 256) {
         const size_t fixed = (size_t)(2 * M + s + 16 * M) * sizeof(double);
         const size_t rows = (size_t)(s > 32 ? s - 32 : 0) * M * sizeof(double);
         if (fixed + rows <= LDS_MAX) rc = launch_bidiag<4, 2, 16, true>(X, s, M, V, tau, fixed + rows, st);

