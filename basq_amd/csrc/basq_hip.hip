@@ -979,6 +979,24 @@ __device__ __forceinline__ double div_by_recip(double a, double b, double rb) {
     return __builtin_fma(r, rb, q0);
 }
 
+// value of lane `src` (wave-uniform index) delivered through SGPRs
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, src);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// v moved across lanes by a DPP control (row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143);
+// lanes without a source, or in rows masked off, receive `fill`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_shift_fill_f64(double v, double fill) {
+    const long long b = __double_as_longlong(v), o = __double_as_longlong(fill);
+    const int lo = __builtin_amdgcn_update_dpp((int)o, (int)b, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(o >> 32), (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Caratheodory elimination (BASQ/_rchq.py:146-175), single work-group, reference op order.
 // ------------------------------------------------------------------------------------------------
@@ -1074,8 +1092,24 @@ __global__ void __launch_bounds__(1024) car_eliminate_kernel(double* __restrict_
     if (tid == 0) { info[0] = total; info[1] = status; }
 }
 
-// LDS-resident form (used when (M-s)*M + M + (M-s) doubles fit in 160 KB, e.g. M = 200, s = 100): identical
-// arithmetic and pivot rule, but the null-space rows never leave the CU -- ~3 barriers per step, no L2 round trips.
+// LDS-resident form (used when (M-s)*M + M doubles fit in 160 KB, e.g. M = 200, s = 100): identical arithmetic
+// and pivot rule, but the null-space rows never leave the CU and a step costs two barriers:
+//   * ratio test: wave minimum by DPP (min is exact, so any association gives the reference's value), first
+//     lane holding it by ballot; the per-wave winners go through LDS and EVERY wave scans them (no second
+//     reduction stage);
+//   * an eliminated column is remembered in a per-thread flag instead of being zeroed (:167-171 zero it only so
+//     that it is never chosen again): Phi[:, j] is then read-only during the rank-1 update and needs no staging.
+__device__ __forceinline__ double wave_min_f64(double v) {
+    const double INF = __builtin_huge_val();
+    v = fmin(v, dpp_shift_fill_f64<0x111, 0xf>(v, INF));      // row_shr 1, 2, 4, 8: running minima inside rows of 16
+    v = fmin(v, dpp_shift_fill_f64<0x112, 0xf>(v, INF));
+    v = fmin(v, dpp_shift_fill_f64<0x114, 0xf>(v, INF));
+    v = fmin(v, dpp_shift_fill_f64<0x118, 0xf>(v, INF));
+    v = fmin(v, dpp_shift_fill_f64<0x142, 0xa>(v, INF));      // row_bcast 15 / 31: lane 63 ends with the wave minimum
+    v = fmin(v, dpp_shift_fill_f64<0x143, 0xc>(v, INF));
+    return readlane_f64(v, 63);
+}
+
 __global__ void __launch_bounds__(1024) car_eliminate_lds_kernel(const double* __restrict__ PhiT_g,
                                                                  double* __restrict__ mu_g, int M, int s,
                                                                  int* __restrict__ keep_rank, int* __restrict__ kept,
@@ -1085,14 +1119,12 @@ __global__ void __launch_bounds__(1024) car_eliminate_lds_kernel(const double* _
     const int nrows = M - s;
     double* Phi = sm;                          // [nrows][M]
     double* mu = sm + (size_t)nrows * M;       // [M]
-    double* pc = mu + M;                       // [nrows]
-    __shared__ double red_v[16];
-    __shared__ int red_i[16];
-    __shared__ double sh_alpha, sh_phij;
-    __shared__ int sh_j;
+    __shared__ double red_v[2][16];            // double-buffered by step parity: one barrier between write and scan
+    __shared__ int red_i[2][16];
     __shared__ int wave_cnt[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int nt = blockDim.x, nwv = nt >> 6;       // 256..1024 threads (BASQ_CAR_THREADS)
+    const int nwv_act = (M + 63) >> 6;              // waves that own a column (tid < M)
     const double INF = __builtin_huge_val();
     for (int e = tid; e < nrows * M; e += nt) Phi[e] = PhiT_g[e];
     if (tid < M) mu[tid] = mu_g[tid];
@@ -1100,52 +1132,47 @@ __global__ void __launch_bounds__(1024) car_eliminate_lds_kernel(const double* _
     const int rows_per_pass = nt / M > 0 ? nt / M : 1;   // M <= nt is guaranteed by the launcher
     const int my_i = tid % M, my_r = tid / M;
     const bool upd = my_r < rows_per_pass;
+    bool dead_col = false;                          // column tid (ratio test)
+    bool dead_upd = false;                          // column my_i (update pass)
     __syncthreads();
     for (int k = 0; k < nrows; ++k) {
         const double* col = Phi + (size_t)k * M;
-        const double phi = (tid < M) ? col[tid] : 0.0;
-        const bool pos = (tid < M) && (phi > 0.0);
-        double av = pos ? (mu[tid] / phi) : INF;
-        int ai = pos ? tid : 0x7fffffff;
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const double ov = __shfl_xor(av, o, 64);
-            const int oi = __shfl_xor(ai, o, 64);
-            if (ov < av || (ov == av && oi < ai)) { av = ov; ai = oi; }
-        }
-        if (lane == 0) { red_v[wv] = av; red_i[wv] = ai; }
-        __syncthreads();
-        if (wv == 0) {
-            double v = (lane < nwv) ? red_v[lane] : INF;
-            int i = (lane < nwv) ? red_i[lane] : 0x7fffffff;
-#pragma unroll
-            for (int o = 8; o >= 1; o >>= 1) {
-                const double ov = __shfl_xor(v, o, 64);
-                const int oi = __shfl_xor(i, o, 64);
-                if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+        const int pb = k & 1;
+        if (wv < nwv_act) {
+            const double phi = (tid < M) ? col[tid] : 0.0;
+            const bool pos = (tid < M) && !dead_col && (phi > 0.0);
+            const double av = pos ? (mu[tid] / phi) : INF;
+            const double wmin = wave_min_f64(av);
+            const unsigned long long hit = __ballot(pos && av == wmin);   // first-index argmin (torch.argmin, :152)
+            if (lane == 0) {
+                red_v[pb][wv] = wmin;
+                red_i[pb][wv] = hit ? (wv * 64 + (int)__builtin_ctzll(hit)) : 0x7fffffff;
             }
-            if (lane == 0) { sh_j = i; sh_alpha = v; }
         }
         __syncthreads();
-        const int j = sh_j;
-        if (j == 0x7fffffff) { status = 1; break; }
-        if (tid == j) sh_phij = phi;
-        const double aj = sh_alpha;
-        if (tid < M) {
-            const double step = aj * phi;
-            mu[tid] = (tid == j) ? 0.0 : (mu[tid] - step);
+        double aj = INF;
+        int j = 0x7fffffff;
+        for (int w = 0; w < nwv_act; ++w) {
+            const double v = red_v[pb][w];
+            const int i = red_i[pb][w];
+            if (i != 0x7fffffff && (v < aj || j == 0x7fffffff)) { aj = v; j = i; }   // ties keep the lower wave
         }
-        for (int cc = k + 1 + tid; cc < nrows; cc += nt) pc[cc] = Phi[(size_t)cc * M + j];
-        __syncthreads();
-        const double phij = sh_phij;
+        if (j == 0x7fffffff) { status = 1; break; }   // uniform: no positive entry (reference raises)
+        const double phij = col[j];
+        if (tid < M) {                                                                  // :158-159
+            const double step = aj * col[tid];
+            if (tid == j) dead_col = true;
+            mu[tid] = dead_col ? 0.0 : (mu[tid] - step);     // eliminated columns: the reference has Phi = 0, mu = 0
+        }
+        if (my_i == j) dead_upd = true;
         const double rphij = 1.0 / phij;                                     // correctly rounded reciprocal
         const double phi_i = col[my_i];
-        if (upd) {
-            for (int cc = k + 1 + my_r; cc < nrows; cc += rows_per_pass) {
-                double* p = Phi + (size_t)cc * M + my_i;
-                const double prod = pc[cc] * phi_i;
+        if (upd && !dead_upd) {
+            for (int cc = k + 1 + my_r; cc < nrows; cc += rows_per_pass) {   // :165-171
+                double* p = Phi + (size_t)cc * M;
+                const double prod = p[j] * phi_i;
                 const double o = div_by_recip(prod, phij, rphij);            // == prod / phij, bit for bit
-                *p = (my_i == j) ? 0.0 : (*p - o);
+                p[my_i] = p[my_i] - o;
             }
         }
         __syncthreads();
@@ -1219,14 +1246,6 @@ __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 #endif
-}
-
-// value of lane `src` (wave-uniform index) delivered through SGPRs
-__device__ __forceinline__ double readlane_f64(double v, int src) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)b, src);
-    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
 // dlarfg: reflector for (alpha, x) from alpha and |x|^2; returns tau, scale = 1/(alpha - beta) (0, 0 if x == 0)
@@ -2105,7 +2124,7 @@ int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32
                            double* w_star, int32_t* info, void* stream) {
     if (!PhiT || !mu || !keep_rank || !kept || !w_star || !info || M < 1 || M > 1024 || s < 1 || s > M)
         return BASQ_EINVAL;
-    const size_t lds = ((size_t)(M - s) * M + M + (M - s)) * sizeof(double);
+    const size_t lds = ((size_t)(M - s) * M + M) * sizeof(double);
     if (s < M && lds <= 162560) {      // 163840 B per CU minus the kernel's static LDS
         if (hipFuncSetAttribute((const void*)car_eliminate_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
