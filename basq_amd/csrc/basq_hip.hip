@@ -211,6 +211,17 @@ __device__ __forceinline__ double sum16(double v) {
     return v;
 }
 
+// optional in-kernel phase stamps (tools/ns_prof.hip): wave w, lane 0 -> g_ns_prof[(t * 8 + slot) * 16 + w]
+#ifdef BASQ_NS_PROF
+__device__ long long* g_ns_prof;
+#define BASQ_NS_STAMP(t, slot)                                                                     \
+    do {                                                                                           \
+        if ((threadIdx.x & 63) == 0) g_ns_prof[((t) * 8 + (slot)) * 16 + (threadIdx.x >> 6)] = clock64(); \
+    } while (0)
+#else
+#define BASQ_NS_STAMP(t, slot) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // pack / init / mean
 // ------------------------------------------------------------------------------------------------
@@ -1502,17 +1513,6 @@ __device__ __forceinline__ void wave_sum4(double& x0, double& x1, double& x2, do
 //   phase B (wave 0): sum the 16 partials, form H_t (tauq, u scale, w = u^T A), update row t+1 with it and form
 //       G_{t+1} from the result -> v_{t+1}, tau_{t+1}.
 // Same reflectors as dgebd2; only the association of the sums differs (agreement with LAPACK ~1e-14).
-// optional in-kernel phase stamps (tools/ns_prof.hip): wave w, lane 0 -> g_ns_prof[(t * 8 + slot) * 16 + w]
-#ifdef BASQ_NS_PROF
-__device__ long long* g_ns_prof;
-#define BASQ_NS_STAMP(t, slot)                                                                     \
-    do {                                                                                           \
-        if ((threadIdx.x & 63) == 0) g_ns_prof[((t) * 8 + (slot)) * 16 + (threadIdx.x >> 6)] = clock64(); \
-    } while (0)
-#else
-#define BASQ_NS_STAMP(t, slot) do { } while (0)
-#endif
-
 template <int NV, int NREG>
 __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const double* __restrict__ X, int m, int n,
                                                                      double* __restrict__ V,
@@ -1819,14 +1819,32 @@ __global__ void __launch_bounds__(1024) chol_inv_kernel(double* __restrict__ G, 
     }
 }
 
+// 1/sqrt(d) to ~1 ulp: v_rsq_f64 seed + three coupled Newton steps (g -> sqrt(d), h -> 1/(2 sqrt(d))).
+__device__ __forceinline__ double rsqrt_nr(double d) {
+    const double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const double r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g);
+        h = __builtin_fma(h, r, h);
+    }
+    return 2.0 * h;
+}
+
 // LDS-resident form of chol_inv_kernel for q*q doubles <= ~150 KB (q <= 136): the factor lives in LDS with an
-// odd leading dimension (column accesses conflict-free), 2 barriers per pivot and no global round trips.
+// odd leading dimension.  Cholesky: right-looking, column j scaled by a reciprocal square root (no sqrt + divide
+// chain), 2 barriers per column.  Inverse: with BLOCKED != 0 (a second q x q square fits in LDS, q <= 100)
+// Y = L^{-1} is assembled from the inverses of four diagonal blocks (one thread per column, chains of
+// (q/4)^2/2 steps instead of q^2/2) and two levels of products Y_CA = -Y_CC (L_CA Y_AA) done by all threads;
+// otherwise one thread per column runs the whole forward substitution.
 __global__ void __launch_bounds__(1024) chol_inv_lds_kernel(double* __restrict__ G, int q, double* __restrict__ W,
-                                                            int* __restrict__ info, double rel_tol) {
+                                                            int* __restrict__ info, double rel_tol, int blocked) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int ld = q | 1;
     double* Ls = sm;                  // [q][ld]
-    double* colj = sm + (size_t)q * ld;
+    double* colj = sm + (size_t)q * ld;            // [q rounded up to even]: column j, then the reciprocal diagonal
+    double* Ys = colj + ((q + 1) & ~1);            // [q][ld]  (only when blocked)
     __shared__ double red[16];
     __shared__ double s_dmax;
     __shared__ int s_bad;
@@ -1850,25 +1868,36 @@ __global__ void __launch_bounds__(1024) chol_inv_lds_kernel(double* __restrict__
     }
     __syncthreads();
     const double floor_ = rel_tol * s_dmax;
+    BASQ_NS_STAMP(0, 0);
     for (int j = 0; j < q; ++j) {
         const double d = Ls[j * ld + j];
         if (!(d > floor_)) {                                  // uniform: every thread reads the same pivot
             if (tid == 0) s_bad = j + 1;
             break;
         }
-        const double piv = sqrt(d);
-        for (int i = j + 1 + tid; i < q; i += 1024) colj[i] = Ls[i * ld + j] / piv;
+        double rpiv = 0.0;
+        if (tid < q - j) {                                    // only the waves that hold column j do the pivot math
+            rpiv = rsqrt_nr(d);
+            if (tid > 0) {
+                const int i = j + tid;
+                const double v = Ls[i * ld + j] * rpiv;
+                colj[i] = v;
+                Ls[i * ld + j] = v;
+            }
+        }
         __syncthreads();
-        if (tid == 0) Ls[j * ld + j] = piv;
-        for (int i = j + 1 + tid; i < q; i += 1024) Ls[i * ld + j] = colj[i];
-        const int n = q - j - 1;
-        for (int idx = tid; idx < n * n; idx += 1024) {
-            const int a = idx / n, b = idx - a * n;
-            if (b <= a) Ls[(j + 1 + a) * ld + (j + 1 + b)] -= colj[j + 1 + a] * colj[j + 1 + b];
+        if (tid == 0) {                                       // after the barrier: every thread has read d by now
+            Ls[j * ld + j] = d * rpiv;
+            colj[j] = rpiv;                                   // reciprocal diagonal, used by the inverse
+        }
+        // trailing update, lower triangle: 8 rows x 128 columns per pass (no index division)
+        for (int a = j + 1 + (tid >> 7); a < q; a += 8) {
+            for (int b = j + 1 + (tid & 127); b <= a; b += 128) Ls[a * ld + b] -= colj[a] * colj[b];
         }
         __syncthreads();
     }
     __syncthreads();
+    BASQ_NS_STAMP(0, 1);
     const int bad = s_bad;
     if (tid == 0) info[0] = bad;
     // write L back (lower triangle incl. diagonal; the strict upper triangle of G is left untouched)
@@ -1876,21 +1905,106 @@ __global__ void __launch_bounds__(1024) chol_inv_lds_kernel(double* __restrict__
         const int i = e / q, k = e - i * q;
         if (k <= i) G[e] = Ls[i * ld + k];
     }
-    if (bad || tid >= q) return;
+    BASQ_NS_STAMP(0, 2);
+    if (bad) return;                                          // uniform
+    if (blocked) {
+        // ---- blocked inverse: Y = L^{-1} in Ys (lower triangle); products staged transposed in Ys' upper triangle
+        int bnd[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) bnd[k] = (k * q) / 4;
+        // (1) diagonal blocks: thread c inverts its column inside its block
+        if (tid < q) {
+            const int c = tid;
+            int hi = q;
+#pragma unroll
+            for (int k = 4; k >= 1; --k) if (c < bnd[k]) hi = bnd[k];
+            const double ycc = colj[c];
+            Ys[c * ld + c] = ycc;
+            for (int i = c + 1; i < hi; ++i) {
+                const double* lrow = Ls + i * ld;
+                double a0 = -lrow[c] * ycc, a1 = 0.0;
+                int k = c + 1;
+                for (; k + 1 < i; k += 2) {
+                    a0 = __builtin_fma(-lrow[k], Ys[k * ld + c], a0);
+                    a1 = __builtin_fma(-lrow[k + 1], Ys[(k + 1) * ld + c], a1);
+                }
+                if (k < i) a0 = __builtin_fma(-lrow[k], Ys[k * ld + c], a0);
+                Ys[i * ld + c] = (a0 + a1) * colj[i];
+            }
+        }
+        __syncthreads();
+        // (2) merge levels: pairs (0,1), (2,3), then (01, 23).  For rows r in C = [c0, c1), columns c in A = [a0, c0):
+        //     T[r][c] = sum_{k=c}^{c0-1} L[r][k] Y[k][c]  -> staged at Ys[c][r];   Y[r][c] = -sum_{k=c0}^{r} Y[r][k] T[k][c]
+        for (int level = 0; level < 2; ++level) {
+            const int npair = level == 0 ? 2 : 1;
+            for (int phase = 0; phase < 2; ++phase) {
+                for (int pr = 0; pr < npair; ++pr) {
+                    const int a0 = level == 0 ? bnd[2 * pr] : bnd[0];
+                    const int c0 = level == 0 ? bnd[2 * pr + 1] : bnd[2];
+                    const int c1 = level == 0 ? bnd[2 * pr + 2] : bnd[4];
+                    const int nA = c0 - a0, nC = c1 - c0;
+                    if (nA <= 0 || nC <= 0) continue;
+                    for (int o = tid; o < nA * nC; o += 1024) {
+                        const int rr = o / nA, cc = o - rr * nA;        // consecutive threads -> consecutive columns
+                        const int r = c0 + rr, c = a0 + cc;
+                        double acc0 = 0.0, acc1 = 0.0;
+                        if (phase == 0) {
+                            const double* lrow = Ls + r * ld;
+                            int k = c;
+                            for (; k + 1 < c0; k += 2) {
+                                acc0 = __builtin_fma(lrow[k], Ys[k * ld + c], acc0);
+                                acc1 = __builtin_fma(lrow[k + 1], Ys[(k + 1) * ld + c], acc1);
+                            }
+                            if (k < c0) acc0 = __builtin_fma(lrow[k], Ys[k * ld + c], acc0);
+                            Ys[c * ld + r] = acc0 + acc1;               // staged transposed (strict upper triangle)
+                        } else {
+                            const double* yrow = Ys + r * ld;
+                            const double* trow = Ys + c * ld;
+                            int k = c0;
+                            for (; k + 1 <= r; k += 2) {
+                                acc0 = __builtin_fma(yrow[k], trow[k], acc0);
+                                acc1 = __builtin_fma(yrow[k + 1], trow[k + 1], acc1);
+                            }
+                            if (k <= r) acc0 = __builtin_fma(yrow[k], trow[k], acc0);
+                            Ys[r * ld + c] = -(acc0 + acc1);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // W = L^{-T}: W[c][i] = Y[i][c], i >= c (W was zeroed above)
+        for (int e = tid; e < q * q; e += 1024) {
+            const int i = e / q, c = e - i * q;
+            if (c <= i) W[(long long)c * q + i] = Ys[i * ld + c];
+        }
+        BASQ_NS_STAMP(0, 3);
+        return;
+    }
+    if (tid >= q) return;
     // column c of Y = L^{-1} by forward substitution, kept in the (now free) upper triangle of Ls:
     // Y[i][c] (i >= c) is stored at Ls[c][i] for i > c (strictly upper), and its diagonal in a register.
     const int c = tid;
     double* wrow = W + (long long)c * q;
-    const double ycc = 1.0 / Ls[c * ld + c];
+    const double* yrow = Ls + c * ld;
+    const double ycc = colj[c];
     wrow[c] = ycc;
     for (int i = c + 1; i < q; ++i) {
         const double* lrow = Ls + i * ld;
-        double acc = -lrow[c] * ycc;
-        for (int k = c + 1; k < i; ++k) acc -= lrow[k] * Ls[c * ld + k];
-        const double y = acc / lrow[i];
+        double a0 = -lrow[c] * ycc, a1 = 0.0, a2 = 0.0, a3 = 0.0;     // four independent chains (latency-bound loop)
+        int k = c + 1;
+        for (; k + 3 < i; k += 4) {
+            a0 = __builtin_fma(-lrow[k], yrow[k], a0);
+            a1 = __builtin_fma(-lrow[k + 1], yrow[k + 1], a1);
+            a2 = __builtin_fma(-lrow[k + 2], yrow[k + 2], a2);
+            a3 = __builtin_fma(-lrow[k + 3], yrow[k + 3], a3);
+        }
+        for (; k < i; ++k) a0 = __builtin_fma(-lrow[k], yrow[k], a0);
+        const double y = ((a0 + a1) + (a2 + a3)) * colj[i];
         Ls[c * ld + i] = y;                                   // row c, column i > c: strictly upper, owned by thread c
         wrow[i] = y;
     }
+    BASQ_NS_STAMP(0, 3);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2230,12 +2344,18 @@ int basq_dense_sq_blocksum_f64(const double* C, int32_t m, int64_t nc, int64_t l
 
 int basq_chol_inv_f64(double* G, int32_t q, double* W, int32_t* info, double rel_tol, void* stream) {
     if (!G || !W || !info || q < 1 || q > 1024 || !(rel_tol >= 0.0)) return BASQ_EINVAL;
-    const size_t lds = ((size_t)q * (q | 1) + 1024) * sizeof(double);
-    if (lds <= 150 * 1024) {
+    const size_t sq = (size_t)q * (q | 1);
+    const size_t qpad = (size_t)((q + 1) & ~1);
+    const size_t lds1 = (sq + qpad) * sizeof(double), lds2 = (2 * sq + qpad) * sizeof(double);
+    const size_t LDS_MAX = 163840 - 256;                        // per-CU LDS minus the kernel's static part
+    if (lds1 <= LDS_MAX) {
+        const int blocked = (lds2 <= LDS_MAX && q >= 8) ? 1 : 0;
+        const size_t lds = blocked ? lds2 : lds1;
         if (hipFuncSetAttribute((const void*)chol_inv_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
             return BASQ_ELAUNCH;
-        hipLaunchKernelGGL(chol_inv_lds_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, G, q, W, info, rel_tol);
+        hipLaunchKernelGGL(chol_inv_lds_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, G, q, W, info, rel_tol,
+                           blocked);
         BASQ_CHECK_LAUNCH();
         return BASQ_OK;
     }

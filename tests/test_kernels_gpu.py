@@ -254,9 +254,10 @@ def test_no_cpu_path():
                                torch.device("cpu"))
 
 
-@pytest.mark.parametrize("q", [5, 99, 199, 300])
+@pytest.mark.parametrize("q", [1, 5, 8, 9, 30, 99, 100, 101, 137, 199, 300])
 def test_chol_inv(hip_ops, q):
-    """CholeskyQR building block: L L^T = G and (X W)^T (X W) = I."""
+    """CholeskyQR building block: L L^T = G and (X W)^T (X W) = I.  Sizes cover the blocked inverse (8 <= q <= 100,
+    incl. block sizes that do not divide q), the column-per-thread inverse in LDS (q <= 142) and the global kernel."""
     X = _rand(4 * q + 7, q, 20 + q)
     G = X.T @ X
     Gd = hip_ops.to_device(G.clone())
@@ -267,6 +268,8 @@ def test_chol_inv(hip_ops, q):
     Q = X @ W.cpu()
     assert (Q.T @ Q - torch.eye(q, dtype=torch.float64)).abs().max().item() <= 1e-10
     assert torch.equal(torch.tril(W.cpu(), -1), torch.zeros(q, q, dtype=torch.float64))
+    Winv = torch.linalg.inv(L).T                               # W = L^{-T}
+    assert (W.cpu() - Winv).abs().max().item() <= 1e-9 * Winv.abs().max().item()
 
 
 def test_chol_inv_flags_rank_deficiency(hip_ops):

@@ -1,4 +1,4 @@
-"""Time the per-round reduction kernels in isolation: basq_nullspace_f64 and basq_car_eliminate_f64.
+"""Time the single-work-group kernels in isolation: basq_nullspace_f64, basq_car_eliminate_f64, basq_chol_inv_f64.
 
     python tools/bench_reduction.py [s M] [--reps 50]
 
@@ -46,6 +46,10 @@ def main():
 
     print(f"nullspace      {timed(lambda: ops.nullspace(Xd, s, M)):9.1f} us / call")
     print(f"car_eliminate  {timed(lambda: ops.car_eliminate(P.clone(), mud.clone(), M, s)):9.1f} us / call (incl. 2 clones)")
+    q = s - 1 if s > 1 else 1
+    Y = torch.randn(4 * q + 7, q, generator=g, dtype=torch.float64)
+    G = ops.to_device(Y.T @ Y)
+    print(f"chol_inv q={q:<4d}{timed(lambda: ops.chol_inv(G.clone())):9.1f} us / call (incl. 1 clone)")
 
 
 if __name__ == "__main__":

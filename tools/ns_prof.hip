@@ -49,5 +49,35 @@ int main(int argc, char** argv) {
                at(t, 2, 0) - at(t, 1, 0), at(t, 3, 0) - at(t, 2, 0), next - at(t, 3, 0), next - at(t, 0, 0),
                at(t, 4, 0) - at(t, 2, 0), at(t, 5, 0) - at(t, 4, 0), at(t, 6, 0) - at(t, 5, 0), at(t, 3, 0) - at(t, 6, 0));
     }
+    // chol_inv phases (q = m - 1)
+    {
+        const int q = m > 1 ? m - 1 : 1;
+        std::vector<double> Y((size_t)(4 * q + 7) * q), G((size_t)q * q, 0.0);
+        for (auto& v : Y) v = rand() / (double)RAND_MAX - 0.5;
+        for (int i = 0; i < q; ++i)
+            for (int j = 0; j < q; ++j) {
+                double acc = 0;
+                for (int r = 0; r < 4 * q + 7; ++r) acc += Y[(size_t)r * q + i] * Y[(size_t)r * q + j];
+                G[(size_t)i * q + j] = acc;
+            }
+        double *dG, *dW;
+        int* dinfo;
+        hipMalloc(&dG, G.size() * 8);
+        hipMalloc(&dW, G.size() * 8);
+        hipMalloc(&dinfo, 8);
+        for (int rep = 0; rep < 3; ++rep) {
+            hipMemcpy(dG, G.data(), G.size() * 8, hipMemcpyHostToDevice);
+            hipEventRecord(e0);
+            int rc = basq_chol_inv_f64(dG, q, dW, dinfo, 1e-13, nullptr);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("rc=%d  chol_inv q=%d total %.1f us\n", rc, q, ms * 1e3);
+        }
+        hipMemcpy(prof.data(), dprof, 4 * 16 * 8, hipMemcpyDeviceToHost);
+        printf("chol_inv clocks (wave 0): cholesky loop %lld, write-back + recip %lld, inverse (wave 0) %lld, inverse (wave 1) %lld\n",
+               at(0, 1, 0) - at(0, 0, 0), at(0, 2, 0) - at(0, 1, 0), at(0, 3, 0) - at(0, 2, 0), at(0, 3, 1) - at(0, 2, 1));
+    }
     return 0;
 }
