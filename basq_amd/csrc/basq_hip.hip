@@ -739,6 +739,9 @@ __global__ void setsum_kernel(const double* __restrict__ mu, double* __restrict_
 #ifndef BASQ_CAR_THREADS
 #define BASQ_CAR_THREADS 1024
 #endif
+#ifndef BASQ_CHOL_THREADS
+#define BASQ_CHOL_THREADS 1024   // work-group size of chol_inv_lds_kernel (multiple of 128)
+#endif
 #ifndef BASQ_VALU_MAX_KK
 #define BASQ_VALU_MAX_KK 3
 #endif
@@ -1456,13 +1459,36 @@ __device__ __forceinline__ double recip_nr(double d) {
     return y;
 }
 
-// householder_params with the two quotients as independent reciprocal chains (serial section of the kernel below)
+// sqrt(d) and 1/sqrt(d) to ~1 ulp: v_rsq_f64 seed + three coupled Newton steps (g -> sqrt(d), h -> 1/(2 sqrt(d))).
+__device__ __forceinline__ void sqrt_rsqrt_nr(double d, double& root, double& rroot) {
+    const double y = __builtin_amdgcn_rsq(d);
+    double g = d * y, h = 0.5 * y;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+        const double r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g);
+        h = __builtin_fma(h, r, h);
+    }
+    root = g;
+    rroot = 2.0 * h;
+}
+__device__ __forceinline__ double rsqrt_nr(double d) {
+    double g, r;
+    sqrt_rsqrt_nr(d, g, r);
+    return r;
+}
+
+// householder_params for the serial section of the kernel below, as one short dependency chain: with
+// n = |(alpha, x)| and s = sign(alpha):  beta = -s n,  tau = (beta - alpha)/beta = 1 + |alpha| / n,
+// scale = 1/(alpha - beta) = s / (|alpha| + n)   (n and 1/n from one Newton iteration, one reciprocal).
 __device__ __forceinline__ void householder_params_fast(double alpha, double ss, double& tau, double& scale) {
     if (ss == 0.0) { tau = 0.0; scale = 0.0; return; }
-    const double nrm = __builtin_sqrt(alpha * alpha + ss);
-    const double beta = (alpha >= 0.0) ? -nrm : nrm;
-    tau = (beta - alpha) * recip_nr(beta);
-    scale = recip_nr(alpha - beta);
+    double nrm, rnrm;
+    sqrt_rsqrt_nr(__builtin_fma(alpha, alpha, ss), nrm, rnrm);
+    const double aa = __builtin_fabs(alpha);
+    tau = __builtin_fma(aa, rnrm, 1.0);
+    const double r = recip_nr(aa + nrm);
+    scale = (alpha >= 0.0) ? r : -r;
 }
 
 template <int CTRL>
@@ -1510,8 +1536,9 @@ __device__ __forceinline__ void wave_sum4(double& x0, double& x1, double& x2, do
 //   phase A (all waves, live rows r > t only): apply the PREVIOUS left reflector H_{t-1} (deferred), apply G_t
 //       (row dots reduced four at a time, rank-1 update), read column t of the updated rows back through SGPRs,
 //       accumulate this wave's share of column_t^T A and |column_t|^2; the owner of row t+1 publishes that row;
-//   phase B (wave 0): sum the 16 partials, form H_t (tauq, u scale, w = u^T A), update row t+1 with it and form
-//       G_{t+1} from the result -> v_{t+1}, tau_{t+1}.
+//   phase B (wave 0, with wave 1 working out H_t's tauq / u scale beside it -- handed over through an LDS flag, no
+//       barrier): sum the 16 partials, w = u^T A, update row t+1 with H_t and form G_{t+1} from the result
+//       -> v_{t+1}, tau_{t+1}.
 // Same reflectors as dgebd2; only the association of the sums differs (agreement with LAPACK ~1e-14).
 template <int NV, int NREG>
 __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const double* __restrict__ X, int m, int n,
@@ -1525,7 +1552,9 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
     __shared__ __attribute__((aligned(16))) double wpart[NW * NC];   // per-wave partials of column_t^T A
     __shared__ double sspart[NW];
     __shared__ double par[4];             // tau_t, tauq_{t-1}, u-scale_{t-1}, alpha of H_t
+    __shared__ int hready;                // = t + 1 once wave 1 has published H_t's parameters
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) hready = 0;
     // slot k of this lane holds column COL(k); column c sits in lane (c & 127) >> 1, slot (c & 1) + 2 (c >> 7)
 #define BASQ_COL(k) (2 * lane + ((k) & 1) + 128 * ((k) >> 1))
     double a[NG * 4][NV], cprev[NG * 4];
@@ -1632,22 +1661,71 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
         BASQ_NS_STAMP(t, 1);
         __syncthreads();
         BASQ_NS_STAMP(t, 2);
-        if (wv == 0) {   // ---- phase B ----
+        if (wv == 1) {   // ---- phase B, wave 1: H_t's parameters, concurrently with wave 0's partial-row sum ----
             double ss2 = 0.0;
 #pragma unroll
             for (int w = 0; w < NW; ++w) ss2 += sspart[w];
             double tauq, uscale;
-            BASQ_NS_STAMP(t, 4);
             householder_params_fast(par[3], ss2, tauq, uscale);
-            BASQ_NS_STAMP(t, 5);
+            if (lane == 0) {
+                par[1] = tauq;
+                par[2] = uscale;
+                __hip_atomic_store(&hready, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (wv == 0) {   // ---- phase B, wave 0 ----
+            BASQ_NS_STAMP(t, 4);
             double rn[NV], accs[NV];
 #pragma unroll
             for (int k = 0; k < NV; ++k) accs[k] = 0.0;
-#pragma unroll 8
-            for (int w = 0; w < NW; ++w) {       // 8 partial rows (16 x 16-byte reads) in flight per batch
+            // 16 partial rows x two 16-byte reads per lane.  Left to the compiler these become 32 serialised LDS round
+            // trips (the kernel sits at its VGPR ceiling, so every read reuses one register quad: ~2700 clocks of the
+            // ~5000 of this serial phase, tools/ns_prof.hip); issue them eight at a time instead.
+            static_assert(NV == 4, "the batched read below assumes two column pairs per lane");
+            {
+                typedef double d2_t __attribute__((ext_vector_type(2)));
+                const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double*)wpart +
+                                      (unsigned)lane * 16u;
 #pragma unroll
-                for (int k = 0; k < NV; ++k) accs[k] += wpart[w * NC + BASQ_COL(k)];
+                for (int w0 = 0; w0 < NW; w0 += 4) {
+                    d2_t v0, v1, v2, v3, v4, v5, v6, v7;
+                    asm volatile(
+                        "ds_read_b128 %0, %8 offset:%9\n\t"
+                        "ds_read_b128 %1, %8 offset:%10\n\t"
+                        "ds_read_b128 %2, %8 offset:%11\n\t"
+                        "ds_read_b128 %3, %8 offset:%12\n\t"
+                        "ds_read_b128 %4, %8 offset:%13\n\t"
+                        "ds_read_b128 %5, %8 offset:%14\n\t"
+                        "ds_read_b128 %6, %8 offset:%15\n\t"
+                        "ds_read_b128 %7, %8 offset:%16\n\t"
+                        "s_waitcnt lgkmcnt(0)"
+                        : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
+                        : "v"(base), "n"((w0 + 0) * NC * 8), "n"((w0 + 0) * NC * 8 + 1024), "n"((w0 + 1) * NC * 8),
+                          "n"((w0 + 1) * NC * 8 + 1024), "n"((w0 + 2) * NC * 8), "n"((w0 + 2) * NC * 8 + 1024),
+                          "n"((w0 + 3) * NC * 8), "n"((w0 + 3) * NC * 8 + 1024)
+                        : "memory");
+                    accs[0] += v0.x; accs[1] += v0.y; accs[2] += v1.x; accs[3] += v1.y;      // wave order 0..15 kept
+                    accs[0] += v2.x; accs[1] += v2.y; accs[2] += v3.x; accs[3] += v3.y;
+                    accs[0] += v4.x; accs[1] += v4.y; accs[2] += v5.x; accs[3] += v5.y;
+                    accs[0] += v6.x; accs[1] += v6.y; accs[2] += v7.x; accs[3] += v7.y;
+                }
             }
+            BASQ_NS_STAMP(t, 5);
+            {   // spin until wave 1 has published (it always gets there: same loop, same t).  One asm statement: a C++
+                // loop at this point makes the register allocator spill ~500 B per lane in the whole kernel.
+                int seen;
+                const unsigned faddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)&hready;
+                asm volatile(
+                    "BASQ_HREADY_SPIN_%=:\n\t"
+                    "ds_read_b32 %0, %1\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    "v_cmp_ne_u32_e32 vcc, %2, %0\n\t"
+                    "s_cbranch_vccnz BASQ_HREADY_SPIN_%="
+                    : "=&v"(seen)
+                    : "v"(faddr), "s"(t + 1)
+                    : "vcc", "memory");
+            }
+            const double tauq = par[1], uscale = par[2];
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 const int c = BASQ_COL(k);
@@ -1656,7 +1734,6 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
                 wsh[c] = wv_c;
                 rn[k] = r1 - tauq * wv_c;                                       // row t+1 after H_t
             }
-            if (lane == 0) { par[1] = tauq; par[2] = uscale; }
             BASQ_NS_STAMP(t, 6);
             make_right(rn, t + 1);
         }
@@ -1819,19 +1896,6 @@ __global__ void __launch_bounds__(1024) chol_inv_kernel(double* __restrict__ G, 
     }
 }
 
-// 1/sqrt(d) to ~1 ulp: v_rsq_f64 seed + three coupled Newton steps (g -> sqrt(d), h -> 1/(2 sqrt(d))).
-__device__ __forceinline__ double rsqrt_nr(double d) {
-    const double y = __builtin_amdgcn_rsq(d);
-    double g = d * y, h = 0.5 * y;
-#pragma unroll
-    for (int it = 0; it < 3; ++it) {
-        const double r = __builtin_fma(-h, g, 0.5);
-        g = __builtin_fma(g, r, g);
-        h = __builtin_fma(h, r, h);
-    }
-    return 2.0 * h;
-}
-
 // LDS-resident form of chol_inv_kernel for q*q doubles <= ~150 KB (q <= 136): the factor lives in LDS with an
 // odd leading dimension.  Cholesky: right-looking, column j scaled by a reciprocal square root (no sqrt + divide
 // chain), 2 barriers per column.  Inverse: with BLOCKED != 0 (a second q x q square fits in LDS, q <= 100)
@@ -1849,7 +1913,8 @@ __global__ void __launch_bounds__(1024) chol_inv_lds_kernel(double* __restrict__
     __shared__ double s_dmax;
     __shared__ int s_bad;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int e = tid; e < q * q; e += 1024) {
+    const int nt = blockDim.x, nwv = nt >> 6, rows_pp = nt >> 7;   // 256..1024 threads (BASQ_CHOL_THREADS)
+    for (int e = tid; e < q * q; e += nt) {
         const int i = e / q, k = e - i * q;
         Ls[i * ld + k] = G[e];
         W[e] = 0.0;
@@ -1863,7 +1928,7 @@ __global__ void __launch_bounds__(1024) chol_inv_lds_kernel(double* __restrict__
     __syncthreads();
     if (tid == 0) {
         double v = red[0];
-        for (int w = 1; w < 16; ++w) v = fmax(v, red[w]);
+        for (int w = 1; w < nwv; ++w) v = fmax(v, red[w]);
         s_dmax = v;
     }
     __syncthreads();
@@ -1878,8 +1943,8 @@ __global__ void __launch_bounds__(1024) chol_inv_lds_kernel(double* __restrict__
         double rpiv = 0.0;
         if (tid < q - j) {                                    // only the waves that hold column j do the pivot math
             rpiv = rsqrt_nr(d);
-            if (tid > 0) {
-                const int i = j + tid;
+            for (int i = j + tid; i < q; i += nt) {
+                if (i == j) continue;
                 const double v = Ls[i * ld + j] * rpiv;
                 colj[i] = v;
                 Ls[i * ld + j] = v;
@@ -1890,8 +1955,8 @@ __global__ void __launch_bounds__(1024) chol_inv_lds_kernel(double* __restrict__
             Ls[j * ld + j] = d * rpiv;
             colj[j] = rpiv;                                   // reciprocal diagonal, used by the inverse
         }
-        // trailing update, lower triangle: 8 rows x 128 columns per pass (no index division)
-        for (int a = j + 1 + (tid >> 7); a < q; a += 8) {
+        // trailing update, lower triangle: nt/128 rows x 128 columns per pass (no index division)
+        for (int a = j + 1 + (tid >> 7); a < q; a += rows_pp) {
             for (int b = j + 1 + (tid & 127); b <= a; b += 128) Ls[a * ld + b] -= colj[a] * colj[b];
         }
         __syncthreads();
@@ -1901,7 +1966,7 @@ __global__ void __launch_bounds__(1024) chol_inv_lds_kernel(double* __restrict__
     const int bad = s_bad;
     if (tid == 0) info[0] = bad;
     // write L back (lower triangle incl. diagonal; the strict upper triangle of G is left untouched)
-    for (int e = tid; e < q * q; e += 1024) {
+    for (int e = tid; e < q * q; e += nt) {
         const int i = e / q, k = e - i * q;
         if (k <= i) G[e] = Ls[i * ld + k];
     }
@@ -1913,8 +1978,7 @@ __global__ void __launch_bounds__(1024) chol_inv_lds_kernel(double* __restrict__
 #pragma unroll
         for (int k = 0; k < 5; ++k) bnd[k] = (k * q) / 4;
         // (1) diagonal blocks: thread c inverts its column inside its block
-        if (tid < q) {
-            const int c = tid;
+        for (int c = tid; c < q; c += nt) {
             int hi = q;
 #pragma unroll
             for (int k = 4; k >= 1; --k) if (c < bnd[k]) hi = bnd[k];
@@ -1944,7 +2008,7 @@ __global__ void __launch_bounds__(1024) chol_inv_lds_kernel(double* __restrict__
                     const int c1 = level == 0 ? bnd[2 * pr + 2] : bnd[4];
                     const int nA = c0 - a0, nC = c1 - c0;
                     if (nA <= 0 || nC <= 0) continue;
-                    for (int o = tid; o < nA * nC; o += 1024) {
+                    for (int o = tid; o < nA * nC; o += nt) {
                         const int rr = o / nA, cc = o - rr * nA;        // consecutive threads -> consecutive columns
                         const int r = c0 + rr, c = a0 + cc;
                         double acc0 = 0.0, acc1 = 0.0;
@@ -1974,17 +2038,16 @@ __global__ void __launch_bounds__(1024) chol_inv_lds_kernel(double* __restrict__
             }
         }
         // W = L^{-T}: W[c][i] = Y[i][c], i >= c (W was zeroed above)
-        for (int e = tid; e < q * q; e += 1024) {
+        for (int e = tid; e < q * q; e += nt) {
             const int i = e / q, c = e - i * q;
             if (c <= i) W[(long long)c * q + i] = Ys[i * ld + c];
         }
         BASQ_NS_STAMP(0, 3);
         return;
     }
-    if (tid >= q) return;
     // column c of Y = L^{-1} by forward substitution, kept in the (now free) upper triangle of Ls:
     // Y[i][c] (i >= c) is stored at Ls[c][i] for i > c (strictly upper), and its diagonal in a register.
-    const int c = tid;
+    for (int c = tid; c < q; c += nt) {
     double* wrow = W + (long long)c * q;
     const double* yrow = Ls + c * ld;
     const double ycc = colj[c];
@@ -2003,6 +2066,7 @@ __global__ void __launch_bounds__(1024) chol_inv_lds_kernel(double* __restrict__
         const double y = ((a0 + a1) + (a2 + a3)) * colj[i];
         Ls[c * ld + i] = y;                                   // row c, column i > c: strictly upper, owned by thread c
         wrow[i] = y;
+    }
     }
     BASQ_NS_STAMP(0, 3);
 }
@@ -2354,8 +2418,8 @@ int basq_chol_inv_f64(double* G, int32_t q, double* W, int32_t* info, double rel
         if (hipFuncSetAttribute((const void*)chol_inv_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
             return BASQ_ELAUNCH;
-        hipLaunchKernelGGL(chol_inv_lds_kernel, dim3(1), dim3(1024), lds, (hipStream_t)stream, G, q, W, info, rel_tol,
-                           blocked);
+        hipLaunchKernelGGL(chol_inv_lds_kernel, dim3(1), dim3(BASQ_CHOL_THREADS), lds, (hipStream_t)stream, G, q, W, info,
+                           rel_tol, blocked);
         BASQ_CHECK_LAUNCH();
         return BASQ_OK;
     }

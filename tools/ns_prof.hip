@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
     hipMemcpy(prof.data(), dprof, prof.size() * 8, hipMemcpyDeviceToHost);
     auto at = [&](int t, int slot, int w) { return prof[((size_t)t * 8 + slot) * 16 + w]; };
     printf("kernel span (wave 0): %lld clocks\n", at(m - 2, 3, 0) - at(0, 0, 0));
-    printf("  t   A(w0)  A(max)  bar1(w0)   B(w0)  bar2(w0)   step | B: ss2  lparams  sum16+w  right\n");
+    printf("  t   A(w0)  A(max)  bar1(w0)   B(w0)  bar2(w0)   step | B:  -    sum16   wait+w   right\n");
     for (int t = 0; t + 1 < m; t += (m > 20 ? m / 12 : 1)) {
         long long amax = 0;
         for (int w = 0; w < 16; ++w) {
