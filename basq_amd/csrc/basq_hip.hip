@@ -1747,32 +1747,41 @@ template <int NV>
 __global__ void __launch_bounds__(256) nullspace_apply_kernel(const double* __restrict__ V,
                                                               const double* __restrict__ tau, int m, int n,
                                                               double* __restrict__ PhiT) {
+    constexpr int PF = 4;                                 // reflector rows in flight (L2 latency ~ one reduction each)
     const int lane = threadIdx.x & 63;
     const int c0 = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c0 >= n - m) return;                              // wave-uniform
-    double y[NV], v[NV], vn[NV];
+    double y[NV], v[PF][NV], tv[PF];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        const int c = lane + 64 * k;
-        y[k] = (c == m + c0) ? 1.0 : 0.0;
-        v[k] = (c < n) ? V[(size_t)(m - 1) * n + c] : 0.0;
-    }
-    for (int i = m - 1; i >= 0; --i) {
-        const int inext = (i > 0) ? i - 1 : 0;
+    for (int k = 0; k < NV; ++k) y[k] = (lane + 64 * k == m + c0) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {                    // prefetch the next reflector behind the reduction
-            const int c = lane + 64 * k;
-            vn[k] = (c < n) ? V[(size_t)inext * n + c] : 0.0;
-        }
-        double dot = 0.0;
-#pragma unroll
-        for (int k = 0; k < NV; ++k) dot += v[k] * y[k];
-        dot = wave_sum(dot);
-        const double t = tau[i] * dot;
+    for (int p = 0; p < PF; ++p) {
+        const int i = m - 1 - p;
+        tv[p] = (i >= 0) ? tau[i] : 0.0;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            y[k] -= t * v[k];
-            v[k] = vn[k];
+            const int c = lane + 64 * k;
+            v[p][k] = (i >= 0 && c < n) ? V[(size_t)i * n + c] : 0.0;
+        }
+    }
+    for (int i0 = m - 1; i0 >= 0; i0 -= PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {                    // static ring slot p holds row i0 - p
+            const int i = i0 - p;
+            if (i < 0) break;                             // wave-uniform
+            double dot = 0.0;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) dot += v[p][k] * y[k];
+            dot = wave_sum(dot);
+            const double t = tv[p] * dot;
+            const int inext = i - PF;                     // refill the slot behind the reduction
+            tv[p] = (inext >= 0) ? tau[inext] : 0.0;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int c = lane + 64 * k;
+                y[k] -= t * v[p][k];
+                v[p][k] = (inext >= 0 && c < n) ? V[(size_t)inext * n + c] : 0.0;
+            }
         }
     }
 #pragma unroll
