@@ -7,6 +7,7 @@ Public surface (mirrors the reference's names):
     KernelQuadrature(...).rchq / .quadrature
     kernels.StationaryKernel / PosteriorKernel / WsabiKernel / from_gpytorch_model
     GaussianCalc(prior, device).unimodal_approximation / uniform_transformation
+    SquareRootAcquisitionFunction / PriorSampler / UncertaintySampler(prior, model, n_rec, nys_ratio, device, ...)
     sober.recombination(pts_rec, pts_nys, num_pts, kernel, device, dtype, init_weights)   (SOBER/_rchq.py flavour)
 
 Importing the package does not touch the GPU; the HIP library is loaded on first use and its
@@ -17,8 +18,8 @@ from ._basq import BASQ, KernelQuadrature                      # noqa: F401
 from ._engine import EngineTrace                               # noqa: F401
 from ._acquisition_function import SquareRootAcquisitionFunction   # noqa: F401
 from ._gaussian_calc import GaussianCalc                       # noqa: F401
-from ._sampler import PriorSampler                             # noqa: F401
+from ._sampler import PriorSampler, UncertaintySampler         # noqa: F401
 from ._rchq import recombination, recombination_sharded        # noqa: F401
 
-__all__ = ["recombination", "recombination_sharded", "BASQ", "KernelQuadrature", "GaussianCalc", "SquareRootAcquisitionFunction", "PriorSampler", "EngineTrace", "kernels",
+__all__ = ["recombination", "recombination_sharded", "BASQ", "KernelQuadrature", "GaussianCalc", "SquareRootAcquisitionFunction", "PriorSampler", "UncertaintySampler", "EngineTrace", "kernels",
            "pools", "sober"]

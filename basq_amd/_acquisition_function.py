@@ -60,14 +60,20 @@ class SquareRootAcquisitionFunction(GaussianCalc):
             return first
         return first + mixture_pdf(ops, x, self.mu_AA, self.wAA, self.sigma_AA)
 
+    def _mvn_draw(self, loc, cov, count):
+        """``MultivariateNormal(loc, cov).sample([count])`` drawn from the CPU global generator (as the reference
+        does when it runs on the CPU -- same shapes, same order, so ``torch.manual_seed`` reproduces its samples),
+        then moved to the device."""
+        mvn = MultivariateNormal(loc.detach().to("cpu", torch.float64), cov.detach().to("cpu", torch.float64))
+        return mvn.sample(torch.Size([int(count)])).to(self.Xobs.device)
+
     def sampling(self, n):                                                     # :99-120
         cntA = (n * self.wA).type(torch.int)
         samplesA = self.prior.sample(torch.Size([int(cntA)])).to(self.Xobs.device)
         if len(self.wAA) == 0:
             return samplesA
-        cntAA = (n * self.wAA).type(torch.int)
-        samplesAA = torch.cat([MultivariateNormal(self.mu_AA[i], self.sigma_AA).sample(torch.Size([int(cnt)]))
-                               for i, cnt in enumerate(cntAA)])
+        cntAA = (n * self.wAA).type(torch.int).tolist()
+        samplesAA = torch.cat([self._mvn_draw(self.mu_AA[i], self.sigma_AA, cnt) for i, cnt in enumerate(cntAA)])
         return torch.cat([samplesA.to(samplesAA.dtype), samplesAA])
 
     def sparseGMM_mean(self):                                                  # :122-165
@@ -99,6 +105,5 @@ class SquareRootAcquisitionFunction(GaussianCalc):
         return mixture_pdf(self._get_ops(), x, self.mu_mean, self.w_mean, self.sig_mean)
 
     def sampling_mean(self, n):                                                # :190-206
-        cnts = (n * self.w_mean).type(torch.int)
-        return torch.cat([MultivariateNormal(self.mu_mean[i], self.sig_mean).sample(torch.Size([int(cnt)]))
-                          for i, cnt in enumerate(cnts)])
+        cnts = (n * self.w_mean).type(torch.int).tolist()
+        return torch.cat([self._mvn_draw(self.mu_mean[i], self.sig_mean, cnt) for i, cnt in enumerate(cnts)])

@@ -159,3 +159,27 @@ def synthetic_gp_state(Xobs: torch.Tensor, base: StationaryOracle, noise: float,
     W = torch.cholesky_inverse(L)
     mean_cache = W @ (y - mean_const)
     return W, mean_const, mean_cache, y
+
+
+def predict_oracle(test_x: torch.Tensor, model):
+    """``predict(test_x, model)`` -- ``BASQ/_gp.py:213-230``: ``(pred.mean, pred.variance)`` of
+    ``model.likelihood(model(test_x))`` for an exact GP with a constant mean and a ``ScaleKernel(RBF)``:
+
+        mean = c + k(x, X) mean_cache,   var = s2 - diag(k(x, X) W k(X, x)) + noise,   W = S S^T (covar_cache)
+
+    ``model`` is duck-typed like the stub of ``oracle/make_golden_sampler.py`` (same attributes the reference reads
+    at ``_gp.py:233-256`` / ``_gaussian_calc.py:44-51`` plus ``mean_module.constant`` and ``likelihood.noise``).
+    Deviation, stated: the reference evaluates the variance under ``gpytorch.settings.fast_pred_var()`` (LOVE, a
+    low-rank approximation inside gpytorch, which is not installed here); this is the exact variance.  Parity
+    unpinned at the gpytorch boundary, as for the kernels above.
+    """
+    Xobs = model.train_inputs[0]
+    ls = float(model.covar_module.base_kernel.lengthscale.reshape(-1)[0])
+    s2 = float(model.covar_module.outputscale)
+    base = StationaryOracle("rbf", ls, s2)
+    S = model.prediction_strategy.covar_cache
+    W = S @ S.T
+    KxX = base(test_x, Xobs)
+    mean = float(model.mean_module.constant) + KxX @ model.prediction_strategy.mean_cache
+    var = s2 - ((KxX @ W) * KxX).sum(1) + float(model.likelihood.noise)
+    return mean, var
