@@ -310,7 +310,7 @@ class RecombinationEngine:
 
     # ------------------------------------------------------------------------------------------------
     def run(self, pts_local, gid0: int, n_total: int, pts_nys, num_pts: int, kernel, trace: EngineTrace | None = None,
-            variant: str = "basq", init_weights=None):
+            variant: str = "basq", init_weights=None, objective=None):
         """Recombine.  ``pts_local`` = this rank's contiguous slice ``[gid0, gid0 + len)`` of the pool.
 
         ``variant="basq"`` follows ``BASQ/_rchq.py`` (uniform start weights, ``init_weights`` ignored);
@@ -318,6 +318,10 @@ class RecombinationEngine:
         are honoured and zero-weight points dropped, the Nystrom Gram goes through ``make_cov_psd``, the ragged
         remainder is additionally added to sets ``0..N_rest-1`` (:127-135), and an elimination that finds no
         positive entry stops early instead of failing (:240-242).
+
+        ``objective`` (sober only): ``-calc_obj(pts_rec)`` (``SOBER/_rchq.py:67-69``), one value per local candidate.
+        The reference can only execute its objective branch when the pool fits a single reduction (``:77-104``); for
+        larger pools it raises at ``:140-142`` -- and so does this engine.
 
         Returns ``(idx int64[<=num_pts] ascending, w float64)`` on the ops device (identical on every rank).
         """
@@ -375,6 +379,15 @@ class RecombinationEngine:
         if warp != "none":
             wx = kernel.mean(ops, pts_local, center) if Rl > 0 else ops.empty(1)
         off, R = gid0, n_total
+        obj_full = obj_live = None
+        if objective is not None:
+            if not sober:
+                raise ValueError("an objective is part of the SOBER variant only")
+            if comm.world > 1 or post is not None or warp != "none":
+                raise NotImplementedError("objective row: single process, stationary kernels only")
+            obj_full = obj_live = ops.to_device(objective, torch.float64).reshape(-1)
+            if obj_full.shape[0] != Rl:
+                raise ValueError("objective must have one entry per candidate")
         if sober and init_weights is not None:
             # SOBER/_rchq.py:60-64: start from the given weights, drop the zero-weight points up front
             w0 = ops.to_device(init_weights, torch.float64)
@@ -382,6 +395,8 @@ class RecombinationEngine:
                 raise ValueError("init_weights must have one entry per local candidate")
             nz = torch.nonzero(w0 != 0).reshape(-1)
             cand, mu, gid = cand[nz].contiguous(), w0[nz].contiguous(), gid[:Rl][nz].contiguous()
+            if obj_live is not None:
+                obj_live = obj_live[nz].contiguous()
             if wx is not None:
                 wx = wx[nz].contiguous()
             if cand_raw is not None:
@@ -458,6 +473,10 @@ class RecombinationEngine:
                 idx, w = gids[keep], mus[keep]
                 break
             final = R <= S                                       # :65-74 single reduction of the points
+            if obj_full is not None and not final:
+                raise RuntimeError("recombination with an objective needs a pool of at most 2 * num_pts points: the "
+                                   "reference fails here too (SOBER/_rchq.py:140-142 adds a [S, 1] sum in place to a "
+                                   "[1, S] buffer)")
             S_r = R if final else S
             geo = RoundGeometry.of(R, S_r)
             t0 = time.perf_counter()
@@ -495,6 +514,11 @@ class RecombinationEngine:
                     ops.synchronize()
                 trace.add_time("blocksum+project", time.perf_counter() - t0)
                 t0 = time.perf_counter()
+            if obj_full is not None:
+                # SOBER/_rchq.py:78-104: one more feature per point, its objective (here still weighted by mu, like
+                # every other message row); the reduction then keeps q + 2 points and the thinning removes one more
+                idx, w = self._reduce_with_objective(msg, obj_live, obj_full, gid, mu, Rl, R, q, trace)
+                break
             parts = comm.all_gather(msg) if comm.world > 1 else msg.unsqueeze(0)
             M = S_r
             if comm.rank == 0:
@@ -571,6 +595,51 @@ class RecombinationEngine:
         return idx, w
 
     # ------------------------------------------------------------------------------------------------
+    def _reduce_with_objective(self, msg, obj_live, obj_full, gid, mu, Rl, R, q, trace):
+        """Single reduction with an objective row (``SOBER/_rchq.py:77-111``), one process.
+
+        ``msg`` = ``[tot ; U @ block sums]`` of the R points (one set each).  The Caratheodory step runs on
+        ``[1 ; features ; objective]`` (q + 2 rows); then, among the kept points, the weights move along the null vector
+        of ``[features ; 1]`` -- oriented so that the weighted objective does not decrease -- until one more reaches
+        zero (``:87-104``).  That last step is k <= q + 2 numbers: host LAPACK, as in the reference.
+        """
+        ops = self.ops
+        obj_row = (obj_live[:Rl] * mu[:Rl]).reshape(1, -1)
+        parts = torch.cat([msg[:q + 1], obj_row], 0).unsqueeze(0).contiguous()
+        XcarT, tot = ops.finalize(parts, 1, q + 2, q + 1, R, None, 0, 0, 0.0, 0)
+        s_car = q + 2
+        if R > s_car:
+            PhiT = ops.nullspace(XcarT, s_car, R)
+            _, kept, w_star, info = ops.car_eliminate(PhiT, tot.clone(), R, s_car)
+            head = ops.to_host(torch.cat([info, kept]), "head")
+            n_keep = int(head[0])
+            kept_pos = torch.tensor([int(v) for v in head[2:2 + n_keep]], dtype=torch.int64)
+            w_host = ops.to_host(w_star[:n_keep], "wobj").clone()
+        else:                                                    # nothing to eliminate (V[-0:] is the whole of V, :235)
+            w_host = ops.to_host(tot, "wobj").clone()
+            live = w_host > 0
+            kept_pos = torch.arange(R, dtype=torch.int64)[live]
+            w_host = w_host[live]
+        F = XcarT[1:q + 1].cpu()[:, kept_pos]                     # features of the kept points, without the objective
+        obj_p = obj_full.cpu()[kept_pos]                          # (sic) :89 indexes the objective by POSITION
+        A = torch.cat([F, torch.ones(1, len(kept_pos), dtype=torch.float64)], 0)
+        with _lapack_threads(HOST_SVD_THREADS):
+            direction = torch.linalg.svd(A)[2][-1]
+        if torch.dot(obj_p, direction) < 0:
+            direction = -direction
+        pos = direction > 0
+        ratio = torch.zeros(len(w_host), dtype=torch.float64)
+        ratio[pos] = w_host[pos] / direction[pos]
+        hit = torch.arange(len(w_host))[pos][torch.argmin(ratio[pos])]
+        w_host = w_host - ratio[hit] * direction
+        w_host[hit] = 0.0
+        sel = w_host > 0
+        kept_pos, w_host = kept_pos[sel], w_host[sel]
+        if trace is not None:
+            trace.rounds.append(dict(R=R, S=R, nb=1, n_tail=0, kept=[int(v) for v in kept_pos]))
+        gids = gid[:Rl]
+        return gids[kept_pos.to(gids.device)], ops.to_device(w_host)
+
     def _wsabim_square_term(self, base, spec, pts_nys, Xo, Bmat, center, cand_raw, mu, Rl, off, n_full, S, m,
                             chunk_bytes=256 << 20):
         """E[j, s] = 0.5 * sum_{p in set s} mu_p * cov(pt_j, x_p)^2  with cov = k - K(pt,X) W K(X, x)  (_wsabi.py:240).

@@ -8,7 +8,9 @@ reference files: importance weights are honoured (zero-weight candidates are dro
 through ``make_cov_psd``, the ragged remainder of every round is additionally added to sets ``0..N_rest-1``,
 and an elimination that runs out of positive entries stops early.  ``dtype`` is accepted for signature
 compatibility; arithmetic is float64 (the reference's default, ``SOBER/_settings.py:11``).  ``calc_obj`` (the
-optional objective row, ``SOBER/_rchq.py:66-68``) is not built: passing one raises.
+optional objective row, ``SOBER/_rchq.py:66-69``) is honoured exactly as far as the reference can execute it: for
+pools of at most ``2 * num_pts`` points (its single-reduction branch, ``:77-111``).  For larger pools the reference
+raises at ``:140-142`` (shape error in its own objective sums) and this entry raises ``RuntimeError`` as well.
 """
 from __future__ import annotations
 
@@ -21,9 +23,8 @@ from ._rchq import _require_structured
 
 def recombination(pts_rec, pts_nys, num_pts, kernel, device, dtype=torch.float64, init_weights=None, calc_obj=None, *,
                   trace: EngineTrace | None = None):
-    if calc_obj is not None:
-        raise NotImplementedError("calc_obj (objective-aware recombination, SOBER/_rchq.py:66-68) is not built")
     _require_structured(kernel)
     eng = RecombinationEngine(HipOps(device), LocalComm())
+    objective = None if calc_obj is None else -1 * calc_obj(pts_rec)            # :67-69
     return eng.run(pts_rec, 0, pts_rec.shape[0], pts_nys, int(num_pts), kernel, trace, variant="sober",
-                   init_weights=init_weights)
+                   init_weights=init_weights, objective=objective)

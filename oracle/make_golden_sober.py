@@ -12,7 +12,24 @@ CASES = [
     dict(name="sober_is_ragged", N=12_345, d=7, m=123, n=37, family="rbf", lengthscale=1.5, pool_seed=3, weights="is"),
     dict(name="sober_zeros_matern", N=5_000, d=3, m=64, n=30, family="matern52", lengthscale=2.0, pool_seed=3, weights="zeros"),
     dict(name="sober_tiny_final", N=150, d=3, m=100, n=100, family="rbf", lengthscale=2.0, pool_seed=5, weights="is"),
+    # with an objective row (calc_obj, SOBER/_rchq.py:14, :67-69, :78-104).  Only the single-reduction branch
+    # (N <= 2n) can be pinned: for larger pools the reference itself raises at :140-142 (a [S,1] sum is added in
+    # place to a [1,S] buffer), see tests/test_sober.py::test_reference_objective_branch_fails_for_large_pools.
+    dict(name="sober_obj_tiny_final", N=150, d=3, m=100, n=100, family="rbf", lengthscale=2.0, pool_seed=5, weights="is",
+         objective="bump"),
 ]
+
+
+def case_objective(c):
+    """``calc_obj`` of the case, or None.  Only correctly rounded IEEE operations (no libm): bit-reproducible."""
+    if c.get("objective", "none") == "none":
+        return None
+
+    def bump(X):
+        d = X.shape[1]
+        return 1.0 / (1.0 + (X * X).sum(1) / d) + 0.125 * X[:, 0]
+
+    return bump
 
 
 def case_weights(c):
@@ -46,7 +63,7 @@ def main():
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             idx, w = sober_recombination(pts, pts[:c["m"]], c["n"], k, torch.device("cpu"), torch.float64,
-                                         init_weights=None if w0 is None else w0.clone())
+                                         init_weights=None if w0 is None else w0.clone(), calc_obj=case_objective(c))
         out.append(dict(case=c, pool_digest=pool_digest(pts), idx=[int(v) for v in idx], w=[float(v) for v in w]))
         print(c["name"], len(idx), float(w.sum()))
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "sober.json")

@@ -266,9 +266,36 @@ def caratheodory_reduce_sober(X, mu):
     return mu[keep], torch.arange(M)[keep]
 
 
-def divide_and_recombine_sober(samp, U, pt, kernel, mu=None, trace: Trace | None = None):
-    """``Mod_Tchernychova_Lyons`` of SOBER (:53-219) without an objective.  ``kernel`` must accept a batched
-    second argument ``[nb, S, d]`` (gpytorch semantics) -> ``[nb, m, S]``."""
+def objective_thinning(feat_cols, obj_vals, w):
+    """The extra elimination SOBER applies when an objective is given (:87-104 and :183-200): among the points the
+    Caratheodory step kept, move along the null vector of ``[features; 1]`` in the direction that does not decrease
+    ``sum w_i obj_i`` until one more weight reaches zero.
+
+    ``feat_cols [q, k]`` (features of the kept points, WITHOUT the objective row), ``obj_vals [k]``, ``w [k]`` ->
+    ``(w_new [k'], keep [k'] positions into the k inputs)``.  The direction is the last row of the full ``Vh`` of
+    ``svd([feat_cols; 1])``, as in the reference (a null vector when k = q + 2, the generic case).
+    """
+    k = feat_cols.shape[1]
+    A = torch.cat((feat_cols, torch.ones(1, k)), 0)
+    direction = torch.linalg.svd(A)[2][-1]
+    if torch.dot(obj_vals, direction) < 0:
+        direction = -direction
+    pos = direction > 0
+    ratio = torch.zeros(len(w))
+    ratio[pos] = w[pos] / direction[pos]
+    cand = torch.arange(len(w))[pos]
+    hit = cand[torch.argmin(ratio[pos])]
+    w = w - ratio[hit] * direction
+    w[hit] = 0.0
+    keep = torch.arange(k)[w > 0]
+    return w[w > 0], keep
+
+
+def divide_and_recombine_sober(samp, U, pt, kernel, mu=None, trace: Trace | None = None, obj=None):
+    """``Mod_Tchernychova_Lyons`` of SOBER (:53-219).  ``kernel`` must accept a batched second argument
+    ``[nb, S, d]`` (gpytorch semantics) -> ``[nb, m, S]``.  ``obj`` = ``-calc_obj(samp)`` (:67-69) or None: with an
+    objective every set carries one more feature (its weighted objective sum, :139-147, :158-160), the reduction
+    keeps q + 2 sets and ``objective_thinning`` removes one more."""
     N = len(samp)
     q, m = U.shape
     S = 2 * (q + 1)
@@ -282,7 +309,12 @@ def divide_and_recombine_sober(samp, U, pt, kernel, mu=None, trace: Trace | None
             return mu[sel], sel
         if R <= S:
             F = U @ kernel(pt, samp[live])
+            if obj is not None:
+                F = torch.cat((F, obj[live].reshape(1, -1)), 0)
             w, keep = caratheodory_reduce_sober(F.T, torch.clone(mu[live]))
+            if obj is not None:
+                w, sub = objective_thinning(F[:-1][:, keep], obj[keep], w)      # (sic) obj indexed by position, :89
+                keep = keep[sub]
             live = live[keep]
             mu[:] = 0.0
             mu[live] = w
@@ -293,19 +325,35 @@ def divide_and_recombine_sober(samp, U, pt, kernel, mu=None, trace: Trace | None
         acc = torch.zeros(m, S)
         acc += K.sum(axis=0)
         n_rest = len(live) - nb * S
+        rest = live[nb * S: nb * S + n_rest]
         if n_rest > 0:                                                          # :127-135 (first count)
-            rest = live[nb * S: nb * S + n_rest]
             Kr = kernel(pt, samp[rest]) * mu[rest].unsqueeze(0)
             acc += torch.cat((Kr, torch.zeros(m, S - n_rest)), dim=1)
-        feat = (U @ acc).T
+        feat_t = U @ acc
+        if obj is not None:                                                     # :137-147
+            orow = torch.zeros(1, S)
+            orow += (obj[grid].unsqueeze(1) * mu[grid].unsqueeze(1)).sum(axis=0).reshape(-1, 1)
+            if n_rest > 0:
+                tail_obj = (obj[rest].unsqueeze(0) * mu[rest].unsqueeze(0)).reshape(-1, 1)
+                orow += torch.cat((tail_obj, torch.zeros(S - n_rest, 1)), dim=0)
+            feat_t = torch.cat((feat_t, orow), 0)
+        feat = feat_t.T
         tot = torch.sum(mu[grid], 0)
         tail = live[nb * S:]
         if len(tail):                                                           # :155-166 (second count)
             Ft = U @ kernel(pt, samp[tail])
+            if obj is not None:
+                Ft = torch.cat((Ft, obj[tail].reshape(1, -1)), 0)
             feat[-1] += torch.multiply(Ft.T, mu[tail].unsqueeze(1)).sum(axis=0)
             tot[-1] += torch.sum(mu[tail], 0)
         feat = torch.divide(feat, tot.unsqueeze(0).T)
+        if obj is not None:
+            feat_raw = torch.clone(feat[:, :q])
+            obj_sets = feat[:, -1:].reshape(-1)
         w, keep = caratheodory_reduce_sober(feat, torch.clone(tot))
+        if obj is not None:                                                     # :183-200
+            w, sub = objective_thinning(feat_raw[keep].T, obj_sets[keep], w)
+            keep = keep[sub]
         if trace is not None:
             trace.rounds.append(RoundTrace(R, nb, len(tail), kept_sets=keep.clone(), kept_weights=w.clone()))
         survivors = grid[:, keep].reshape(-1)
@@ -325,11 +373,13 @@ def divide_and_recombine_sober(samp, U, pt, kernel, mu=None, trace: Trace | None
         R = len(live)
 
 
-def recombination_sober_oracle(pts_rec, pts_nys, num_pts, kernel, init_weights=None, trace: Trace | None = None):
-    """``SOBER/_rchq.py:recombination`` (:6-31) with ``calc_obj=None`` -> ``(idx, w)``."""
+def recombination_sober_oracle(pts_rec, pts_nys, num_pts, kernel, init_weights=None, trace: Trace | None = None,
+                               calc_obj=None):
+    """``SOBER/_rchq.py:recombination`` (:6-31) -> ``(idx, w)``; ``calc_obj`` as there (a callable on the pool)."""
     mat = make_cov_psd_sober(kernel(pts_nys, pts_nys))                          # :35-36
     Uq, _, _ = torch.svd_lowrank(mat, q=num_pts - 1)                            # :37
     U = -1 * Uq.T
     mu = None if init_weights is None else init_weights.clone()
-    w, idx = divide_and_recombine_sober(pts_rec, U, pts_nys, kernel, mu, trace)
+    obj = None if calc_obj is None else -1 * calc_obj(pts_rec)                  # :67-69
+    w, idx = divide_and_recombine_sober(pts_rec, U, pts_nys, kernel, mu, trace, obj)
     return idx, w
