@@ -64,11 +64,17 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # BASQ_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL group, sharded entry, collectives) even with one
+    # rank -- the only way to exercise it on a 1-GPU box; never set by the driver.
+    force_dist = os.environ.get("BASQ_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        t_init = time.perf_counter()
         dist.init_process_group("nccl", device_id=dev)
+        if rank == 0:
+            print(f"[bench] RCCL group of {world} up in {time.perf_counter() - t_init:.1f} s", file=sys.stderr)
 
     import basq_amd
     from basq_amd._partition import initial_shards
@@ -86,7 +92,7 @@ def main():
 
     def one_batch(trace=None):
         torch.manual_seed(1)                                         # manual_seed(1) before each call
-        if world == 1:
+        if world == 1 and not force_dist:
             return basq_amd.recombination(pool_dev, pts_nys, n, kern, dev, trace=trace)
         return basq_amd.recombination_sharded(pts_local, off, N, pts_nys, n, kern, dev, trace=trace)
 
