@@ -92,19 +92,19 @@ class EngineTrace:
 class _Timer:
     """Host timer feeding ``EngineTrace.timers`` (synchronising only when the trace asks for it)."""
 
-    def __init__(self, ops, trace, key):
-        self.ops, self.trace, self.key = ops, trace, key
+    def __init__(self, ops, trace, key, sync=True):
+        self.ops, self.trace, self.key, self.sync = ops, trace, key, sync
 
     def __enter__(self):
         if self.trace is not None:
-            if self.trace.host_sync:
+            if self.sync and self.trace.host_sync:
                 self.ops.synchronize()
             self.t0 = time.perf_counter()
         return self
 
     def __exit__(self, *exc):
         if self.trace is not None:
-            if self.trace.host_sync:
+            if self.sync and self.trace.host_sync:
                 self.ops.synchronize()
             self.trace.add_time(self.key, time.perf_counter() - self.t0)
         return False
@@ -182,22 +182,50 @@ def _cholqr(ops, X, flags, passes=2):
     return X
 
 
-def _gaussian_test_matrix(ops, m, q):
+def _gaussian_test_matrix(ops, m, q, trace=None):
     """``R = torch.randn(m, q)`` of ``torch._lowrank.get_approximate_basis`` with the reference's RNG consumption.
 
     torch's CPU ``normal_`` first fills the tensor with mt19937 uniforms and then applies Box-Muller in blocks of
     16 (scalar libm, ~12 ms for 1e4 x 99).  ``torch.rand`` makes exactly the same draws (the generator ends in
-    the same state: ``test_rand_consumes_like_randn``), so only the uniforms are produced on the host and the
-    transform runs on the GPU; values agree with ``torch.randn`` to 1 ulp (device vs host libm), far inside the
-    stability margin of the selection.
+    the same state: ``test_rand_consumes_like_randn``), so only the uniforms are produced on the host -- straight
+    into the pinned staging buffer, no intermediate allocation -- and the transform runs on the GPU; values agree
+    with ``torch.randn`` to 1 ulp (device vs host libm), far inside the stability margin of the selection.
     """
     n = m * q
     if n < 16:
         return ops.to_device(torch.randn(m, q, dtype=torch.float64))
-    u = torch.rand(n, dtype=torch.float64)                       # CPU global generator
-    ut = torch.rand(16, dtype=torch.float64) if n % 16 else None
-    R = ops.box_muller(ops.from_host(u, "rand_u"), None if ut is None else ops.from_host(ut, "rand_ut"))
+    with _Timer(ops, trace, "basis.rand_host", sync=False):
+        u = ops.host_uniform(n, "rand_u")                        # CPU global generator
+        ut = ops.host_uniform(16, "rand_ut") if n % 16 else None
+    with _Timer(ops, trace, "basis.rand_h2d", sync=False):
+        R = ops.box_muller(ops.from_pinned(u), None if ut is None else ops.from_pinned(ut))
     return R.view(m, q)
+
+
+LATE_CHUNKS = 1                  # chunks of the round-1 block sums deferred behind the range finder (0 = none)
+
+
+def _late_split(off: int, Rl: int, n_full: int, S: int, n_chunks: int, n_late: int):
+    """Local position at which the round-1 block sums can be cut into two launches with UNCHANGED chunk boundaries
+    (``basq_blocksum_f64`` splits the block range evenly: chunk c = blocks ``[lo + c*per, lo + (c+1)*per)``), or None.
+
+    The first launch takes chunks ``0 .. n_chunks-n_late-1``, the second the rest (incl. the ragged tail, which
+    belongs to the last chunk).  Both launches recompute ``per`` from their own ranges: the cut is only taken when
+    they arrive at the same value, so that every partial sum is bit-identical to the single-launch result.
+    """
+    if n_late < 1 or n_chunks < 4 or n_late >= n_chunks:
+        return None
+    lim = min(off + Rl, n_full)
+    if lim <= off:
+        return None
+    lo, hi = off // S, -(-lim // S)
+    per = max(1, -(-(hi - lo) // n_chunks))
+    c_a = n_chunks - n_late
+    rest = (hi - lo) - c_a * per
+    if rest < 1 or max(1, -(-rest // n_late)) != per:
+        return None
+    p = (lo + c_a * per) * S - off
+    return p if 0 < p < Rl else None
 
 
 # The GPU range finder may be switched off (tests compare both paths).
@@ -207,7 +235,7 @@ GPU_RANGE_FINDER = True
 GPU_NULLSPACE = True
 
 
-def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None):
+def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None, overlap=None):
     """``ker_svd_sparsify`` (``BASQ/_rchq.py:28-31``): ``-svd_lowrank(A, q)[0].T`` -> ``[min(q,m), m]``.
 
     Restates ``torch._lowrank.get_approximate_basis`` / ``_svd_lowrank`` (torch 2.10, niter=2, square A so
@@ -221,10 +249,14 @@ def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None):
     the ``[k, m]`` SVD by an LQ reduction on the GPU + a ``k x k`` SVD on the host.  If a Cholesky pivot
     signals a numerically rank-deficient panel (cond > ~1e6) the whole basis is recomputed with host
     Householder QR, from the same Gaussian draw.
+
+    ``overlap``: optional callable that enqueues independent GPU work; it is called once, right after the copy of
+    the small ``L`` factor to the host has been enqueued, so that work runs while the host does the ``k x k`` SVD
+    (otherwise ~1 ms of GPU idle time per batch).
     """
     m = A.shape[0]
     with _Timer(ops, trace, "basis.randn"):
-        R = _gaussian_test_matrix(ops, m, q_req)
+        R = _gaussian_test_matrix(ops, m, q_req, trace)
     At = A.t()
     if GPU_RANGE_FINDER and q_req <= m:
         with _Timer(ops, trace, "basis.gpu_range"):
@@ -243,9 +275,15 @@ def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None):
             _, i2 = ops.chol_inv(G2)
             L = ops.matmul(torch.tril(G1), torch.tril(G2))
             bad = torch.stack([f.reshape(()) for f in flags + [i1, i2]]).max()
+            k = L.shape[0]
+            both, ready = ops.to_host_async(torch.cat([L.reshape(-1), bad.to(torch.float64).reshape(1)]), "basisL")
+        if overlap is not None:
+            overlap()
+            overlap = None
         with _Timer(ops, trace, "basis.host_svd"):
-            Lh = L.cpu()                                       # one synchronisation for the whole range finder
-            ok = int(bad.item()) == 0
+            ready.synchronize()                                # one wait for the whole range finder
+            Lh = both[:k * k].reshape(k, k)
+            ok = int(both[k * k].item()) == 0
             if ok:
                 with _lapack_threads(HOST_SVD_THREADS):
                     Ub = torch.linalg.svd(Lh)[0]
@@ -255,6 +293,8 @@ def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None):
                 return (-1 * U.t()).contiguous()               # :30
         if trace is not None:
             trace.timers["basis.fallback"] = trace.timers.get("basis.fallback", 0) + 1
+    if overlap is not None:
+        overlap()
     with _Timer(ops, trace, "basis.gemm"):
         X = ops.matmul(A, R)
     Q = _host_qr_q(ops, X, trace)
@@ -413,14 +453,29 @@ class RecombinationEngine:
         # ---- round-1 block sums are queued BEFORE the basis: they do not depend on U, and the ~12 ms CPU
         #      randn of the range finder then overlaps with the largest kernel of the batch ----------------
         pre = None
+        late = None                                             # deferred part of the round-1 block sums
         if R > S:
             geo = RoundGeometry.of(R, S)
             n_chunks = choose_chunks(local_blocks(off, Rl, geo), m_ext, S, kp // 4)
-            ev0 = ops.record_event() if (trace is not None and trace.time_kernels) else None
-            Xpart, totpart = ops.blocksum(spec, nys_ext, m_ext, cand, mu, wx, Rl, off, geo.n_full, S, n_chunks)
-            if ev0 is not None:
-                trace.kernel_events.append((ev0, ops.record_event(), dict(pairs=float(Rl) * m_ext, R=Rl, m=m_ext, S=S,
-                                                                         chunks=n_chunks)))
+            Xpart, totpart = ops.empty(n_chunks, m_ext, S), ops.empty(n_chunks, S)
+
+            def launch(c_lo, c_hi, p_lo, p_hi):
+                ev0 = ops.record_event() if (trace is not None and trace.time_kernels) else None
+                ops.blocksum(spec, nys_ext, m_ext, cand[p_lo:], mu[p_lo:], None if wx is None else wx[p_lo:], p_hi - p_lo,
+                             off + p_lo, geo.n_full, S, c_hi - c_lo, out=(Xpart[c_lo:c_hi], totpart[c_lo:c_hi]))
+                if ev0 is not None:
+                    trace.kernel_events.append((ev0, ops.record_event(), dict(pairs=float(p_hi - p_lo) * m_ext,
+                                                                             R=p_hi - p_lo, m=m_ext, S=S,
+                                                                             chunks=c_hi - c_lo)))
+
+            p_split = _late_split(off, Rl, geo.n_full, S, n_chunks, LATE_CHUNKS) if Rl > 0 else None
+            if p_split is None:
+                launch(0, n_chunks, 0, Rl)
+            else:
+                # the last chunk(s) are launched behind the range finder's GPU work: they run while the host does the
+                # k x k SVD of the basis (~1 ms during which the GPU would idle); same chunk boundaries, same sums
+                launch(0, n_chunks - LATE_CHUNKS, 0, p_split)
+                late = lambda: launch(n_chunks - LATE_CHUNKS, n_chunks, p_split, Rl)      # noqa: E731
             pre = (Xpart, totpart, n_chunks)
 
         # ---- Nystrom basis: rank 0 computes, everyone receives (one randn draw, as in the reference) ----
@@ -429,11 +484,13 @@ class RecombinationEngine:
                 A = kernel.dense(ops, pts_nys, pts_nys, center)
                 if sober:
                     A = _make_cov_psd(A)
-            U = nystrom_basis(ops, A, num_pts - 1, trace)
+            U = nystrom_basis(ops, A, num_pts - 1, trace, overlap=late)
             del A
             assert U.shape[0] == q
         else:
             U = ops.empty(q, m)
+            if late is not None:
+                late()                                          # runs while rank 0 finishes the basis
         if comm.world > 1:
             comm.broadcast(U)
         if trace is not None:
@@ -548,15 +605,20 @@ class RecombinationEngine:
                     res[2 + 3 * M:] = tot
                 comm.broadcast(res)
                 head = ops.to_host(res[:2 + M], "head")
-                n_keep, status = int(head[0]), int(head[1])
-                kept_list = [int(v) for v in head[2:2 + n_keep]]
+                hl = head.tolist()                               # one conversion (iterating a tensor costs ~1 us/element)
+                n_keep, status = int(hl[0]), int(hl[1])
+                kept_list = [int(v) for v in hl[2:2 + n_keep]]
                 w_star = res[2 + M:2 + 2 * M].contiguous()
                 keep_rank = res[2 + 2 * M:2 + 3 * M].to(torch.int32)
                 tot = res[2 + 3 * M:].contiguous()
             else:
-                head = ops.to_host(torch.cat([info, kept]), "head")     # one D2H for status + survivor list
-                n_keep, status = int(head[0]), int(head[1])
-                kept_list = [int(v) for v in head[2:2 + n_keep]]
+                base = getattr(info, "_base", None)              # HipOps hands out views of one [info | kept] buffer
+                both = base if (base is not None and base.numel() == info.numel() + kept.numel()) \
+                    else torch.cat([info, kept])
+                head = ops.to_host(both, "head")                 # one D2H for status + survivor list
+                hl = head.tolist()
+                n_keep, status = hl[0], hl[1]
+                kept_list = hl[2:2 + n_keep]
             if status != 0 and not sober:
                 raise RuntimeError("Caratheodory elimination: a null vector has no positive entry "
                                    "(the reference fails here too: argmin of an empty tensor, _rchq.py:152)")
@@ -612,8 +674,9 @@ class RecombinationEngine:
             PhiT = ops.nullspace(XcarT, s_car, R)
             _, kept, w_star, info = ops.car_eliminate(PhiT, tot.clone(), R, s_car)
             head = ops.to_host(torch.cat([info, kept]), "head")
-            n_keep = int(head[0])
-            kept_pos = torch.tensor([int(v) for v in head[2:2 + n_keep]], dtype=torch.int64)
+            hl = head.tolist()
+            n_keep = hl[0]
+            kept_pos = torch.tensor(hl[2:2 + n_keep], dtype=torch.int64)
             w_host = ops.to_host(w_star[:n_keep], "wobj").clone()
         else:                                                    # nothing to eliminate (V[-0:] is the whole of V, :235)
             w_host = ops.to_host(tot, "wobj").clone()

@@ -102,9 +102,15 @@ class HipOps:
                                               _ptr(out), self._stream()), "basq_kernel_matvec_f64")
         return out
 
-    def blocksum(self, spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, impl="mfma"):
-        Xpart = self.empty(n_chunks, m, S)
-        totpart = self.empty(n_chunks, S)
+    def blocksum(self, spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, impl="mfma", out=None):
+        """``out = (Xpart [n_chunks, m, S], totpart [n_chunks, S])``: write into caller-provided (contiguous) slices."""
+        if out is None:
+            Xpart = self.empty(n_chunks, m, S)
+            totpart = self.empty(n_chunks, S)
+        else:
+            Xpart, totpart = out
+            assert Xpart.is_contiguous() and totpart.is_contiguous()
+            assert tuple(Xpart.shape) == (n_chunks, m, S) and tuple(totpart.shape) == (n_chunks, S)
         if Rl == 0:
             Xpart.zero_()
             totpart.zero_()
@@ -234,6 +240,24 @@ class HipOps:
         buf.copy_(t, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
         return buf
+
+    def to_host_async(self, t, tag="d2h"):
+        """Device -> pinned host tensor, enqueued on the current stream WITHOUT waiting: returns ``(buf, event)``;
+        ``event.synchronize()`` makes ``buf`` valid.  Work enqueued afterwards overlaps with the host's use of it."""
+        buf = self._pinned(t.shape, t.dtype, tag)
+        buf.copy_(t, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return buf, ev
+
+    def host_uniform(self, n, tag):
+        """``torch.rand(n, float64)`` from the CPU global generator, written straight into a cached pinned buffer."""
+        buf = self._pinned((n,), torch.float64, tag)
+        return torch.rand(n, dtype=torch.float64, out=buf)
+
+    def from_pinned(self, buf):
+        """Pinned host tensor -> device (asynchronous on the current stream)."""
+        return buf.to(self.device, non_blocking=True)
 
     def from_host(self, t, tag="h2d"):
         """Host tensor -> device through a pinned staging buffer (asynchronous on the current stream)."""

@@ -60,6 +60,11 @@ def householder_nullspace(X):
     return torch.from_numpy(np.ascontiguousarray(N.T))
 
 
+class _DoneEvent:
+    def synchronize(self):
+        pass
+
+
 class CpuStandInOps:
     name = "cpu-stand-in"
 
@@ -121,11 +126,15 @@ class CpuStandInOps:
         self._count("matvec")
         return bias + spec.outputscale * (self._kfun(spec, packA[:na] @ packB[:nb].T) @ v)
 
-    def blocksum(self, spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks):
+    def blocksum(self, spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, out=None):
         self._count("blocksum")
         Xpart = torch.zeros(n_chunks, m, S, dtype=torch.float64)
         totpart = torch.zeros(n_chunks, S, dtype=torch.float64)
         if Rl == 0:
+            if out is not None:
+                out[0].copy_(Xpart)
+                out[1].copy_(totpart)
+                return out
             return Xpart, totpart
         pg = off + torch.arange(Rl)
         sets = torch.where(pg < n_full, pg % S, torch.full_like(pg, S - 1))
@@ -149,6 +158,10 @@ class CpuStandInOps:
         tf = torch.zeros(n_chunks * S, dtype=torch.float64)
         tf.index_add_(0, flat, mu[:Rl])
         totpart = tf.reshape(n_chunks, S)
+        if out is not None:
+            out[0].copy_(Xpart)
+            out[1].copy_(totpart)
+            return out
         return Xpart, totpart
 
     def project(self, U, q, m, Xpart, totpart, n_chunks, S, outputscale, ksplit=None):
@@ -276,8 +289,17 @@ class CpuStandInOps:
     def to_host(self, t, tag="d2h"):
         return t
 
+    def to_host_async(self, t, tag="d2h"):
+        return t, _DoneEvent()
+
     def from_host(self, t, tag="h2d"):
         return t.contiguous()
+
+    def host_uniform(self, n, tag):
+        return torch.rand(n, dtype=torch.float64)
+
+    def from_pinned(self, buf):
+        return buf
 
     def synchronize(self):
         pass

@@ -52,6 +52,34 @@ def test_choose_chunks_bounds():
     assert local_blocks(0, 1000, geo) == 5 and local_blocks(150, 300, geo) == 3 and local_blocks(1000, 0, geo) == 0
 
 
+@pytest.mark.parametrize("off,Rl,n_full,S,n_chunks", [(0, 10_000, 10_000, 200, 10), (0, 10_077, 10_000, 200, 10),
+                                                      (0, 9_800, 9_800, 200, 7), (350, 4_000, 9_800, 200, 5),
+                                                      (0, 1_000, 1_000, 200, 4), (0, 5_000, 5_000, 200, 3)])
+def test_late_split_keeps_chunk_boundaries(off, Rl, n_full, S, n_chunks):
+    """Cutting the round-1 block sums into two launches (the second one deferred behind the range finder) must not
+    move any chunk boundary: the partial sums have to be bit-identical to the single launch's."""
+    from basq_amd._engine import _late_split
+    from basq_amd.kernels import StationaryKernel
+
+    ops = CpuStandInOps()
+    spec = StationaryKernel("rbf", 1.5, 1.0).spec(3)
+    g = torch.Generator().manual_seed(off + Rl)
+    nys = ops.pack(spec, torch.randn(20, 3, generator=g, dtype=torch.float64), torch.zeros(3, dtype=torch.float64), 0)
+    cand = ops.pack(spec, torch.randn(Rl, 3, generator=g, dtype=torch.float64), torch.zeros(3, dtype=torch.float64), 1)
+    mu = torch.rand(Rl, generator=g, dtype=torch.float64)
+    X1, t1 = ops.blocksum(spec, nys, 20, cand, mu, None, Rl, off, n_full, S, n_chunks)
+    p = _late_split(off, Rl, n_full, S, n_chunks, 1)
+    if n_chunks < 4:
+        assert p is None
+        return
+    if p is None:                                                   # uneven ranges may refuse the cut; never wrong
+        return
+    X2, t2 = torch.empty_like(X1), torch.empty_like(t1)
+    ops.blocksum(spec, nys, 20, cand, mu, None, p, off, n_full, S, n_chunks - 1, out=(X2[:-1], t2[:-1]))
+    ops.blocksum(spec, nys, 20, cand[p:], mu[p:], None, Rl - p, off + p, n_full, S, 1, out=(X2[-1:], t2[-1:]))
+    assert torch.equal(X1, X2) and torch.equal(t1, t2)
+
+
 @pytest.mark.parametrize("name", ENGINE_CASES)
 def test_engine_host_logic_reproduces_golden(name):
     """Fused formulation (block sums -> contraction -> reduction -> closed-form compaction, posterior and
