@@ -34,7 +34,8 @@ from dataclasses import dataclass, field
 import torch
 
 from ._lib import ROLE_A, ROLE_B
-from ._partition import RoundGeometry, choose_chunks, local_blocks, next_shard, survivors_before
+from ._partition import (RoundGeometry, choose_chunks, initial_shards, local_blocks, next_shard,
+                         survivors_before)
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -202,6 +203,7 @@ def _gaussian_test_matrix(ops, m, q, trace=None):
     return R.view(m, q)
 
 
+SHARDED_BASIS = True             # multi-rank: split the range finder's Gram products over the ranks (False: rank 0 only)
 LATE_CHUNKS = 1                  # chunks of the round-1 block sums deferred behind the range finder (0 = none)
 
 
@@ -235,6 +237,70 @@ GPU_RANGE_FINDER = True
 GPU_NULLSPACE = True
 
 
+class _DenseProducts:
+    """The Nystrom Gram matrix ``A`` resident on this GPU: the three products of the range finder as library GEMMs."""
+
+    def __init__(self, ops, A):
+        self.ops, self.A, self.At, self.m = ops, A, A.t(), A.shape[0]
+
+    def draw(self, q, trace):
+        return _gaussian_test_matrix(self.ops, self.m, q, trace)
+
+    def a(self, Q):
+        return _mm_splitk(self.ops, self.A, Q)
+
+    def at(self, Q):
+        return _mm_splitk(self.ops, self.At, Q)
+
+    def qta(self, Q):
+        return _mm_splitk(self.ops, Q.t(), self.A)
+
+    def full(self):
+        return self.A
+
+
+class _ShardedProducts:
+    """Rows ``[r0, r0 + mr)`` of ``A`` on this rank (multi-GPU, SURVEY 8e: the range finder no longer idles W-1 GPUs).
+
+    ``A`` is a kernel Gram matrix -- symmetric up to the rounding of its entries -- so ``A^T Q`` and ``(Q^T A)^T`` are
+    computed as ``A Q`` as well: every product is ``A_rows @ Q`` on each rank followed by ONE all-gather of the
+    ``[mr, q]`` blocks (1 MB per rank at the headline size), after which all ranks hold the same ``[m, q]`` matrix and
+    run the small replicated steps (CholeskyQR, LQ, the q x q host SVD) identically.  Only rank 0 consumes the RNG: the
+    Gaussian test matrix is broadcast.  The deviation from the single-GPU arithmetic (A for A^T) is at rounding
+    level, far inside the stability margin of the selection (SURVEY finding 3); the gloo tests pin the indices.
+    """
+
+    def __init__(self, ops, comm, A_rows, shards, m):
+        self.ops, self.comm, self.rows, self.shards, self.m = ops, comm, A_rows, shards, m
+        self.mb = max(n for _, n in shards)
+
+    def draw(self, q, trace):
+        if self.comm.rank == 0:
+            R = _gaussian_test_matrix(self.ops, self.m, q, trace).contiguous()
+        else:
+            R = self.ops.empty(self.m, q)
+        return self.comm.broadcast(R)
+
+    def a(self, Q):
+        mr = self.rows.shape[0]
+        blk = self.ops.zeros(self.mb, Q.shape[1])
+        if mr:
+            blk[:mr] = _mm_splitk(self.ops, self.rows, Q, 64)
+        g = self.comm.all_gather(blk)                            # [W, mb, q]
+        return torch.cat([g[r, :n] for r, (_, n) in enumerate(self.shards)], 0)
+
+    at = a
+
+    def qta(self, Q):
+        return self.a(Q).t().contiguous()
+
+    def full(self):
+        blk = self.ops.zeros(self.mb, self.m)
+        blk[:self.rows.shape[0]] = self.rows
+        g = self.comm.all_gather(blk)
+        return torch.cat([g[r, :n] for r, (_, n) in enumerate(self.shards)], 0)
+
+
 def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None, overlap=None):
     """``ker_svd_sparsify`` (``BASQ/_rchq.py:28-31``): ``-svd_lowrank(A, q)[0].T`` -> ``[min(q,m), m]``.
 
@@ -250,23 +316,24 @@ def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None, overlap=
     signals a numerically rank-deficient panel (cond > ~1e6) the whole basis is recomputed with host
     Householder QR, from the same Gaussian draw.
 
+    ``A``: the Gram matrix (a tensor) or a products object (``_DenseProducts`` / ``_ShardedProducts``).
     ``overlap``: optional callable that enqueues independent GPU work; it is called once, right after the copy of
     the small ``L`` factor to the host has been enqueued, so that work runs while the host does the ``k x k`` SVD
     (otherwise ~1 ms of GPU idle time per batch).
     """
-    m = A.shape[0]
+    prod = _DenseProducts(ops, A) if torch.is_tensor(A) else A
+    m = prod.m
     with _Timer(ops, trace, "basis.randn"):
-        R = _gaussian_test_matrix(ops, m, q_req, trace)
-    At = A.t()
+        R = prod.draw(q_req, trace)
     if GPU_RANGE_FINDER and q_req <= m:
         with _Timer(ops, trace, "basis.gpu_range"):
             flags = []
-            Q = _cholqr(ops, _mm_splitk(ops, A, R), flags, passes=1)
-            Q = _cholqr(ops, _mm_splitk(ops, At, Q), flags, passes=1)
-            Q = _cholqr(ops, _mm_splitk(ops, A, Q), flags, passes=1)
-            Q = _cholqr(ops, _mm_splitk(ops, At, Q), flags, passes=1)
-            Q = _cholqr(ops, _mm_splitk(ops, A, Q), flags, passes=2)      # the basis that is actually used
-            B = _mm_splitk(ops, Q.t(), A)                      # [k, m]
+            Q = _cholqr(ops, prod.a(R), flags, passes=1)
+            Q = _cholqr(ops, prod.at(Q), flags, passes=1)
+            Q = _cholqr(ops, prod.a(Q), flags, passes=1)
+            Q = _cholqr(ops, prod.at(Q), flags, passes=1)
+            Q = _cholqr(ops, prod.a(Q), flags, passes=2)         # the basis that is actually used
+            B = prod.qta(Q)                                    # [k, m]
             # LQ of B (CholeskyQR2 on its rows):  B = L1 L2 Qb^T  ->  left singular vectors of B = those of L
             G1 = _mm_splitk(ops, B, B.t(), 32)
             W1, i1 = ops.chol_inv(G1)
@@ -295,6 +362,8 @@ def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None, overlap=
             trace.timers["basis.fallback"] = trace.timers.get("basis.fallback", 0) + 1
     if overlap is not None:
         overlap()
+    A = prod.full()                                            # (sharded: gathered -- the rare path)
+    At = A.t()
     with _Timer(ops, trace, "basis.gemm"):
         X = ops.matmul(A, R)
     Q = _host_qr_q(ops, X, trace)
@@ -479,20 +548,30 @@ class RecombinationEngine:
             pre = (Xpart, totpart, n_chunks)
 
         # ---- Nystrom basis: rank 0 computes, everyone receives (one randn draw, as in the reference) ----
-        if comm.rank == 0:
+        if SHARDED_BASIS and comm.world > 1 and not sober:
+            # every rank builds its row block of the Gram matrix and takes part in the range finder (no broadcast of U)
+            shards = initial_shards(m, comm.world)
+            r0, mr = shards[comm.rank]
             with _Timer(ops, trace, "basis.gram"):
-                A = kernel.dense(ops, pts_nys, pts_nys, center)
-                if sober:
-                    A = _make_cov_psd(A)
-            U = nystrom_basis(ops, A, num_pts - 1, trace, overlap=late)
-            del A
-            assert U.shape[0] == q
+                A_rows = kernel.dense(ops, pts_nys[r0:r0 + mr].contiguous(), pts_nys, center, diag_offset=r0) \
+                    if mr else ops.zeros(0, m)
+            U = nystrom_basis(ops, _ShardedProducts(ops, comm, A_rows, shards, m), num_pts - 1, trace, overlap=late)
+            del A_rows
         else:
-            U = ops.empty(q, m)
-            if late is not None:
-                late()                                          # runs while rank 0 finishes the basis
-        if comm.world > 1:
-            comm.broadcast(U)
+            if comm.rank == 0:
+                with _Timer(ops, trace, "basis.gram"):
+                    A = kernel.dense(ops, pts_nys, pts_nys, center)
+                    if sober:
+                        A = _make_cov_psd(A)
+                U = nystrom_basis(ops, A, num_pts - 1, trace, overlap=late)
+                del A
+                assert U.shape[0] == q
+            else:
+                U = ops.empty(q, m)
+                if late is not None:
+                    late()                                      # runs while rank 0 finishes the basis
+            if comm.world > 1:
+                comm.broadcast(U)
         if trace is not None:
             if trace.host_sync:
                 ops.synchronize()

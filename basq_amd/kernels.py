@@ -59,7 +59,9 @@ class StationaryKernel:
             raise ValueError(f"dimension {d} outside 1..{MAX_DIM}")
         return KernelSpec(self.family, int(d), self.lengthscale, self.outputscale)
 
-    def dense(self, ops, x, y, center=None):
+    def dense(self, ops, x, y, center=None, diag_offset=0):
+        """``diag_offset``: ``x`` is rows ``diag_offset..`` of the first operand of a square block (the structured
+        kernels add their diagonal terms on the TRUE diagonal then); no effect for a stationary kernel."""
         spec = self.spec(x.shape[1])
         if center is None:
             center = ops.col_mean(x)          # gpytorch centres on the first operand
@@ -96,7 +98,7 @@ class PosteriorKernel:
     def posterior(self):
         return self
 
-    def dense(self, ops, x, y, center=None):
+    def dense(self, ops, x, y, center=None, diag_offset=0):
         Xo = ops.to_device(self.Xobs, torch.float64)
         W = ops.to_device(self.W, torch.float64)
         if center is None:
@@ -105,8 +107,9 @@ class PosteriorKernel:
         KxX = self.base.dense(ops, x, Xo, center)
         KXy = self.base.dense(ops, Xo, y, center)
         cov = cov - KxX @ W @ KXy
-        k = min(x.shape[0], y.shape[0])
-        cov.diagonal()[:k] += self.noise                      # _gp.py:275-276
+        k = min(x.shape[0], y.shape[0] - diag_offset)
+        if k > 0:
+            cov.diagonal(diag_offset)[:k] += self.noise       # _gp.py:275-276
         return cov
 
     def __call__(self, x, y):
@@ -168,15 +171,16 @@ class WsabiKernel:
         pb = ops.pack(spec, Xo, center, ROLE_B)
         return ops.matvec(spec, pa, x.shape[0], pb, Xo.shape[0], v, self.mean_const)
 
-    def dense(self, ops, x, y, center=None):
+    def dense(self, ops, x, y, center=None, diag_offset=0):
         if center is None:
             center = ops.col_mean(x)
-        cov = self.posterior.dense(ops, x, y, center)
+        cov = self.posterior.dense(ops, x, y, center, diag_offset)
         out = self.mean(ops, x, center).unsqueeze(1) * cov * self.mean(ops, y, center).unsqueeze(0)
         if self.warp == "wsabim":
             out = out + 0.5 * cov * cov
-        k = min(x.shape[0], y.shape[0])
-        out.diagonal()[:k] += self.jitter
+        k = min(x.shape[0], y.shape[0] - diag_offset)
+        if k > 0:
+            out.diagonal(diag_offset)[:k] += self.jitter
         return out
 
     def __call__(self, x, y):

@@ -112,3 +112,59 @@ def test_sharded_sober_variant_matches_golden(i, world):
     for rank, idx, w in res:
         assert idx == fx["idx"], f"rank {rank}"
         assert ((torch.tensor(w, dtype=torch.float64) - gw).abs() / gw).max().item() <= 1e-6
+
+
+def _basis_worker(rank, world, port, name, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from basq_amd._engine import TorchDistComm, _ShardedProducts, nystrom_basis
+        from basq_amd._partition import initial_shards
+        from tests.cpu_stand_in import CpuStandInOps
+
+        c = BY_NAME[name]
+        _, nys = build_pool(c)
+        ops, comm = CpuStandInOps(), TorchDistComm()
+        kern = build_product_kernel(c)
+        center = ops.col_mean(nys)
+        shards = initial_shards(c["m"], world)
+        r0, mr = shards[rank]
+        rows = kern.dense(ops, nys[r0:r0 + mr].contiguous(), nys, center, diag_offset=r0)
+        torch.manual_seed(7 if rank == 0 else 99)
+        U = nystrom_basis(ops, _ShardedProducts(ops, comm, rows, shards, c["m"]), c["n"] - 1)
+        full = kern.dense(ops, nys, nys, center)
+        q.put((rank, U, (rows - full[r0:r0 + mr]).abs().max().item()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("cfg1_posterior_1e4", 2), ("wsabil_2e4", 3)])
+def test_sharded_range_finder_equals_dense(name, world):
+    """Row-sharded Gram products (+ the symmetry A ~ A^T) give the same Nystrom basis as the single-process range
+    finder, up to the sign of each row and rounding; the row blocks carry the structured kernels' diagonal terms on the
+    true diagonal (``diag_offset``); every rank ends up with the same basis; only rank 0's generator is consumed."""
+    from basq_amd._engine import nystrom_basis
+    from tests.cpu_stand_in import CpuStandInOps
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_basis_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+    c = BY_NAME[name]
+    _, nys = build_pool(c)
+    ops = CpuStandInOps()
+    kern = build_product_kernel(c)
+    torch.manual_seed(7)
+    Ud = nystrom_basis(ops, kern.dense(ops, nys, nys, ops.col_mean(nys)), c["n"] - 1)
+    for rank, U, blk_err in res:
+        assert blk_err == 0.0                                   # same entries as the full Gram, diagonal terms included
+        assert torch.equal(U, res[0][1])                        # replicated steps agree bit for bit across ranks
+        sign = torch.sign((U * Ud).sum(1, keepdim=True))
+        assert (U * sign - Ud).abs().max().item() <= 1e-7

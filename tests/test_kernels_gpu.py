@@ -350,3 +350,60 @@ def test_box_muller_vs_torch_randn(hip_ops, n):
     ut = torch.rand(16, dtype=torch.float64) if n % 16 else None
     out = hip_ops.box_muller(hip_ops.to_device(u), None if ut is None else hip_ops.to_device(ut)).cpu()
     assert (out - ref).abs().max().item() <= 1e-14
+
+
+def test_sharded_products_on_device(hip_ops):
+    """The row-sharded range finder's device code (split-K batched GEMM on a row block, padded all-gather layout)
+    against the dense range finder, on one GPU: a loop-back communicator that plays both ranks of a 2-rank group."""
+    import basq_amd._engine as E
+    from basq_amd.kernels import StationaryKernel
+    from basq_amd.pools import gmm_pool
+
+    m, q = 1000, 99
+    nys = hip_ops.to_device(gmm_pool(m, 10, 3))
+    kern = StationaryKernel("rbf", 2.0)
+    center = hip_ops.col_mean(nys)
+    A = kern.dense(hip_ops, nys, nys, center)
+    shards = [(0, 501), (501, 499)]
+
+    class LoopBack:
+        """all_gather answers with what the OTHER emulated rank would have contributed, computed right here."""
+        rank, world = 0, 2
+
+        def __init__(self):
+            self.other = None
+
+        def broadcast(self, t, src=0):
+            return t
+
+        def all_gather(self, blk):
+            return torch.stack([blk, self.other(blk)], 0)
+
+    comm = LoopBack()
+    prod = E._ShardedProducts(hip_ops, comm, A[:501].contiguous(), shards, m)
+    state = {}
+    orig_a = prod.a
+
+    def a(Q):
+        state["Q"] = Q
+        return orig_a(Q)
+
+    def other(blk):
+        out = torch.zeros_like(blk)
+        if blk.shape[1] == m:                                     # full(): the row block itself
+            out[:499] = A[501:]
+        else:
+            out[:499] = E._mm_splitk(hip_ops, A[501:].contiguous(), state["Q"], 64)
+        return out
+
+    comm.other = other
+    prod.a = a
+    prod.at = a
+    prod.qta = lambda Q: a(Q).t().contiguous()
+    torch.manual_seed(5)
+    Us = E.nystrom_basis(hip_ops, prod, q)
+    torch.manual_seed(5)
+    Ud = E.nystrom_basis(hip_ops, A, q)
+    sign = torch.sign((Us * Ud).sum(1, keepdim=True))
+    assert (Us * sign - Ud).abs().max().item() <= 1e-7
+    assert torch.equal(prod.full(), A)
