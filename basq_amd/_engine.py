@@ -203,6 +203,9 @@ def _gaussian_test_matrix(ops, m, q, trace=None):
     return R.view(m, q)
 
 
+# Multi-rank: every rank reduces the gathered message itself (the kernels sum in a fixed order, so all ranks obtain
+# the same survivors bit for bit) instead of rank 0 reducing and broadcasting the result: one collective less per round.
+REPLICATED_REDUCTION = True
 SHARDED_BASIS = True             # multi-rank: split the range finder's Gram products over the ranks (False: rank 0 only)
 LATE_CHUNKS = 1                  # chunks of the round-1 block sums deferred behind the range finder (0 = none)
 
@@ -657,7 +660,8 @@ class RecombinationEngine:
                 break
             parts = comm.all_gather(msg) if comm.world > 1 else msg.unsqueeze(0)
             M = S_r
-            if comm.rank == 0:
+            replicate = REPLICATED_REDUCTION and comm.world > 1
+            if comm.rank == 0 or replicate:
                 XcarT, tot = ops.finalize(parts, comm.world, q_ext + 1, q, S_r, diagU, m, min(m, S_r), diag_noise, wrow)
                 if GPU_NULLSPACE:
                     with _Timer(ops, trace, "nullspace"):
@@ -673,7 +677,7 @@ class RecombinationEngine:
                 mu_car = tot.clone()
                 with _Timer(ops, trace, "eliminate"):
                     keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, mu_car, M, s)
-            if comm.world > 1:
+            if comm.world > 1 and not replicate:
                 # one broadcast of the (tiny) reduction result: info | kept | w_star | keep_rank | tot
                 res = ops.empty(2 + 4 * M)
                 if comm.rank == 0:

@@ -46,13 +46,18 @@ def _sober_worker(rank, world, port, i, q):
         dist.destroy_process_group()
 
 
-def _worker(rank, world, port, name, q):
+def _worker(rank, world, port, name, q, rank0_only=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        import basq_amd._engine as E
         from basq_amd._engine import EngineTrace, RecombinationEngine, TorchDistComm
+
+        if rank0_only:                                          # basis + per-round reduction on rank 0, results broadcast
+            E.SHARDED_BASIS = False
+            E.REPLICATED_REDUCTION = False
         from basq_amd._partition import initial_shards
         from tests.cpu_stand_in import CpuStandInOps
 
@@ -68,14 +73,19 @@ def _worker(rank, world, port, name, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,world", [("rbf_ragged", 2), ("rbf_1e4", 2), ("cfg1_posterior_1e4", 2), ("wsabil_2e4", 2),
-                                        ("rbf_ragged", 3), ("rbf_tiny_final", 2), ("wsabim_1e4", 2)])
-def test_sharded_engine_matches_golden(name, world):
+@pytest.mark.parametrize("name,world,rank0_only", [("rbf_ragged", 2, False), ("rbf_1e4", 2, False),
+                                                   ("cfg1_posterior_1e4", 2, False), ("wsabil_2e4", 2, False),
+                                                   ("rbf_ragged", 3, False), ("rbf_tiny_final", 2, False),
+                                                   ("wsabim_1e4", 2, False), ("rbf_ragged", 3, True),
+                                                   ("cfg1_posterior_1e4", 2, True)])
+def test_sharded_engine_matches_golden(name, world, rank0_only):
+    """Default multi-rank mode (sharded range finder, reduction replicated on every rank) and the rank-0-only mode
+    (basis and reduction on rank 0, results broadcast): same indices as the reference either way."""
     fx = load_golden(name)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q, rank0_only)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
