@@ -1110,13 +1110,16 @@ __global__ void __launch_bounds__(1024) car_eliminate_kernel(double* __restrict_
     if (tid == 0) { info[0] = total; info[1] = status; }
 }
 
-// LDS-resident form (used when (M-s)*M + M doubles fit in 160 KB, e.g. M = 200, s = 100): identical arithmetic
-// and pivot rule, but the null-space rows never leave the CU and a step costs two barriers:
+// LDS-resident form (used when (M-s)*M doubles fit in 160 KB, e.g. M = 200, s = 100): identical arithmetic and
+// pivot rule, but the null-space rows never leave the CU and a step costs ONE barrier:
 //   * ratio test: wave minimum by DPP (min is exact, so any association gives the reference's value), first
-//     lane holding it by ballot; the per-wave winners go through LDS and EVERY wave scans them (no second
-//     reduction stage);
+//     lane holding it by ballot; the per-wave winners (value, index, reciprocal of the pivot entry -- one IEEE
+//     divide per step instead of one per thread) go through LDS and EVERY wave scans them;
 //   * an eliminated column is remembered in a per-thread flag instead of being zeroed (:167-171 zero it only so
-//     that it is never chosen again): Phi[:, j] is then read-only during the rank-1 update and needs no staging.
+//     that it is never chosen again): Phi[:, j] is then read-only during the rank-1 update and needs no staging;
+//   * software pipeline: thread (column i, row group 0) updates row k+1 FIRST and, holding the fresh entry and its
+//     own weight in registers, runs the ratio test of step k+1 at once -- concurrently with the other waves'
+//     updates of rows k+2.. -- so the test is off the critical path; weights never touch memory.
 __device__ __forceinline__ double wave_min_f64(double v) {
     const double INF = __builtin_huge_val();
     v = fmin(v, dpp_shift_fill_f64<0x111, 0xf>(v, INF));      // row_shr 1, 2, 4, 8: running minima inside rows of 16
@@ -1136,8 +1139,8 @@ __global__ void __launch_bounds__(1024) car_eliminate_lds_kernel(const double* _
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int nrows = M - s;
     double* Phi = sm;                          // [nrows][M]
-    double* mu = sm + (size_t)nrows * M;       // [M]
-    __shared__ double red_v[2][16];            // double-buffered by step parity: one barrier between write and scan
+    __shared__ double red_v[2][16];            // per-wave winners, double-buffered by step parity
+    __shared__ double red_r[2][16];            // 1 / phi of each wave's winner (the pivot's reciprocal, computed once)
     __shared__ int red_i[2][16];
     __shared__ int wave_cnt[16];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -1145,57 +1148,99 @@ __global__ void __launch_bounds__(1024) car_eliminate_lds_kernel(const double* _
     const int nwv_act = (M + 63) >> 6;              // waves that own a column (tid < M)
     const double INF = __builtin_huge_val();
     for (int e = tid; e < nrows * M; e += nt) Phi[e] = PhiT_g[e];
-    if (tid < M) mu[tid] = mu_g[tid];
+    double mu_r = (tid < M) ? mu_g[tid] : 0.0;      // weight of column tid: only this thread ever touches it
     int status = 0;
     const int rows_per_pass = nt / M > 0 ? nt / M : 1;   // M <= nt is guaranteed by the launcher
-    const int my_i = tid % M, my_r = tid / M;
+    const int my_i = tid % M, my_r = tid / M;       // tid < M  <=>  my_r == 0 and my_i == tid
     const bool upd = my_r < rows_per_pass;
-    bool dead_col = false;                          // column tid (ratio test)
-    bool dead_upd = false;                          // column my_i (update pass)
+    bool dead = false;                              // column my_i has been eliminated
+    __syncthreads();
+    // ratio test on (phi = entry of the current null vector in column tid, mu_r): publishes this wave's winner
+    auto ratio_test = [&](double phi, int parity) {
+        const bool pos = (tid < M) && !dead && (phi > 0.0);
+        const double av = pos ? (mu_r / phi) : INF;
+        const double rphi = pos ? (1.0 / phi) : 0.0;     // second, independent divide: shares the latency of the first
+        const double wmin = wave_min_f64(av);
+        const unsigned long long hit = __ballot(pos && av == wmin);   // first-index argmin (torch.argmin, :152)
+        const int first = hit ? (int)__builtin_ctzll(hit) : 0;
+        if (lane == first) {
+            red_v[parity][wv] = wmin;
+            red_r[parity][wv] = rphi;
+            red_i[parity][wv] = hit ? (wv * 64 + first) : 0x7fffffff;
+        }
+    };
+    if (nrows > 0 && wv < nwv_act) ratio_test((tid < M) ? Phi[tid] : 0.0, 0);
     __syncthreads();
     for (int k = 0; k < nrows; ++k) {
         const double* col = Phi + (size_t)k * M;
         const int pb = k & 1;
-        if (wv < nwv_act) {
-            const double phi = (tid < M) ? col[tid] : 0.0;
-            const bool pos = (tid < M) && !dead_col && (phi > 0.0);
-            const double av = pos ? (mu[tid] / phi) : INF;
-            const double wmin = wave_min_f64(av);
-            const unsigned long long hit = __ballot(pos && av == wmin);   // first-index argmin (torch.argmin, :152)
-            if (lane == 0) {
-                red_v[pb][wv] = wmin;
-                red_i[pb][wv] = hit ? (wv * 64 + (int)__builtin_ctzll(hit)) : 0x7fffffff;
+        BASQ_NS_STAMP(k, 0);
+        // every wave scans the (<= 16) per-wave winners: lower wave wins ties
+        double aj = INF, rphij = 0.0;
+        int j = 0x7fffffff;
+        if (nwv_act <= 4) {                             // M <= 256: all loads in flight at once
+            const double v0 = red_v[pb][0], v1 = red_v[pb][1], v2 = red_v[pb][2], v3 = red_v[pb][3];
+            const double r0 = red_r[pb][0], r1 = red_r[pb][1], r2 = red_r[pb][2], r3 = red_r[pb][3];
+            const int i0 = red_i[pb][0], i1 = red_i[pb][1], i2 = red_i[pb][2], i3 = red_i[pb][3];
+            if (i0 != 0x7fffffff) { aj = v0; j = i0; rphij = r0; }
+            if (nwv_act > 1 && i1 != 0x7fffffff && (v1 < aj || j == 0x7fffffff)) { aj = v1; j = i1; rphij = r1; }
+            if (nwv_act > 2 && i2 != 0x7fffffff && (v2 < aj || j == 0x7fffffff)) { aj = v2; j = i2; rphij = r2; }
+            if (nwv_act > 3 && i3 != 0x7fffffff && (v3 < aj || j == 0x7fffffff)) { aj = v3; j = i3; rphij = r3; }
+        } else {
+            for (int w = 0; w < nwv_act; ++w) {
+                const double v = red_v[pb][w];
+                const int i = red_i[pb][w];
+                if (i != 0x7fffffff && (v < aj || j == 0x7fffffff)) { aj = v; j = i; rphij = red_r[pb][w]; }
             }
         }
-        __syncthreads();
-        double aj = INF;
-        int j = 0x7fffffff;
-        for (int w = 0; w < nwv_act; ++w) {
-            const double v = red_v[pb][w];
-            const int i = red_i[pb][w];
-            if (i != 0x7fffffff && (v < aj || j == 0x7fffffff)) { aj = v; j = i; }   // ties keep the lower wave
-        }
         if (j == 0x7fffffff) { status = 1; break; }   // uniform: no positive entry (reference raises)
-        const double phij = col[j];
-        if (tid < M) {                                                                  // :158-159
-            const double step = aj * col[tid];
-            if (tid == j) dead_col = true;
-            mu[tid] = dead_col ? 0.0 : (mu[tid] - step);     // eliminated columns: the reference has Phi = 0, mu = 0
-        }
-        if (my_i == j) dead_upd = true;
-        const double rphij = 1.0 / phij;                                     // correctly rounded reciprocal
+        const double phij = col[j];                    // rphij = RN(1 / phij), from the pivot's own lane
         const double phi_i = col[my_i];
-        if (upd && !dead_upd) {
-            for (int cc = k + 1 + my_r; cc < nrows; cc += rows_per_pass) {   // :165-171
+        if (my_i == j) dead = true;
+        if (tid < M) {                                                                  // :158-159
+            const double step = aj * phi_i;
+            mu_r = dead ? 0.0 : (mu_r - step);         // eliminated columns: the reference has Phi = 0, mu = 0
+        }
+        BASQ_NS_STAMP(k, 3);
+        int cc = k + 1 + my_r;
+        double fresh = 0.0;
+        if (upd && !dead && cc < nrows) {              // first row of this thread: row k+1 for the column owners
+            double* p = Phi + (size_t)cc * M;
+            const double o = div_by_recip(p[j] * phi_i, phij, rphij);     // == prod / phij, bit for bit
+            fresh = p[my_i] - o;
+            p[my_i] = fresh;
+        }
+        cc += rows_per_pass;
+        if (k + 1 < nrows && wv < nwv_act) ratio_test(fresh, pb ^ 1);    // step k+1's test, off the critical path
+        if (upd && !dead) {
+            // four independent rows per trip, all LDS reads before the writes (otherwise every row is its own round trip)
+            for (; cc + 3 * rows_per_pass < nrows; cc += 4 * rows_per_pass) {   // :165-171
+                double* p0 = Phi + (size_t)cc * M;
+                double* p1 = p0 + (size_t)rows_per_pass * M;
+                double* p2 = p1 + (size_t)rows_per_pass * M;
+                double* p3 = p2 + (size_t)rows_per_pass * M;
+                const double a0 = p0[j], a1 = p1[j], a2 = p2[j], a3 = p3[j];
+                const double b0 = p0[my_i], b1 = p1[my_i], b2 = p2[my_i], b3 = p3[my_i];
+                const double o0 = div_by_recip(a0 * phi_i, phij, rphij);
+                const double o1 = div_by_recip(a1 * phi_i, phij, rphij);
+                const double o2 = div_by_recip(a2 * phi_i, phij, rphij);
+                const double o3 = div_by_recip(a3 * phi_i, phij, rphij);
+                p0[my_i] = b0 - o0;
+                p1[my_i] = b1 - o1;
+                p2[my_i] = b2 - o2;
+                p3[my_i] = b3 - o3;
+            }
+            for (; cc < nrows; cc += rows_per_pass) {
                 double* p = Phi + (size_t)cc * M;
-                const double prod = p[j] * phi_i;
-                const double o = div_by_recip(prod, phij, rphij);            // == prod / phij, bit for bit
+                const double o = div_by_recip(p[j] * phi_i, phij, rphij);
                 p[my_i] = p[my_i] - o;
             }
         }
+        BASQ_NS_STAMP(k, 4);
         __syncthreads();
+        BASQ_NS_STAMP(k, 5);
     }
-    const bool keep = (tid < M) && (mu[tid] > 0.0);
+    const bool keep = (tid < M) && (mu_r > 0.0);
     const unsigned long long bal = __ballot(keep);
     if (lane == 0) wave_cnt[wv] = __popcll(bal);
     __syncthreads();
@@ -1207,8 +1252,8 @@ __global__ void __launch_bounds__(1024) car_eliminate_lds_kernel(const double* _
     const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
     if (tid < M) {
         keep_rank[tid] = keep ? rank : -1;
-        mu_g[tid] = mu[tid];
-        if (keep) { kept[rank] = tid; w_star[rank] = mu[tid]; }
+        mu_g[tid] = mu_r;
+        if (keep) { kept[rank] = tid; w_star[rank] = mu_r; }
     }
     if (tid == 0) { info[0] = total; info[1] = status; }
 }
@@ -2315,7 +2360,7 @@ int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32
                            double* w_star, int32_t* info, void* stream) {
     if (!PhiT || !mu || !keep_rank || !kept || !w_star || !info || M < 1 || M > 1024 || s < 1 || s > M)
         return BASQ_EINVAL;
-    const size_t lds = ((size_t)(M - s) * M + M) * sizeof(double);
+    const size_t lds = (size_t)(M - s) * M * sizeof(double);
     if (s < M && lds <= 162560) {      // 163840 B per CU minus the kernel's static LDS
         if (hipFuncSetAttribute((const void*)car_eliminate_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)

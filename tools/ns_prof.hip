@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -DBASQ_NS_PROF tools/ns_prof.hip -o /tmp/ns_prof
 #include "../basq_amd/csrc/basq_hip.hip"
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 
@@ -78,6 +79,38 @@ int main(int argc, char** argv) {
         hipMemcpy(prof.data(), dprof, 4 * 16 * 8, hipMemcpyDeviceToHost);
         printf("chol_inv clocks (wave 0): cholesky loop %lld, write-back + recip %lld, inverse (wave 0) %lld, inverse (wave 1) %lld\n",
                at(0, 1, 0) - at(0, 0, 0), at(0, 2, 0) - at(0, 1, 0), at(0, 3, 0) - at(0, 2, 0), at(0, 3, 1) - at(0, 2, 1));
+    }
+    // elimination phases (PhiT = the null space just computed)
+    {
+        std::vector<double> mu(n);
+        double tot = 0;
+        for (auto& v : mu) { v = 0.05 + rand() / (double)RAND_MAX; tot += v; }
+        for (auto& v : mu) v /= tot;
+        double *dmu, *dw;
+        int *dkr, *dkept, *dinfo;
+        hipMalloc(&dmu, n * 8);
+        hipMalloc(&dw, n * 8);
+        hipMalloc(&dkr, n * 4);
+        hipMalloc(&dkept, n * 4);
+        hipMalloc(&dinfo, 8);
+        hipMemcpy(dmu, mu.data(), n * 8, hipMemcpyHostToDevice);
+        basq_nullspace_f64(dX, m, n, dV, dtau, dP, nullptr);
+        hipEventRecord(e0);
+        int rc = basq_car_eliminate_f64(dP, dmu, n, m, dkr, dkept, dw, dinfo, nullptr);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        printf("rc=%d  car_eliminate %d x %d total %.1f us\n", rc, m, n, ms * 1e3);
+        hipMemcpy(prof.data(), dprof, prof.size() * 8, hipMemcpyDeviceToHost);
+        printf("  k  scan+mu(w0)  update+ratio(w0)  update(max over waves)  barrier(w0)  step\n");
+        const int nr = n - m;
+        for (int k = 0; k + 1 < nr; k += (nr > 20 ? nr / 10 : 1)) {
+            long long umax = 0;
+            for (int w = 0; w < 16; ++w) umax = std::max(umax, at(k, 4, w) - at(k, 3, w));
+            printf("%3d %12lld %17lld %23lld %12lld %6lld\n", k, at(k, 3, 0) - at(k, 0, 0), at(k, 4, 0) - at(k, 3, 0), umax,
+                   at(k, 5, 0) - at(k, 4, 0), at(k + 1, 0, 0) - at(k, 0, 0));
+        }
     }
     return 0;
 }
