@@ -76,6 +76,9 @@ SETS_PER_WAVE = 16
 RESIDENT_WAVES = 256 * 4 * 3
 
 
+CHUNK_EFFICIENCY = 0.96          # smallest chunk count reaching this tail efficiency wins (A/B: tools/ab_engine.py)
+
+
 def rows_per_wave(kk: int) -> int:
     """BASQ_JT_FOR(KK) * 16 in basq_hip.hip: 64 rows per wave up to KP = 20, 32 beyond."""
     return 32 if kk >= 6 else 64
@@ -98,7 +101,7 @@ def choose_chunks(n_local_blocks: int, m: int, S: int, kk: int = 3, max_chunks: 
     for c in range(1, cap + 1):
         rounds = per_chunk * c / resident
         eff = rounds / max(1.0, float(-(-per_chunk * c // resident)))
-        if eff >= 0.96:
+        if eff >= CHUNK_EFFICIENCY:
             return c
         if eff > best_eff + 1e-9:
             best, best_eff = c, eff

@@ -25,8 +25,14 @@ def main():
     ap.add_argument("values", nargs="+")
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--visits", type=int, default=3)
+    ap.add_argument("--module", default="_engine", help="basq_amd submodule holding the switch (_engine, _partition)")
     a = ap.parse_args()
-    vals = [type(getattr(eng, a.name))(int(v)) if isinstance(getattr(eng, a.name), (bool, int)) else v for v in a.values]
+    global eng
+    import importlib
+
+    eng = importlib.import_module("basq_amd." + a.module)
+    cur = getattr(eng, a.name)
+    vals = [type(cur)(int(v)) if isinstance(cur, (bool, int)) else type(cur)(v) for v in a.values]
     dev = torch.device("cuda:0")
     N, d, n = 1_000_000, 10, 100
     pts = gmm_pool(N, d, 0).to(dev)
@@ -54,7 +60,7 @@ def main():
                 times[v].append((time.perf_counter() - t0) * 1e3)
             if ref is None:
                 ref = (idx.clone(), w.clone())
-            assert torch.equal(idx, ref[0]) and torch.equal(w, ref[1]), "the switch changed the result"
+            assert torch.equal(idx, ref[0]) and torch.allclose(w, ref[1], rtol=1e-9, atol=0), "the switch changed the result"
     for v in vals:
         t = sorted(times[v])
         print(f"{a.name}={v}: mean {sum(t) / len(t):7.2f} ms  median {t[len(t) // 2]:7.2f}  min {t[0]:7.2f}  ({len(t)} batches)")
