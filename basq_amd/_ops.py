@@ -197,12 +197,23 @@ class HipOps:
               "basq_box_muller_f64")
         return out
 
+    CHOL_SQUARE_MAX_Q = 142          # q (q|1) + q doubles fit in 160 KB of LDS
+    CHOL_PACKED_MAX_Q = 200          # q (q+1)/2 + q doubles fit
+
     def chol_inv(self, G, rel_tol=1e-12):
         """In place: G -> L (lower).  Returns (W = L^{-T}, info[1] int32 on device)."""
         self._chk(G)
         q = G.shape[0]
-        W = self.empty(q, q)
         info = self.empty(1, dtype=torch.int32)
+        if self.CHOL_SQUARE_MAX_Q < q <= self.CHOL_PACKED_MAX_Q:
+            # the square no longer fits in LDS: factor in the packed-triangle kernel, W = L^{-T} by a library
+            # triangular solve (plumbing); a failed factorisation (info != 0) leaves garbage in W, as the kernels do
+            check(self.lib.basq_chol_inv_f64(_ptr(G), q, None, _ptr(info), float(rel_tol), self._stream()),
+                  "basq_chol_inv_f64")
+            eye = torch.eye(q, dtype=torch.float64, device=self.device)
+            W = torch.linalg.solve_triangular(torch.tril(G).t(), eye, upper=True)
+            return torch.nan_to_num(W).contiguous(), info
+        W = self.empty(q, q)
         check(self.lib.basq_chol_inv_f64(_ptr(G), q, _ptr(W), _ptr(info), float(rel_tol), self._stream()),
               "basq_chol_inv_f64")
         return W, info

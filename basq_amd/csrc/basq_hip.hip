@@ -2125,6 +2125,66 @@ __global__ void __launch_bounds__(1024) chol_inv_lds_kernel(double* __restrict__
     BASQ_NS_STAMP(0, 3);
 }
 
+// Factor-only form for Gram matrices whose square does not fit in LDS but whose lower triangle does (142 < q <= 200,
+// e.g. q = 199 for batches of 200): packed row-major lower triangle L(i,j) at i(i+1)/2 + j, same right-looking
+// steps as above.  The caller obtains W = L^{-T} from a library triangular solve (plumbing, like the GEMMs).
+__global__ void __launch_bounds__(1024) chol_packed_lds_kernel(double* __restrict__ G, int q, int* __restrict__ info,
+                                                               double rel_tol) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* Lp = sm;                                     // [q (q + 1) / 2]
+    double* colj = sm + (size_t)q * (q + 1) / 2;         // [q]
+    __shared__ double red[16];
+    __shared__ double s_dmax;
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#define BASQ_TRI(i, j) Lp[(size_t)(i) * ((i) + 1) / 2 + (j)]
+    for (int i = tid >> 7; i < q; i += 8)
+        for (int k = tid & 127; k <= i; k += 128) BASQ_TRI(i, k) = G[(size_t)i * q + k];
+    if (tid == 0) s_bad = 0;
+    __syncthreads();
+    double dm = (tid < q) ? BASQ_TRI(tid, tid) : 0.0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) dm = fmax(dm, __shfl_xor(dm, o, 64));
+    if (lane == 0) red[wv] = dm;
+    __syncthreads();
+    if (tid == 0) {
+        double v = red[0];
+        for (int w = 1; w < 16; ++w) v = fmax(v, red[w]);
+        s_dmax = v;
+    }
+    __syncthreads();
+    const double floor_ = rel_tol * s_dmax;
+    for (int j = 0; j < q; ++j) {
+        const double d = BASQ_TRI(j, j);
+        if (!(d > floor_)) {                                  // uniform: every thread reads the same pivot
+            if (tid == 0) s_bad = j + 1;
+            break;
+        }
+        double rpiv = 0.0;
+        if (tid < q - j) {
+            rpiv = rsqrt_nr(d);
+            if (tid > 0) {
+                const int i = j + tid;
+                const double v = BASQ_TRI(i, j) * rpiv;
+                colj[i] = v;
+                BASQ_TRI(i, j) = v;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) BASQ_TRI(j, j) = d * rpiv;              // after the barrier: every thread has read d by now
+        for (int a = j + 1 + (tid >> 7); a < q; a += 8) {
+            const double ca = colj[a];
+            for (int b = j + 1 + (tid & 127); b <= a; b += 128) BASQ_TRI(a, b) -= ca * colj[b];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid == 0) info[0] = s_bad;
+    for (int i = tid >> 7; i < q; i += 8)
+        for (int k = tid & 127; k <= i; k += 128) G[(size_t)i * q + k] = BASQ_TRI(i, k);
+#undef BASQ_TRI
+}
+
 // ------------------------------------------------------------------------------------------------
 // Block sums of the SQUARE of a dense per-pair matrix (WSABI-M's 0.5 cov^2 term, BASQ/_wsabi.py:240-242):
 //     E[j][s] += scale * sum_{p in chunk, set(p) = s} mu_p * C[j][p]^2
@@ -2461,7 +2521,17 @@ int basq_dense_sq_blocksum_f64(const double* C, int32_t m, int64_t nc, int64_t l
 }
 
 int basq_chol_inv_f64(double* G, int32_t q, double* W, int32_t* info, double rel_tol, void* stream) {
-    if (!G || !W || !info || q < 1 || q > 1024 || !(rel_tol >= 0.0)) return BASQ_EINVAL;
+    if (!G || !info || q < 1 || q > 1024 || !(rel_tol >= 0.0)) return BASQ_EINVAL;
+    if (!W) {                                                   // factor only
+        const size_t ldsp = ((size_t)q * (q + 1) / 2 + q) * sizeof(double);
+        if (ldsp > 163840 - 256) return BASQ_EUNSUPPORTED;
+        if (hipFuncSetAttribute((const void*)chol_packed_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)ldsp) != hipSuccess)
+            return BASQ_ELAUNCH;
+        hipLaunchKernelGGL(chol_packed_lds_kernel, dim3(1), dim3(1024), ldsp, (hipStream_t)stream, G, q, info, rel_tol);
+        BASQ_CHECK_LAUNCH();
+        return BASQ_OK;
+    }
     const size_t sq = (size_t)q * (q | 1);
     const size_t qpad = (size_t)((q + 1) & ~1);
     const size_t lds1 = (sq + qpad) * sizeof(double), lds2 = (2 * sq + qpad) * sizeof(double);

@@ -210,6 +210,8 @@ int basq_box_muller_f64(const double* u, int64_t n, const double* u_tail, double
  * the strict upper triangle is left as it was) and W [q,q] receives L^{-T} (upper triangular), so that
  * Q = X W has orthonormal columns.  info[0] = 0 on success, j+1 if pivot j <= rel_tol * max_i G[i][i]
  * (numerically rank-deficient: the caller falls back to Householder QR on the host).  q <= 1024.
+ * W == NULL: factor only (G -> L), through a packed-triangle LDS kernel that also serves 142 < q <= 200, where the
+ * square no longer fits in LDS; returns BASQ_EUNSUPPORTED for q > 200 (pass W then: global-memory kernel).
  */
 int basq_chol_inv_f64(double* G, int32_t q, double* W, int32_t* info, double rel_tol, void* stream);
 

@@ -254,10 +254,11 @@ def test_no_cpu_path():
                                torch.device("cpu"))
 
 
-@pytest.mark.parametrize("q", [1, 5, 8, 9, 30, 99, 100, 101, 137, 199, 300])
+@pytest.mark.parametrize("q", [1, 5, 8, 9, 30, 99, 100, 101, 137, 142, 143, 199, 200, 201, 300])
 def test_chol_inv(hip_ops, q):
     """CholeskyQR building block: L L^T = G and (X W)^T (X W) = I.  Sizes cover the blocked inverse (8 <= q <= 100,
-    incl. block sizes that do not divide q), the column-per-thread inverse in LDS (q <= 142) and the global kernel."""
+    incl. block sizes that do not divide q), the column-per-thread inverse in LDS (q <= 142), the packed-triangle
+    factorisation + library triangular solve (143..200) and the global kernel."""
     X = _rand(4 * q + 7, q, 20 + q)
     G = X.T @ X
     Gd = hip_ops.to_device(G.clone())
