@@ -408,3 +408,15 @@ def test_sharded_products_on_device(hip_ops):
     sign = torch.sign((Us * Ud).sum(1, keepdim=True))
     assert (Us * sign - Ud).abs().max().item() <= 1e-7
     assert torch.equal(prod.full(), A)
+
+
+def test_fuzz_single_workgroup_kernels(hip_ops):
+    """Random shapes through the hand-synchronised kernels (tools/fuzz_reduction.py): LAPACK's null-space rows, bit-exact
+    and bitwise-repeatable elimination, orthonormalising Cholesky -- a race would show up as a flaky last bit."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from fuzz_reduction import run
+
+    assert run(30, 7, hip_ops).startswith("fuzz ok")
