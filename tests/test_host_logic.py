@@ -184,3 +184,82 @@ def test_rand_consumes_like_randn(n):
     assert torch.equal(s1, s2)
     b = CpuStandInOps().box_muller(u, ut)
     assert (a - b).abs().max().item() <= 4e-15
+
+
+def _numerical_rank(A, rel=1e-10):
+    ev = torch.linalg.eigvalsh(0.5 * (A + A.T))
+    return int((ev > rel * ev.max()).sum())
+
+
+def test_differential_fuzz_engine_vs_oracle():
+    """Random small configurations (N, d, n, m, kernel family): the engine's host logic on the CPU stand-in against the
+    oracle (= the reference's op sequence), indices identical, weights within the 1e-5 bar.
+
+    Configurations where the requested rank q exceeds the NUMERICAL rank of the Nystrom Gram are counted, not compared:
+    there the trailing rows of the reference's own basis are round-off (see the next test), so no implementation --
+    including the reference under a 1-ulp change of its kernel -- reproduces them."""
+    from oracle.kernels_oracle import StationaryOracle
+    from oracle.rchq_oracle import recombination_oracle
+    from basq_amd.kernels import StationaryKernel
+    from basq_amd.pools import gmm_pool
+
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        g = torch.Generator().manual_seed(11)
+        compared = ill_posed = 0
+        for case in range(36):
+            N = int(torch.randint(3, 2500, (1,), generator=g))
+            d = int(torch.randint(1, 7, (1,), generator=g))
+            n = int(torch.randint(2, 41, (1,), generator=g))
+            m = int(torch.randint(1, min(N, 150) + 1, (1,), generator=g))
+            fam = ["rbf", "matern52", "matern32"][case % 3]
+            ls = 0.8 + 0.4 * (case % 5)
+            pts = gmm_pool(N, d, 100 + case)
+            nys = pts[:m]
+            ko = StationaryOracle(fam, ls, 1.0)
+            q = min(n - 1, m)
+            if _numerical_rank(ko(nys, nys)) < q:
+                ill_posed += 1
+                continue
+            torch.manual_seed(case)
+            io, wo = recombination_oracle(pts, nys, n, ko)
+            torch.manual_seed(case)
+            ie, we = RecombinationEngine(CpuStandInOps()).run(pts, 0, N, nys, n, StationaryKernel(fam, ls, 1.0))
+            assert io.tolist() == ie.tolist(), f"case {case}: N={N} d={d} n={n} m={m} {fam}"
+            if len(wo):
+                assert ((we - wo).abs() / wo).max().item() <= 1e-5
+            compared += 1
+        assert compared >= 20 and ill_posed >= 1
+    finally:
+        torch.set_default_dtype(prev)
+
+
+def test_reference_is_unstable_when_q_exceeds_the_numerical_rank():
+    """Where parity is NOT defined: a 1-D RBF Gram of 42 points has numerical rank ~16; asked for q = 37 features, the
+    reference's own selection (oracle == reference op sequence) changes almost entirely when its kernel values move by
+    one ulp.  DESIGN.md section 2 states this limit of the parity claim."""
+    from oracle.kernels_oracle import StationaryOracle
+    from oracle.rchq_oracle import recombination_oracle
+    from basq_amd.pools import gmm_pool
+
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        pts = gmm_pool(190, 1, 148)
+        nys = pts[:42]
+        ko = StationaryOracle("rbf", 2.0, 1.0)
+        assert _numerical_rank(ko(nys, nys)) < 37
+
+        def perturbed(x, y):
+            K = ko(x, y)
+            gg = torch.Generator().manual_seed(K.numel() % 1000)
+            return K * (1 + 2e-16 * (torch.rand(K.shape, generator=gg) - 0.5))
+
+        torch.manual_seed(48)
+        i0, _ = recombination_oracle(pts, nys, 38, ko)
+        torch.manual_seed(48)
+        i1, _ = recombination_oracle(pts, nys, 38, perturbed)
+        assert len(set(i0.tolist()) & set(i1.tolist())) < len(i0) // 2
+    finally:
+        torch.set_default_dtype(prev)
