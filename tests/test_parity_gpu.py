@@ -125,3 +125,44 @@ def test_full_size_properties():
     # survivors halve every round: R_{r+1} = nb * n_keep (+ tail)
     for a, b in zip(tr.rounds[:-1], tr.rounds[1:]):
         assert b["R"] <= a["R"] // 2 + a["S"]
+
+
+def test_differential_fuzz_gpu():
+    """Random configurations through the HIP path against the oracle: odd sizes, every small-d kernel variant, tiny and
+    ragged pools.  Indices identical, weights inside the 1e-5 bar; configurations whose Nystrom Gram is numerically
+    rank-deficient for the requested q are skipped (the reference itself is round-off dependent there, see
+    tests/test_host_logic.py::test_reference_is_unstable_when_q_exceeds_the_numerical_rank)."""
+    import basq_amd
+    from basq_amd.pools import gmm_pool
+    from oracle.kernels_oracle import StationaryOracle
+    from oracle.rchq_oracle import recombination_oracle
+
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        g = torch.Generator().manual_seed(23)
+        compared = 0
+        for case in range(40):
+            N = int(torch.randint(3, 4000, (1,), generator=g))
+            d = int(torch.randint(1, 15, (1,), generator=g))
+            n = int(torch.randint(2, 61, (1,), generator=g))
+            m = int(torch.randint(1, min(N, 200) + 1, (1,), generator=g))
+            fam = ["rbf", "matern52", "matern32"][case % 3]
+            ls = 0.8 + 0.4 * (case % 5)
+            pts = gmm_pool(N, d, 300 + case)
+            nys = pts[:m]
+            ko = StationaryOracle(fam, ls, 1.0)
+            ev = torch.linalg.eigvalsh(ko(nys, nys))
+            if int((ev > 1e-10 * ev.max()).sum()) < min(n - 1, m):
+                continue
+            torch.manual_seed(case)
+            io, wo = recombination_oracle(pts, nys, n, ko)
+            torch.manual_seed(case)
+            ie, we = basq_amd.recombination(pts, nys, n, basq_amd.kernels.StationaryKernel(fam, ls, 1.0), torch.device(DEV))
+            assert io.tolist() == ie.cpu().tolist(), f"case {case}: N={N} d={d} n={n} m={m} {fam}"
+            if len(wo):
+                assert ((we.cpu() - wo).abs() / wo).max().item() <= 1e-5
+            compared += 1
+        assert compared >= 25
+    finally:
+        torch.set_default_dtype(prev)
