@@ -646,8 +646,19 @@ class RecombinationEngine:
                 # + U @ (0.5 sum mu cov^2): the one term of wsabim_kernel that is not linear in the block sums
                 with _Timer(ops, trace, "wsabim_sq"):
                     E = self._wsabim_square_term(base, spec, pts_nys, Xo, Bmat, center, cand_raw, mu, Rl, off,
-                                                 geo.n_full, S_r, m)
+                                                 geo.n_full, S_r, m, diag_noise)
                     msg[1:q + 1] += ops.matmul(U, E)
+            tail_row, n_tail_diag = 0, 0
+            if diag_noise != 0.0 and not final and geo.n_tail > 0:
+                # the ragged tail is a kernel block of its own (:91-99): predictive_covariance adds the noise to ITS
+                # entries [k][k] too (tail point k x Nystrom row k).  One more message row carries the tail weights.
+                tailw = ops.zeros(S_r)
+                t0l = max(geo.n_full - off, 0)                   # first local tail position
+                if t0l < Rl:
+                    k0 = off + t0l - geo.n_full
+                    tailw[k0:k0 + (Rl - t0l)] = mu[t0l:Rl] if wx is None else mu[t0l:Rl] * wx[t0l:Rl]
+                msg = torch.cat([msg, tailw.unsqueeze(0)], 0)
+                tail_row, n_tail_diag = msg.shape[0] - 1, min(m, geo.n_tail)
             if trace is not None:
                 if trace.host_sync:
                     ops.synchronize()
@@ -662,7 +673,8 @@ class RecombinationEngine:
             M = S_r
             replicate = REPLICATED_REDUCTION and comm.world > 1
             if comm.rank == 0 or replicate:
-                XcarT, tot = ops.finalize(parts, comm.world, q_ext + 1, q, S_r, diagU, m, min(m, S_r), diag_noise, wrow)
+                XcarT, tot = ops.finalize(parts, comm.world, parts.shape[1], q, S_r, diagU, m, min(m, S_r), diag_noise, wrow,
+                                          tail_row, n_tail_diag)
                 if GPU_NULLSPACE:
                     with _Timer(ops, trace, "nullspace"):
                         PhiT = ops.nullspace(XcarT, s, M)        # :140-143 (rows = null-space vectors)
@@ -787,8 +799,11 @@ class RecombinationEngine:
         return gids[kept_pos.to(gids.device)], ops.to_device(w_host)
 
     def _wsabim_square_term(self, base, spec, pts_nys, Xo, Bmat, center, cand_raw, mu, Rl, off, n_full, S, m,
-                            chunk_bytes=256 << 20):
+                            diag_noise=0.0, chunk_bytes=256 << 20):
         """E[j, s] = 0.5 * sum_{p in set s} mu_p * cov(pt_j, x_p)^2  with cov = k - K(pt,X) W K(X, x)  (_wsabi.py:240).
+
+        ``cov`` is ``predictive_covariance``, which carries the likelihood noise on entry [k][k] of every block the
+        reference builds: candidate p of a full block meets Nystrom row ``p mod S``, tail point k meets row k.
 
         Dense in chunks of candidates: two HIP Gram blocks, one rocBLAS GEMM for the posterior correction and the
         HIP squared block sum; the chunk partials are accumulated in position order (fixed summation order).
@@ -805,6 +820,11 @@ class RecombinationEngine:
             pb = ops.pack(spec, cand_raw[p0:p0 + nc].contiguous(), center, ROLE_B)
             cov = ops.gram(spec, pa, m, pb, nc)
             cov -= Bmat @ ops.gram(spec, po, Xo.shape[0], pb, nc)
+            if diag_noise != 0.0:
+                pg = off + p0 + torch.arange(nc, device=cov.device)
+                kappa = torch.where(pg < n_full, pg % S, pg - n_full)
+                hit = kappa < m
+                cov[kappa[hit], torch.arange(nc, device=cov.device)[hit]] += diag_noise
             ops.dense_sq_blocksum(cov, mu[p0:p0 + nc], off + p0, n_full, S, 0.5, E)
         return E
 

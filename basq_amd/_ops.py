@@ -131,12 +131,14 @@ class HipOps:
                                         ksplit, _ptr(work), _ptr(out), self._stream()), "basq_project_f64")
         return out
 
-    def finalize(self, parts, n_parts, msg_rows, q, S, diagU=None, ld_diag=0, n_diag=0, diag_noise=0.0, diag_wrow=0):
+    def finalize(self, parts, n_parts, msg_rows, q, S, diagU=None, ld_diag=0, n_diag=0, diag_noise=0.0, diag_wrow=0,
+                 diag_tail_row=0, n_tail_diag=0):
         self._chk(parts)
         XcarT = self.empty(q + 1, S)
         tot = self.empty(S)
         check(self.lib.basq_finalize_f64(_ptr(parts), n_parts, msg_rows, q, S, _ptr(diagU), ld_diag, n_diag,
-                                         float(diag_noise), diag_wrow, _ptr(XcarT), _ptr(tot), self._stream()),
+                                         float(diag_noise), diag_wrow, diag_tail_row, n_tail_diag, _ptr(XcarT),
+                                         _ptr(tot), self._stream()),
               "basq_finalize_f64")
         return XcarT, tot
 

@@ -963,7 +963,8 @@ __global__ void project_reduce_kernel(const double* __restrict__ work, int kspli
 
 __global__ void finalize_kernel(const double* __restrict__ parts, int n_parts, int msg_rows, int q, int S,
                                 const double* __restrict__ diagU, long long ld_diag, int n_diag, double diag_noise,
-                                int diag_wrow, double* __restrict__ XcarT, double* __restrict__ tot_out) {
+                                int diag_wrow, int diag_tail_row, int n_tail_diag, double* __restrict__ XcarT,
+                                double* __restrict__ tot_out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (q + 1) * S) return;
     const int r = idx / S, s = idx % S;
@@ -977,13 +978,34 @@ __global__ void finalize_kernel(const double* __restrict__ parts, int n_parts, i
     }
     double v = 0.0;
     for (int p = 0; p < n_parts; ++p) v += parts[p * stride + idx];
-    if (diagU && s < n_diag) {
-        double wgt = tot;
-        if (diag_wrow != 0) {
-            wgt = 0.0;
-            for (int p = 0; p < n_parts; ++p) wgt += parts[p * stride + (long long)diag_wrow * S + s];
+    if (diagU) {
+        const bool tail_set = diag_tail_row != 0 && s == S - 1;
+        const double* urow = diagU + (long long)(r - 1) * ld_diag;
+        if (s < n_diag) {
+            // entry [s][s] of every FULL block: weight of set s without the ragged tail (which is its own block)
+            double wgt = tot;
+            if (diag_wrow != 0) {
+                wgt = 0.0;
+                for (int p = 0; p < n_parts; ++p) wgt += parts[p * stride + (long long)diag_wrow * S + s];
+            }
+            if (tail_set) {
+                double tw = 0.0;
+                for (int k = 0; k < S; ++k)
+                    for (int p = 0; p < n_parts; ++p) tw += parts[p * stride + (long long)diag_tail_row * S + k];
+                wgt -= tw;
+            }
+            v += diag_noise * wgt * urow[s];
         }
-        v += diag_noise * wgt * diagU[(long long)(r - 1) * ld_diag + s];
+        if (tail_set) {
+            // entry [k][k] of the tail block: tail point k meets Nystrom row k, and the tail belongs to the last set
+            double acc = 0.0;
+            for (int k = 0; k < n_tail_diag; ++k) {
+                double tw = 0.0;
+                for (int p = 0; p < n_parts; ++p) tw += parts[p * stride + (long long)diag_tail_row * S + k];
+                acc += tw * urow[k];
+            }
+            v += diag_noise * acc;
+        }
     }
     XcarT[idx] = v / tot;
 }
@@ -2405,13 +2427,15 @@ int basq_project_f64(const double* U, int32_t q, int32_t m, const double* Xpart,
 
 int basq_finalize_f64(const double* parts, int32_t n_parts, int32_t msg_rows, int32_t q, int32_t S,
                       const double* diagU, int64_t ld_diag, int32_t n_diag, double diag_noise, int32_t diag_wrow,
-                      double* XcarT, double* tot_out, void* stream) {
+                      int32_t diag_tail_row, int32_t n_tail_diag, double* XcarT, double* tot_out, void* stream) {
     if (!parts || !XcarT || !tot_out || n_parts < 1 || q < 1 || S < 1 || msg_rows < q + 1) return BASQ_EINVAL;
     if (diag_wrow < 0 || diag_wrow >= msg_rows) return BASQ_EINVAL;
+    if (diag_tail_row < 0 || diag_tail_row >= msg_rows || n_tail_diag < 0 || n_tail_diag > S) return BASQ_EINVAL;
+    if (diagU && (n_diag > ld_diag || n_tail_diag > ld_diag)) return BASQ_EINVAL;
     const int tot = (q + 1) * S;
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, parts,
-                       n_parts, msg_rows, q, S, diagU, (long long)ld_diag, n_diag, diag_noise, diag_wrow, XcarT,
-                       tot_out);
+                       n_parts, msg_rows, q, S, diagU, (long long)ld_diag, n_diag, diag_noise, diag_wrow, diag_tail_row,
+                       n_tail_diag, XcarT, tot_out);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }

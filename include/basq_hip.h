@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BASQ_ABI_VERSION 1
+#define BASQ_ABI_VERSION 2
 
 /* error codes */
 #define BASQ_OK            0
@@ -129,14 +129,19 @@ int basq_project_f64(const double* U, int32_t q, int32_t m, const double* Xpart,
  * barycentres, BASQ/_rchq.py:101) and write the matrix the reduction decomposes
  * (BASQ/_rchq.py:138-140):  XcarT[0][s] = 1, XcarT[1+r][s] = feature_r(s) / tot[s];  tot[s] -> tot_out.
  * Optional additive term (predictive_covariance's diagonal noise, BASQ/_gp.py:275-276, which the
- * reference adds to entry [k][k] of EVERY kernel block):  if diagU != NULL,
- *     feature_r(s) += diag_noise * weight(s) * diagU[r*ld_diag + s]      for s < n_diag
- * with weight = message row `diag_wrow` (0 = the set weights; q+1 = an extra message row, used by the
- * WSABI-L kernel whose block sums carry a per-candidate factor).  msg_rows >= q + 1.
+ * reference adds to entry [k][k] of EVERY kernel block it builds): if diagU != NULL,
+ *     feature_r(s) += diag_noise * weight(s) * diagU[r*ld_diag + s]                  for s < n_diag
+ * with weight = the weight of set s summed over the FULL blocks: message row `diag_wrow` (0 = the set weights;
+ * q+1 = an extra message row, used by the WSABI-L kernel whose block sums carry a per-candidate factor), minus --
+ * for the last set -- the tail weights.  The ragged tail is its own block (BASQ/_rchq.py:91-99), whose entry
+ * [k][k] pairs tail point k with Nystrom row k and lands in the LAST set: with `diag_tail_row` != 0 naming a
+ * message row that holds the tail points' weights (tail[k], zero beyond the tail),
+ *     feature_r(S-1) += diag_noise * sum_{k < n_tail_diag} tail[k] * diagU[r*ld_diag + k].
+ * msg_rows >= q + 1;  n_diag, n_tail_diag <= ld_diag.
  */
 int basq_finalize_f64(const double* parts, int32_t n_parts, int32_t msg_rows, int32_t q, int32_t S,
                       const double* diagU, int64_t ld_diag, int32_t n_diag, double diag_noise, int32_t diag_wrow,
-                      double* XcarT, double* tot_out, void* stream);
+                      int32_t diag_tail_row, int32_t n_tail_diag, double* XcarT, double* tot_out, void* stream);
 
 /*
  * Null-space basis of the wide [s, M] matrix XcarT, replacing the full SVD of BASQ/_rchq.py:140-143

@@ -48,6 +48,14 @@ CASES = [
     case("wsabil_2e4", 20_000, 10, 200, 100, K("rbf", 2.0, 1.0, posterior=POST_W, warp="wsabil"), pool_seed=9),
     case("wsabim_1e4", 10_000, 6, 100, 50, K("rbf", 2.0, 1.0, posterior=POST, warp="wsabim"), pool_seed=10),
     case("matern52_posterior", 9_000, 8, 90, 60, K("matern52", 3.0, 1.0, posterior=POST), pool_seed=13),
+    # likelihood noise far above the reference's default 1e-10: the per-block diagonal terms of predictive_covariance
+    # (full blocks, the ragged tail block, the squared term of WSABI-M) become visible in the selection
+    case("posterior_noise_ragged", 9_123, 6, 90, 40, K("matern52", 2.5, 1.2, posterior=dict(n_obs=60, noise=1e-3, obs_seed=14)),
+         pool_seed=14),
+    case("wsabil_noise_ragged", 7_777, 5, 120, 30, K("rbf", 2.0, 1.0, posterior=dict(n_obs=80, noise=1e-3, obs_seed=15),
+                                                      warp="wsabil"), pool_seed=15),
+    case("wsabim_noise_ragged", 4_321, 4, 70, 25, K("rbf", 2.0, 1.0, posterior=dict(n_obs=50, noise=1e-2, obs_seed=16),
+                                                     warp="wsabim"), pool_seed=16),
     # BASELINE config 2: N=1e5, d=10, n=100, m=1e3.
     case("cfg2_rbf_1e5", 100_000, 10, 1_000, 100, K("rbf", 2.0)),
     # BASELINE config 3 / headline metric: N=1e6, d=10, n=100, m=1e4 (reference: ~2 min of CPU).

@@ -169,16 +169,22 @@ class CpuStandInOps:
         X = Xpart.sum(0)
         return torch.cat([totpart.sum(0).unsqueeze(0), outputscale * (U @ X)], 0)
 
-    def finalize(self, parts, n_parts, msg_rows, q, S, diagU=None, ld_diag=0, n_diag=0, diag_noise=0.0, diag_wrow=0):
+    def finalize(self, parts, n_parts, msg_rows, q, S, diagU=None, ld_diag=0, n_diag=0, diag_noise=0.0, diag_wrow=0,
+                 diag_tail_row=0, n_tail_diag=0):
         self._count("finalize")
         msg = parts[0].clone()
         for p in range(1, n_parts):
             msg = msg + parts[p]
         tot = msg[0].clone()
         feat = msg[1:q + 1].clone()
-        if diagU is not None and n_diag > 0:
-            wgt = msg[diag_wrow]
-            feat[:, :n_diag] += diag_noise * wgt[:n_diag].unsqueeze(0) * diagU[:, :n_diag]
+        if diagU is not None:
+            wgt = msg[diag_wrow].clone()
+            if diag_tail_row:
+                tail = msg[diag_tail_row]
+                wgt[S - 1] -= tail.sum()                       # the last set's weight over the FULL blocks only
+                feat[:, S - 1] += diag_noise * (diagU[:, :n_tail_diag] @ tail[:n_tail_diag])
+            if n_diag > 0:
+                feat[:, :n_diag] += diag_noise * wgt[:n_diag].unsqueeze(0) * diagU[:, :n_diag]
         XcarT = torch.cat([torch.ones(1, S, dtype=torch.float64), feat / tot.unsqueeze(0)], 0)
         return XcarT, tot
 

@@ -76,7 +76,9 @@ def _worker(rank, world, port, name, q, rank0_only=False):
 @pytest.mark.parametrize("name,world,rank0_only", [("rbf_ragged", 2, False), ("rbf_1e4", 2, False),
                                                    ("cfg1_posterior_1e4", 2, False), ("wsabil_2e4", 2, False),
                                                    ("rbf_ragged", 3, False), ("rbf_tiny_final", 2, False),
-                                                   ("wsabim_1e4", 2, False), ("rbf_ragged", 3, True),
+                                                   ("wsabim_1e4", 2, False), ("posterior_noise_ragged", 3, False),
+                                                   ("wsabil_noise_ragged", 2, False), ("wsabim_noise_ragged", 2, False),
+                                                   ("rbf_ragged", 3, True),
                                                    ("cfg1_posterior_1e4", 2, True)])
 def test_sharded_engine_matches_golden(name, world, rank0_only):
     """Default multi-rank mode (sharded range finder, reduction replicated on every rank) and the rank-0-only mode
