@@ -127,12 +127,16 @@ def main():
 
     # HBM bytes of the largest block-sum launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE in separate runs, KiB units; 8-B-per-lane loads, so the gfx950 16-B half-count does not apply)
-    traffic, traffic_src = None, None
+    traffic, traffic_src, pipe_busy = None, None, None
     pmc = os.path.join(ROOT, "profiles", "r01_traffic.json")
     if os.path.exists(pmc) and N == WORKLOAD["N"] and d == WORKLOAD["d"] and world == 1:
         with open(pmc) as f:
             rec = json.load(f)
         traffic, traffic_src = rec["bytes_per_launch"], rec["source"]
+        try:                                                         # (4 INSTS_VALU + MFMA_BUSY) / SIMD-cycles, same passes
+            pipe_busy = float(rec["pipe"]["fp64_pipe_busy"].rsplit("=", 1)[1])
+        except (KeyError, ValueError, IndexError):
+            pipe_busy = None
 
     if args.breakdown:
         tb = basq_amd.EngineTrace(time_kernels=False, host_sync=True)
@@ -182,11 +186,14 @@ def main():
                 "achieved": achieved_tf, "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tf / PEAK_FP64_VECTOR_TFLOPS,
                 "traffic": traffic,
+                "fp64_pipe_busy_pmc": pipe_busy,
                 "launches_per_batch": k_launches, "kernel_ms_per_batch": k_ms, "pairs_per_batch": k_pairs,
                 "flops_per_pair": 3 * d + 3,
                 "hbm_algorithmic_GBs": bytes_alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
                 "hbm_peak_GBs": PEAK_HBM_GBS,
-                "note": "compute-bound on the fp64 vector ALU (SURVEY 8d); measured per rank 0; traffic: see profiles/",
+                "note": "compute-bound on the fp64 pipe (f64 MFMA and fp64 VALU share it on gfx950; SURVEY 8d): 33 flop "
+                        "per pair by SURVEY's count cost ~108 pipe-cycles per 64 pairs, half of them the exp; measured "
+                        "per rank 0; traffic / pipe occupancy: committed PMC passes, see profiles/",
             },
             "cpu_baseline": cpu,
             "result_digest": {"n_selected": int(idx.numel()), "w_sum": float(w.sum().item())},
