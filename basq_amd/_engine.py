@@ -7,9 +7,10 @@ Mirrors ``BASQ/_rchq.py``: ``rc_kernel_svd`` (:34-40) = Nystrom basis + ``Mod_Tc
 step (reference lines)                   here
 =======================================  ==========================================================
 Gram ``kernel(pt, pt)`` (:29)            ``basq_gram_f64`` (+ small rocBLAS GEMMs for GP corrections)
-``torch.svd_lowrank`` (:29)              same algorithm (Halko 4.4/5.1, niter=2): Gaussian test matrix
-                                         from the CPU global generator (parity), GEMMs on the GPU,
-                                         QR / small SVD on host LAPACK (parity: sign conventions)
+``torch.svd_lowrank`` (:29)              same algorithm (Halko 4.4/5.1, niter=2): uniforms of the Gaussian test
+                                         matrix from the CPU global generator (parity) + Box-Muller on the GPU,
+                                         GEMMs on the GPU, CholeskyQR (``basq_chol_inv_f64``) instead of the
+                                         Householder QRs, one q x q SVD on host LAPACK
 hot loop + tail + tot (:79-99)           ``basq_blocksum_f64`` (fused, nothing materialised)
 ``U_svd @ X_for_nys`` (:88)              ``basq_project_f64`` (f64 MFMA)
 divide, ones column (:101, :138)         ``basq_finalize_f64``
@@ -23,8 +24,9 @@ re-weight + compaction (:107-130)        ``basq_reweight_compact_f64`` (closed-f
 =======================================  ==========================================================
 
 Multi-GPU: the candidate pool is sharded in contiguous id ranges; per round every rank
-block-sums and projects its shard, the ``(q+1) x S`` messages are all-gathered and added in rank order,
-rank 0 runs the reduction and broadcasts the (tiny) result; re-weighting/compaction are local.
+block-sums and projects its shard, the ``(q+1) x S`` messages are all-gathered and added in rank order, and
+every rank runs the (deterministic) reduction on the same message; re-weighting/compaction are local.  The range
+finder's Gram products are row-sharded as well (``_ShardedProducts``).
 """
 from __future__ import annotations
 
@@ -522,8 +524,8 @@ class RecombinationEngine:
             if Rl == 0:                                         # keep pointers valid for empty shards
                 cand, mu, gid = ops.zeros(1, kp), ops.zeros(1), ops.zeros(1, dtype=torch.int64)
 
-        # ---- round-1 block sums are queued BEFORE the basis: they do not depend on U, and the ~12 ms CPU
-        #      randn of the range finder then overlaps with the largest kernel of the batch ----------------
+        # ---- round-1 block sums are queued BEFORE the basis: they do not depend on U, and the host's RNG draw
+        #      for the range finder then overlaps with the largest kernel of the batch -----------------------
         pre = None
         late = None                                             # deferred part of the round-1 block sums
         if R > S:
@@ -550,7 +552,7 @@ class RecombinationEngine:
                 late = lambda: launch(n_chunks - LATE_CHUNKS, n_chunks, p_split, Rl)      # noqa: E731
             pre = (Xpart, totpart, n_chunks)
 
-        # ---- Nystrom basis: rank 0 computes, everyone receives (one randn draw, as in the reference) ----
+        # ---- Nystrom basis (one Gaussian draw on rank 0, as in the reference) ----------------------------
         if SHARDED_BASIS and comm.world > 1 and not sober:
             # every rank builds its row block of the Gram matrix and takes part in the range finder (no broadcast of U)
             shards = initial_shards(m, comm.world)
