@@ -445,6 +445,9 @@ class RecombinationEngine:
         sober = variant == "sober"
         if n_total >= 2 ** 31:
             raise ValueError("pool sizes >= 2^31 are not supported")
+        if n_total == 0:                                        # empty pool: nothing to select (the reference returns [])
+            return (torch.empty(0, dtype=torch.int64, device=getattr(ops, "device", "cpu")),
+                    torch.empty(0, dtype=torch.float64, device=getattr(ops, "device", "cpu")))
         pts_nys = ops.to_device(pts_nys, torch.float64)
         pts_local = ops.to_device(pts_local, torch.float64)
         m, d = pts_nys.shape

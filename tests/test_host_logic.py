@@ -263,3 +263,28 @@ def test_reference_is_unstable_when_q_exceeds_the_numerical_rank():
         assert len(set(i0.tolist()) & set(i1.tolist())) < len(i0) // 2
     finally:
         torch.set_default_dtype(prev)
+
+
+@pytest.mark.parametrize("N,d,n,m", [(1, 2, 2, 1), (2, 2, 2, 1), (2, 2, 3, 2), (3, 1, 2, 2), (5, 3, 2, 3), (4, 2, 2, 4),
+                                     (7, 2, 3, 1), (10, 2, 10, 5), (6, 2, 2, 6), (0, 2, 3, 0)])
+def test_tiny_and_degenerate_pools(N, d, n, m):
+    """One-point pools, pools smaller than the batch, n = 2 (a single Nystrom feature), m = 1, the empty pool: whatever
+    the reference's op sequence returns, the engine returns."""
+    from oracle.kernels_oracle import StationaryOracle
+    from oracle.rchq_oracle import recombination_oracle
+    from basq_amd.kernels import StationaryKernel
+    from basq_amd.pools import gmm_pool
+
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        pts = gmm_pool(max(N, 1), d, 3)[:N]
+        nys = pts[:m]
+        torch.manual_seed(1)
+        io, wo = recombination_oracle(pts, nys, n, StationaryOracle("rbf", 1.5, 1.0))
+        torch.manual_seed(1)
+        ie, we = RecombinationEngine(CpuStandInOps()).run(pts, 0, N, nys, n, StationaryKernel("rbf", 1.5, 1.0))
+        assert io.tolist() == ie.tolist()
+        assert len(wo) == len(we) and (len(wo) == 0 or ((we - wo).abs() / wo).max().item() <= 1e-9)
+    finally:
+        torch.set_default_dtype(prev)

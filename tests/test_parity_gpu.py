@@ -166,3 +166,27 @@ def test_differential_fuzz_gpu():
         assert compared >= 25
     finally:
         torch.set_default_dtype(prev)
+
+
+@pytest.mark.parametrize("N,d,n,m", [(1, 2, 2, 1), (2, 2, 2, 1), (2, 2, 3, 2), (3, 1, 2, 2), (5, 3, 2, 3), (4, 2, 2, 4),
+                                     (7, 2, 3, 1), (10, 2, 10, 5), (6, 2, 2, 6), (0, 2, 3, 0)])
+def test_tiny_and_degenerate_pools_gpu(N, d, n, m):
+    """The HIP path on one-point pools, pools smaller than the batch, a single Nystrom feature, m = 1, the empty pool."""
+    import basq_amd
+    from basq_amd.pools import gmm_pool
+    from oracle.kernels_oracle import StationaryOracle
+    from oracle.rchq_oracle import recombination_oracle
+
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        pts = gmm_pool(max(N, 1), d, 3)[:N]
+        nys = pts[:m]
+        torch.manual_seed(1)
+        io, wo = recombination_oracle(pts, nys, n, StationaryOracle("rbf", 1.5, 1.0))
+        torch.manual_seed(1)
+        ie, we = basq_amd.recombination(pts, nys, n, basq_amd.kernels.StationaryKernel("rbf", 1.5, 1.0), torch.device(DEV))
+        assert io.tolist() == ie.cpu().tolist()
+        assert len(wo) == len(we) and (len(wo) == 0 or ((we.cpu() - wo).abs() / wo).max().item() <= 1e-9)
+    finally:
+        torch.set_default_dtype(prev)
