@@ -23,6 +23,9 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+PROJECT_KSPLIT_MAX = 48          # K slices of the projection GEMM (A/B: tools/ab_engine.py --module _ops)
+
+
 class HipOps:
     """Operations on ``device`` (a ``torch.device('cuda', i)``)."""
 
@@ -124,7 +127,7 @@ class HipOps:
     def project(self, U, q, m, Xpart, totpart, n_chunks, S, outputscale, ksplit=None):
         self._chk(U)
         if ksplit is None:
-            ksplit = max(1, min(48, m // 128))
+            ksplit = max(1, min(PROJECT_KSPLIT_MAX, m // 128))
         work = self.empty((m * S if n_chunks > 1 else 0) + ksplit * q * S)
         out = self.empty(q + 1, S)
         check(self.lib.basq_project_f64(_ptr(U), q, m, _ptr(Xpart), _ptr(totpart), n_chunks, S, float(outputscale),
