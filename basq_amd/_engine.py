@@ -67,7 +67,8 @@ class TorchDistComm:
     def all_gather(self, t):
         """-> ``[world, *t.shape]`` (rank order).  Messages are tiny ((q+1) x S doubles): latency-bound."""
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        self.dist.all_gather(list(out.unbind(0)), t.contiguous(), group=self.group)
+        # ONE flat output buffer (RCCL: a single ncclAllGather, no per-rank output list / copy-out kernels)
+        self.dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=self.group)
         return out
 
     def broadcast(self, t, src=0):
@@ -205,6 +206,21 @@ def _gaussian_test_matrix(ops, m, q, trace=None):
     return R.view(m, q)
 
 
+def _skip_test_matrix_draw(ops, m, q):
+    """Advance the CPU global generator exactly as ``_gaussian_test_matrix(ops, m, q)`` does, without the device work.
+
+    Multi-rank runs draw the Gaussian test matrix on rank 0 and broadcast it; the other ranks call this, so that every
+    rank's global generator stays in lock-step with rank 0's -- a BASQ loop that samples its next pool from the global
+    RNG on every rank (as ``bench.py`` and ``PriorSampler`` do) keeps seeing ONE pool, not one per rank."""
+    n = m * q
+    if n < 16:
+        torch.randn(m, q, dtype=torch.float64)
+        return
+    ops.host_uniform(n, "rand_u")
+    if n % 16:
+        ops.host_uniform(16, "rand_ut")
+
+
 # Multi-rank: every rank reduces the gathered message itself (the kernels sum in a fixed order, so all ranks obtain
 # the same survivors bit for bit) instead of rank 0 reducing and broadcasting the result: one collective less per round.
 REPLICATED_REDUCTION = True
@@ -283,6 +299,7 @@ class _ShardedProducts:
         if self.comm.rank == 0:
             R = _gaussian_test_matrix(self.ops, self.m, q, trace).contiguous()
         else:
+            _skip_test_matrix_draw(self.ops, self.m, q)         # same generator consumption on every rank
             R = self.ops.empty(self.m, q)
         return self.comm.broadcast(R)
 
@@ -453,11 +470,21 @@ class RecombinationEngine:
         m, d = pts_nys.shape
         Rl = pts_local.shape[0]
         base, post, warp = kernel.base, kernel.posterior, kernel.warp
-        spec = base.spec(d)
-        kp = ops.kp(d)
+        # an opaque callable (the reference's own ``kernel`` contract): no packing, no fused kernel -- the candidates
+        # stay raw [R, d] rows and every round's block sums come from dense chunks (``_opaque_message``)
+        opaque = bool(getattr(kernel, "opaque", False))
+        if opaque and sober:
+            raise NotImplementedError("the SOBER variant needs a structured kernel (basq_amd.kernels)")
+        if getattr(kernel, "jitter", 0.0) != 0.0:
+            # wsabil/wsabim_kernel add `jitter` to entries [k][k] of every block (_wsabi.py:223,247), UNweighted by the
+            # warped means; the reference hard-codes jitter = 0 (_wsabi.py:56) and the fused path carries no such term
+            raise NotImplementedError("WsabiKernel.jitter != 0 is not supported by the fused recombination path")
+        spec = None if opaque else base.spec(d)
+        kp = d if opaque else ops.kp(d)
+        kscale = 1.0 if opaque else spec.outputscale
         t_all = time.perf_counter()
 
-        center = ops.col_mean(pts_nys)
+        center = None if opaque else ops.col_mean(pts_nys)
         q = min(num_pts - 1, m)                                 # rank of svd_lowrank's output (reduced QR clips at m)
         s = q + 1
         S = 2 * s                                               # :50
@@ -481,15 +508,17 @@ class RecombinationEngine:
             m_ext += 1
             q_ext = q + 1
             wrow = q + 1
-        nys_cat = torch.cat(nys_rows, 0) if len(nys_rows) > 1 else pts_nys
-        nys_ext = ops.pack(spec, nys_cat, center, ROLE_A, pad_rows_to=64)
-        if nys_ext.shape[0] < ((m_ext + 63) // 64) * 64:
-            nys_ext = torch.cat([nys_ext, ops.zeros(64, kp)], 0)
-        if wrow:
-            nys_ext[zero_row_idx].zero_()
+        nys_ext = None
+        if not opaque:
+            nys_cat = torch.cat(nys_rows, 0) if len(nys_rows) > 1 else pts_nys
+            nys_ext = ops.pack(spec, nys_cat, center, ROLE_A, pad_rows_to=64)
+            if nys_ext.shape[0] < ((m_ext + 63) // 64) * 64:
+                nys_ext = torch.cat([nys_ext, ops.zeros(64, kp)], 0)
+            if wrow:
+                nys_ext[zero_row_idx].zero_()
 
         # ---- candidate state ---------------------------------------------------------------------------
-        cand = ops.pack(spec, pts_local, center, ROLE_B)
+        cand = (pts_local if Rl > 0 else ops.zeros(1, d)) if opaque else ops.pack(spec, pts_local, center, ROLE_B)
         cand_raw = pts_local if warp == "wsabim" else None      # WSABI-M needs dense kernel blocks of the survivors
         mu, gid = ops.init_state(Rl, gid0, n_total)
         wx = None
@@ -531,7 +560,7 @@ class RecombinationEngine:
         #      for the range finder then overlaps with the largest kernel of the batch -----------------------
         pre = None
         late = None                                             # deferred part of the round-1 block sums
-        if R > S:
+        if R > S and not opaque:
             geo = RoundGeometry.of(R, S)
             n_chunks = choose_chunks(local_blocks(off, Rl, geo), m_ext, S, kp // 4)
             Xpart, totpart = ops.empty(n_chunks, m_ext, S), ops.empty(n_chunks, S)
@@ -556,7 +585,7 @@ class RecombinationEngine:
             pre = (Xpart, totpart, n_chunks)
 
         # ---- Nystrom basis (one Gaussian draw on rank 0, as in the reference) ----------------------------
-        if SHARDED_BASIS and comm.world > 1 and not sober:
+        if SHARDED_BASIS and comm.world > 1 and not sober and not opaque:
             # every rank builds its row block of the Gram matrix and takes part in the range finder (no broadcast of U)
             shards = initial_shards(m, comm.world)
             r0, mr = shards[comm.rank]
@@ -576,6 +605,7 @@ class RecombinationEngine:
                 assert U.shape[0] == q
             else:
                 U = ops.empty(q, m)
+                _skip_test_matrix_draw(ops, m, num_pts - 1)     # keep this rank's global generator in step with rank 0
                 if late is not None:
                     late()                                      # runs while rank 0 finishes the basis
             if comm.world > 1:
@@ -601,7 +631,7 @@ class RecombinationEngine:
         if wrow:
             sel = ops.zeros(1, m_ext)
             U_ext = torch.cat([torch.cat([U_ext, ops.zeros(q, 1)], 1), sel], 0)
-            U_ext[q, zero_row_idx] = 1.0 / spec.outputscale
+            U_ext[q, zero_row_idx] = 1.0 / kscale
         U_ext = U_ext.contiguous()
         diagU = Um if diag_noise != 0.0 else None
         if trace is not None:
@@ -624,7 +654,11 @@ class RecombinationEngine:
             S_r = R if final else S
             geo = RoundGeometry.of(R, S_r)
             t0 = time.perf_counter()
-            if pre is not None:
+            if opaque:
+                with _Timer(ops, trace, "blocksum"):
+                    Xpart, totpart = self._opaque_block_sums(kernel, pts_nys, cand, mu, Rl, off, geo.n_full, S_r, m)
+                n_chunks = 1
+            elif pre is not None:
                 Xpart, totpart, n_chunks = pre
                 pre = None
             else:
@@ -646,7 +680,7 @@ class RecombinationEngine:
                     totpart = torch.cat([totpart, ops.zeros(1, S_r)], 0)
                     n_chunks += 1
             with _Timer(ops, trace, "project"):
-                msg = ops.project(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S_r, spec.outputscale)
+                msg = ops.project(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S_r, kscale)
             if warp == "wsabim":
                 # + U @ (0.5 sum mu cov^2): the one term of wsabim_kernel that is not linear in the block sums
                 with _Timer(ops, trace, "wsabim_sq"):
@@ -712,8 +746,8 @@ class RecombinationEngine:
                 keep_rank = res[2 + 2 * M:2 + 3 * M].to(torch.int32)
                 tot = res[2 + 3 * M:].contiguous()
             else:
-                base = getattr(info, "_base", None)              # HipOps hands out views of one [info | kept] buffer
-                both = base if (base is not None and base.numel() == info.numel() + kept.numel()) \
+                ik_buf = getattr(info, "_base", None)            # HipOps hands out views of one [info | kept] buffer
+                both = ik_buf if (ik_buf is not None and ik_buf.numel() == info.numel() + kept.numel()) \
                     else torch.cat([info, kept])
                 head = ops.to_host(both, "head")                 # one D2H for status + survivor list
                 hl = head.tolist()
@@ -757,6 +791,42 @@ class RecombinationEngine:
         return idx, w
 
     # ------------------------------------------------------------------------------------------------
+    def _opaque_block_sums(self, kernel, pts_nys, cand, mu, Rl, off, n_full, S, m):
+        """Block sums of one round for an opaque callable: ``X_for_nys`` and ``tot_weights`` of ``_rchq.py:79-99`` as
+        ``(Xpart [1, m, S], totpart [1, S])``, same layout as ``basq_blocksum_f64`` with one chunk.
+
+        Chunked mode: ``C = kernel(pts_nys, chunk)`` ([m, nc] float64 on the device, at most ``chunk_bytes``) per chunk
+        of consecutive candidates, summed into the sets by ``basq_dense_blocksum_f64`` in position order (the set
+        weights through the same kernel with an all-ones row).  ``block_exact`` mode: the reference's own calls, one
+        ``kernel(pts_nys, block)`` per block of S points and one for the ragged tail (needed when the callable's value
+        depends on the block it is asked for, e.g. ``predictive_covariance``'s per-block noise diagonal)."""
+        ops = self.ops
+        E, T = ops.zeros(m, S), ops.zeros(1, S)
+        if Rl == 0:
+            return E.unsqueeze(0), T
+        if kernel.block_exact:
+            if self.comm.world > 1:
+                raise NotImplementedError("block_exact callables run on a single rank (blocks straddle shard borders)")
+            nb = n_full // S
+            for i in range(nb):                                   # _rchq.py:81-86, call for call
+                lo = i * S
+                Kb = kernel.dense(ops, pts_nys, cand[lo:lo + S])
+                ops.dense_blocksum(Kb, mu[lo:lo + S], lo, n_full, S, 1.0, E)
+            if Rl > n_full:                                       # :91-99 the remainder, one call
+                Kt = kernel.dense(ops, pts_nys, cand[n_full:Rl])
+                ops.dense_blocksum(Kt, mu[n_full:Rl], n_full, n_full, S, 1.0, E)
+            ones = ops.zeros(1, Rl) + 1.0
+            ops.dense_blocksum(ones, mu, 0, n_full, S, 1.0, T)
+            return E.unsqueeze(0), T
+        nc_max = max(S, min(Rl, kernel.chunk_bytes // (8 * m)))
+        ones = ops.zeros(1, min(nc_max, Rl)) + 1.0
+        for p0 in range(0, Rl, nc_max):
+            nc = min(nc_max, Rl - p0)
+            Kc = kernel.dense(ops, pts_nys, cand[p0:p0 + nc])
+            ops.dense_blocksum(Kc, mu[p0:p0 + nc], off + p0, n_full, S, 1.0, E)
+            ops.dense_blocksum(ones[:, :nc], mu[p0:p0 + nc], off + p0, n_full, S, 1.0, T)
+        return E.unsqueeze(0), T
+
     def _reduce_with_objective(self, msg, obj_live, obj_full, gid, mu, Rl, R, q, trace):
         """Single reduction with an objective row (``SOBER/_rchq.py:77-111``), one process.
 
@@ -830,7 +900,7 @@ class RecombinationEngine:
                 kappa = torch.where(pg < n_full, pg % S, pg - n_full)
                 hit = kappa < m
                 cov[kappa[hit], torch.arange(nc, device=cov.device)[hit]] += diag_noise
-            ops.dense_sq_blocksum(cov, mu[p0:p0 + nc], off + p0, n_full, S, 0.5, E)
+            ops.dense_blocksum(cov, mu[p0:p0 + nc], off + p0, n_full, S, 0.5, E, square=True)
         return E
 
     # ------------------------------------------------------------------------------------------------

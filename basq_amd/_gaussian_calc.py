@@ -71,10 +71,17 @@ class GaussianCalc:
         return self._ops
 
     def get_cache(self, model):
-        """``:18-42`` -> (woodbury_vector, woodbury_inv = S S^T)."""
-        ps = model.prediction_strategy
-        S = ps.covar_cache
-        return ps.mean_cache, S @ S.T
+        """``:18-42`` -> (woodbury_vector, woodbury_inv = S S^T).  When the caches do not exist yet (a freshly trained
+        model: ``prediction_strategy`` is None) the reference evaluates the model once at the prior mean to build
+        them (``:35-38``); same here."""
+        from .kernels import _prediction_caches
+
+        warm = None
+        if getattr(model, "prediction_strategy", None) is None or \
+                not hasattr(model.prediction_strategy, "covar_cache"):
+            warm = self.prior.loc.view(-1).unsqueeze(0)                       # :36
+        mean_cache, S = _prediction_caches(model, warm)
+        return mean_cache, S @ S.T
 
     def parameters_extraction(self, model):
         ops = self._get_ops()

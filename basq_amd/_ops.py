@@ -186,13 +186,17 @@ class HipOps:
               "basq_init_state_f64")
         return mu, gid
 
-    def dense_sq_blocksum(self, Cmat, mu_chunk, pg0, n_full, S, scale, E):
-        """E[j, s] += scale * sum_{p in chunk, set(p)=s} mu_p * C[j, p]^2  (in place on E)."""
-        self._chk(Cmat)
+    def dense_blocksum(self, Cmat, mu_chunk, pg0, n_full, S, scale, E, square=False):
+        """E[j, s] += scale * sum_{p in chunk, set(p)=s} mu_p * C[j, p]  (``square``: ... * C[j, p]^2); in place on E.
+
+        ``Cmat`` may be a row-strided view (``stride(1) == 1``) of a wider buffer."""
         self._chk(E)
+        if Cmat.dtype != torch.float64 or Cmat.stride(1) != 1:
+            raise ValueError("expected a float64 matrix with unit column stride")
         m, nc = Cmat.shape
-        check(self.lib.basq_dense_sq_blocksum_f64(_ptr(Cmat), m, nc, nc, _ptr(mu_chunk), pg0, n_full, S, float(scale),
-                                                  _ptr(E), self._stream()), "basq_dense_sq_blocksum_f64")
+        check(self.lib.basq_dense_blocksum_f64(_ptr(Cmat), m, nc, Cmat.stride(0), _ptr(mu_chunk), pg0, n_full, S,
+                                               float(scale), 1 if square else 0, _ptr(E), self._stream()),
+              "basq_dense_blocksum_f64")
 
     def box_muller(self, u, u_tail=None):
         """Normals from torch's uniforms (see basq_box_muller_f64); u on the device, n >= 16."""

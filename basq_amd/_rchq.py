@@ -11,9 +11,11 @@ Same name, argument order, return convention and RNG consumption as the referenc
 
 Differences that are part of the design:
 
-* ``kernel`` must be one of :mod:`basq_amd.kernels` (``StationaryKernel`` / ``PosteriorKernel`` /
-  ``WsabiKernel``, or ``from_gpytorch_model(model, ...)``) -- the fused GPU path needs the kernel's
-  structure, it cannot call an opaque Python callable per block;
+* ``kernel``: the objects of :mod:`basq_amd.kernels` (``StationaryKernel`` / ``PosteriorKernel`` /
+  ``WsabiKernel``, or ``from_gpytorch_model(model, ...)``) take the fused GPU path, which needs the kernel's
+  structure; any OTHER callable ``(X[a,d], Y[b,d]) -> Tensor[a,b]`` -- the reference's contract, tutorial 02 --
+  is evaluated on the device chunk by chunk and block-summed by ``basq_dense_blocksum_f64``
+  (``kernels.CallableKernel``: correct for every kernel, HBM-bound instead of fused);
 * arithmetic is float64 whatever the default dtype (SURVEY finding 3: the reference's selection is only
   reproducible in float64);
 * ``device`` must be a HIP device (``torch.device('cuda', i)``); there is no CPU path.
@@ -26,25 +28,30 @@ from ._engine import EngineTrace, LocalComm, RecombinationEngine, TorchDistComm
 from ._ops import HipOps
 
 
-def _require_structured(kernel):
-    if not all(hasattr(kernel, a) for a in ("base", "posterior", "warp", "dense")):
-        raise TypeError(
-            "basq_amd.recombination needs a structured kernel (basq_amd.kernels.StationaryKernel / "
-            "PosteriorKernel / WsabiKernel or from_gpytorch_model(...)); got %r" % (type(kernel),)
-        )
+def _as_kernel_object(kernel):
+    """Structured kernels pass through (fused path); any other callable is the reference's opaque ``kernel``
+    argument (``BASQ/_rchq.py:8,16``) and runs through the chunked dense path (``kernels.CallableKernel``)."""
+    if all(hasattr(kernel, a) for a in ("base", "posterior", "warp", "dense")):
+        return kernel
+    if callable(kernel):
+        from .kernels import CallableKernel
+
+        return CallableKernel(kernel)
+    raise TypeError("kernel must be a basq_amd.kernels object or a callable (X[a,d], Y[b,d]) -> Tensor[a,b]; got %r"
+                    % (type(kernel),))
 
 
 def recombination(
     pts_rec,          # random samples for recombination          [N, d]
     pts_nys,          # samples for the Nystrom approximation       [m, d]
     num_pts,          # number of samples finally returned (batch size)
-    kernel,           # structured kernel object (basq_amd.kernels)
+    kernel,           # basq_amd.kernels object (fused path) or any callable (X, Y) -> Tensor (chunked dense path)
     device,           # HIP device
     init_weights=0,   # ignored, as in the reference
     *,
     trace: EngineTrace | None = None,
 ):
-    _require_structured(kernel)
+    kernel = _as_kernel_object(kernel)
     ops = HipOps(device)
     eng = RecombinationEngine(ops, LocalComm())
     N = pts_rec.shape[0]
@@ -59,7 +66,7 @@ def recombination_sharded(pts_local, gid0, n_total, pts_nys, num_pts, kernel, de
     Slices must tile ``0..n_total`` in rank order; ``pts_nys`` identical on all ranks.  The result is
     identical on every rank and equal (indices) to the single-GPU result.
     """
-    _require_structured(kernel)
+    kernel = _as_kernel_object(kernel)
     ops = HipOps(device)
     eng = RecombinationEngine(ops, TorchDistComm(group))
     return eng.run(pts_local, int(gid0), int(n_total), pts_nys, int(num_pts), kernel, trace)

@@ -2208,35 +2208,68 @@ __global__ void __launch_bounds__(1024) chol_packed_lds_kernel(double* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// Block sums of the SQUARE of a dense per-pair matrix (WSABI-M's 0.5 cov^2 term, BASQ/_wsabi.py:240-242):
-//     E[j][s] += scale * sum_{p in chunk, set(p) = s} mu_p * C[j][p]^2
-// C [m, nc] holds the posterior covariances of the Nystrom rows against nc consecutive candidates whose
-// first global position is pg0.  One thread per (j, s): candidates of a set are visited in position order,
-// chunks are launched in order, so the sum has a fixed order.  Reads of C are coalesced along s.
+// Block sums of a dense per-pair matrix handed over by the caller:
+//     E[j][s] += scale * sum_{p in chunk, set(p) = s} mu_p * C[j][p]        (SQ = false)
+//     E[j][s] += scale * sum_{p in chunk, set(p) = s} mu_p * C[j][p]^2      (SQ = true)
+// SQ = false is the hot loop of BASQ/_rchq.py:79-99 for an OPAQUE kernel callable (the reference's `kernel` argument is
+// any Python callable; C = kernel(pts_nys, chunk of candidates) is evaluated by the caller, on the device);
+// SQ = true is WSABI-M's 0.5 cov^2 term (BASQ/_wsabi.py:240-242).
+// C [m, nc] holds the values of the Nystrom rows against nc consecutive candidates whose first global position is pg0.
+// A work-group owns JR rows and all S sets: thread = set, so consecutive lanes read consecutive candidates of a
+// row (coalesced 512-B wave loads) and every (row, set) sum runs in position order; chunks are launched in position
+// order, hence a fixed summation order overall.  HBM-bound by construction: 8 B per pair, read once.
 // ------------------------------------------------------------------------------------------------
-__global__ void dense_sq_blocksum_kernel(const double* __restrict__ C, int m, long long nc, long long ldc,
-                                         const double* __restrict__ mu, long long pg0, long long n_full, int S,
-                                         double scale, double* __restrict__ E) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
-    if (s >= S || j >= m) return;
-    const double* row = C + (long long)j * ldc;
-    double acc = 0.0;
-    // block positions of set s inside [pg0, pg0 + nc)
-    const long long blk_end = (pg0 + nc < n_full) ? (pg0 + nc) : n_full;
-    long long p = pg0 + ((s - pg0 % S) % S + S) % S;          // first global position >= pg0 congruent to s
-    for (; p < blk_end; p += S) {
-        const double c = row[p - pg0];
-        acc = __builtin_fma(mu[p - pg0] * c, c, acc);
-    }
-    if (s == S - 1) {                                           // ragged tail: positions >= n_full
-        long long t = (n_full > pg0) ? n_full : pg0;
-        for (; t < pg0 + nc; ++t) {
-            const double c = row[t - pg0];
-            acc = __builtin_fma(mu[t - pg0] * c, c, acc);
+template <int JR, bool SQ>
+__global__ void __launch_bounds__(256) dense_blocksum_kernel(const double* __restrict__ C, int m, long long nc,
+                                                             long long ldc, const double* __restrict__ mu,
+                                                             long long pg0, long long n_full, int S, double scale,
+                                                             double* __restrict__ E) {
+    const int j0 = blockIdx.x * JR;
+    const double* rows[JR];
+#pragma unroll
+    for (int jr = 0; jr < JR; ++jr) rows[jr] = C + (long long)((j0 + jr < m) ? (j0 + jr) : (m - 1)) * ldc;
+    const long long blk_end = (pg0 + nc < n_full) ? (pg0 + nc) : n_full;     // end of the block positions of this chunk
+    for (int s = threadIdx.x; s < S; s += 256) {
+        double acc[JR];
+#pragma unroll
+        for (int jr = 0; jr < JR; ++jr) acc[jr] = 0.0;
+        long long o = ((s - pg0 % S) % S + S) % S;                            // first chunk offset whose position = s mod S
+        const long long oe = blk_end - pg0;
+        // two positions per trip: 2 JR + 2 independent loads in flight per lane
+        for (; o + S < oe; o += 2 * (long long)S) {
+            const double w0 = mu[o], w1 = mu[o + S];
+            double c0[JR], c1[JR];
+#pragma unroll
+            for (int jr = 0; jr < JR; ++jr) { c0[jr] = rows[jr][o]; c1[jr] = rows[jr][o + S]; }
+#pragma unroll
+            for (int jr = 0; jr < JR; ++jr) {
+                acc[jr] = __builtin_fma(SQ ? w0 * c0[jr] : w0, c0[jr], acc[jr]);
+                acc[jr] = __builtin_fma(SQ ? w1 * c1[jr] : w1, c1[jr], acc[jr]);
+            }
         }
+        for (; o < oe; o += S) {
+            const double w0 = mu[o];
+#pragma unroll
+            for (int jr = 0; jr < JR; ++jr) {
+                const double c = rows[jr][o];
+                acc[jr] = __builtin_fma(SQ ? w0 * c : w0, c, acc[jr]);
+            }
+        }
+        if (s == S - 1) {                                                     // ragged tail: positions >= n_full
+            long long t = ((n_full > pg0) ? n_full : pg0) - pg0;
+            for (; t < nc; ++t) {
+                const double w0 = mu[t];
+#pragma unroll
+                for (int jr = 0; jr < JR; ++jr) {
+                    const double c = rows[jr][t];
+                    acc[jr] = __builtin_fma(SQ ? w0 * c : w0, c, acc[jr]);
+                }
+            }
+        }
+#pragma unroll
+        for (int jr = 0; jr < JR; ++jr)
+            if (j0 + jr < m) E[(long long)(j0 + jr) * S + s] += scale * acc[jr];
     }
-    E[(long long)j * S + s] += scale * acc;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2498,7 +2531,7 @@ int basq_reweight_compact_f64(const double* cand, const double* mu, const int64_
                               int64_t new_off, double* cand_out, double* mu_out, int64_t* gid_out, double* wx_out,
                               void* stream) {
     if (!cand || !mu || !gid || !keep_rank || !w_star || !tot || !cand_out || !mu_out || !gid_out) return BASQ_EINVAL;
-    if (Rl < 0 || S < 1 || kp < 4 || n_keep < 0 || (wx && !wx_out)) return BASQ_EINVAL;
+    if (Rl < 0 || S < 1 || kp < 1 || n_keep < 0 || (wx && !wx_out)) return BASQ_EINVAL;
     if (Rl == 0) return BASQ_OK;
     const long long nt = (long long)Rl * kp;
     hipLaunchKernelGGL(reweight_compact_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
@@ -2532,14 +2565,19 @@ int basq_box_muller_f64(const double* u, int64_t n, const double* u_tail, double
     return BASQ_OK;
 }
 
-int basq_dense_sq_blocksum_f64(const double* C, int32_t m, int64_t nc, int64_t ldc, const double* mu, int64_t pg0,
-                               int64_t n_full, int32_t S, double scale, double* E, void* stream) {
+int basq_dense_blocksum_f64(const double* C, int32_t m, int64_t nc, int64_t ldc, const double* mu, int64_t pg0,
+                            int64_t n_full, int32_t S, double scale, int32_t square, double* E, void* stream) {
     if (!C || !mu || !E || m < 1 || nc < 0 || ldc < nc || pg0 < 0 || n_full < 0 || S < 1 || n_full % S != 0)
         return BASQ_EINVAL;
     if (nc == 0) return BASQ_OK;
-    dim3 grid((unsigned)((S + 63) / 64), (unsigned)m);
-    hipLaunchKernelGGL(dense_sq_blocksum_kernel, grid, dim3(64), 0, (hipStream_t)stream, C, m, (long long)nc,
-                       (long long)ldc, mu, (long long)pg0, (long long)n_full, S, scale, E);
+    constexpr int JR = 4;
+    const dim3 grid((unsigned)((m + JR - 1) / JR)), block(256);
+    if (square)
+        hipLaunchKernelGGL((dense_blocksum_kernel<JR, true>), grid, block, 0, (hipStream_t)stream, C, m, (long long)nc,
+                           (long long)ldc, mu, (long long)pg0, (long long)n_full, S, scale, E);
+    else
+        hipLaunchKernelGGL((dense_blocksum_kernel<JR, false>), grid, block, 0, (hipStream_t)stream, C, m, (long long)nc,
+                           (long long)ldc, mu, (long long)pg0, (long long)n_full, S, scale, E);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }

@@ -18,6 +18,12 @@ and additionally expose what the fused recombination kernels need:
 
 ``from_gpytorch_model`` builds them from a fitted gpytorch model by attribute access only (gpytorch
 itself is not imported).
+
+``CallableKernel`` keeps the reference's own contract for everything else: ANY callable ``(X, Y) -> Tensor[a, b]``
+(tutorial 02, "BayesQuad with arbitrary kernel"; BASELINE config 4 names this path).  The callable is evaluated on
+the device in chunks of candidates and the block sums are taken by ``basq_dense_blocksum_f64`` -- the unfused,
+HBM-bound form (8 bytes per pair) -- so the structured classes remain the fast path; ``recombination`` wraps a
+bare callable automatically.
 """
 from __future__ import annotations
 
@@ -199,6 +205,60 @@ class WsabiKernel:
         return self.alpha + 0.5 * (mu_w ** 2 + self.posterior.gp_variance(ops, x, center))
 
 
+class CallableKernel:
+    """An opaque kernel callable, the reference's ``kernel`` argument as is (``BASQ/_rchq.py:8,16``).
+
+    ``fn(X[a, d], Y[b, d]) -> Tensor[a, b]`` is called with tensors on the HIP device (``input_dtype``, float64 by
+    default) under ``torch.no_grad()``; its result is cast to float64.  Two evaluation modes:
+
+    * chunked (default): ``fn(pts_nys, chunk)`` for chunks of up to ``chunk_bytes / (8 m)`` consecutive candidates;
+    * ``block_exact=True``: exactly the reference's calls -- one ``fn(pts_nys, block of 2n points)`` per block
+      (``_rchq.py:81-86``) and one for the ragged tail (``:91-99``).  Needed only for callables whose value depends
+      on the shape of the block they are asked for, like ``predictive_covariance``, which adds the likelihood
+      noise to entries ``[k][k]`` of EVERY block (``BASQ/_gp.py:275-276``); N/(2n) Python calls per round.
+    """
+
+    opaque = True
+    base = None
+    posterior = None
+    warp = "none"
+
+    def __init__(self, fn, block_exact: bool = False, chunk_bytes: int = 256 << 20, input_dtype=torch.float64):
+        if not callable(fn):
+            raise TypeError("CallableKernel needs a callable (X, Y) -> Tensor")
+        self.fn = fn
+        self.block_exact = bool(block_exact)
+        self.chunk_bytes = int(chunk_bytes)
+        self.input_dtype = input_dtype
+
+    def dense(self, ops, x, y, center=None, diag_offset=0):
+        with torch.no_grad():
+            K = self.fn(x.to(self.input_dtype), y.to(self.input_dtype))
+        K = K.to_dense() if hasattr(K, "to_dense") else K        # gpytorch lazy tensors / linear operators
+        if not torch.is_tensor(K) or tuple(K.shape) != (x.shape[0], y.shape[0]):
+            raise ValueError("kernel callable must return a dense [len(X), len(Y)] tensor; got %r"
+                             % (getattr(K, "shape", type(K)),))
+        return ops.to_device(K.detach(), torch.float64)
+
+    def __call__(self, x, y):
+        return self.fn(x, y)
+
+
+def _prediction_caches(model, warm_x):
+    """``(mean_cache, covar_cache)`` of a gpytorch ExactGP, warming them up the way the reference does when they do
+    not exist yet (``BASQ/_gp.py:247-253``, ``BASQ/_gaussian_calc.py:32-38``): a freshly trained model, or one put
+    back into train mode, has ``prediction_strategy = None`` -> ``model.eval(); model(one point)`` builds it."""
+    try:
+        ps = model.prediction_strategy
+        return ps.mean_cache, ps.covar_cache
+    except AttributeError:
+        model.eval()
+        with torch.no_grad():
+            model(warm_x)
+        ps = model.prediction_strategy
+        return ps.mean_cache, ps.covar_cache
+
+
 def from_gpytorch_model(model, kind: str = "predictive", wsabi_label: str = "wsabil", wsabi_alpha: float = 0.0):
     """Build a kernel object from a fitted gpytorch ``ExactGP`` (duck-typed; gpytorch is not imported).
 
@@ -226,8 +286,8 @@ def from_gpytorch_model(model, kind: str = "predictive", wsabi_label: str = "wsa
         return base
     Xobs = model.train_inputs[0].detach()
     noise = float(model.likelihood.noise.detach().reshape(-1)[0])
-    S = model.prediction_strategy.covar_cache.detach()
-    mean_cache = model.prediction_strategy.mean_cache.detach()
+    mean_cache, S = _prediction_caches(model, Xobs[0].unsqueeze(0))      # _gp.py:247-253 (incl. the warm-up call)
+    mean_cache, S = mean_cache.detach().reshape(-1), S.detach()
     const = float(model.mean_module.constant.detach().reshape(-1)[0])
     post = PosteriorKernel(base, Xobs, S @ S.T, noise, const, mean_cache)       # _gp.py:255
     if kind == "predictive":

@@ -18,12 +18,12 @@ import torch
 
 from ._engine import EngineTrace, LocalComm, RecombinationEngine
 from ._ops import HipOps
-from ._rchq import _require_structured
+from ._rchq import _as_kernel_object
 
 
 def recombination(pts_rec, pts_nys, num_pts, kernel, device, dtype=torch.float64, init_weights=None, calc_obj=None, *,
                   trace: EngineTrace | None = None):
-    _require_structured(kernel)
+    kernel = _as_kernel_object(kernel)
     eng = RecombinationEngine(HipOps(device), LocalComm())
     objective = None if calc_obj is None else -1 * calc_obj(pts_rec)            # :67-69
     return eng.run(pts_rec, 0, pts_rec.shape[0], pts_nys, int(num_pts), kernel, trace, variant="sober",

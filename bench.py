@@ -30,8 +30,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_FP64_VECTOR_TFLOPS = 78.6      # MI355X: 256 CU x 128 flop/clk x 2.4 GHz (fp64 vector == fp64 matrix peak)
+PEAK_FP64_VECTOR_TFLOPS = 78.6      # MI355X nominal: 256 CU x 128 flop/clk x 2.4 GHz (fp64 vector == fp64 matrix peak)
+# What the part sustains in a register-only micro-benchmark (tools/microbench.hip, profiles/r01_microbench_fp64_rates.txt,
+# 4 waves/SIMD): v_fma_f64 only 69.6 TF/s, v_mfma_f64_16x16x4 only 48.3 TF/s, the two interleaved 61.4 TF/s.  The
+# block-sum kernel is such a mix, so 61.4 is its practical ceiling; ``frac`` stays against the nominal figure.
+MEASURED_FP64_TFLOPS = {"fma_only": 69.6, "mfma_only": 48.3, "mixed_fma_mfma": 61.4}
 PEAK_HBM_GBS = 8000.0
+POOL_SEEDS = (0, 1, 2, 3, 4)        # seeds 0-4, median
 
 WORKLOAD = dict(N=1_000_000, d=10, n=100, nys_ratio=1e-2, family="rbf", lengthscale=2.0, outputscale=1.0, pool_seed=0)
 
@@ -46,6 +51,7 @@ def parse():
     ap.add_argument("--n", type=int, default=WORKLOAD["n"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-stride", type=int, default=0, help="run every k-th hot-loop block on the CPU (0 = auto)")
+    ap.add_argument("--cpu-threads", type=str, default="", help="comma list of CPU thread counts (default: 8 and all cores)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-phase host timer breakdown to stderr")
     return ap.parse_args()
 
@@ -83,17 +89,23 @@ def main():
     N, d, n = args.N, args.d, args.n
     m = int(N * WORKLOAD["nys_ratio"])
     kern = basq_amd.kernels.StationaryKernel(WORKLOAD["family"], WORKLOAD["lengthscale"], WORKLOAD["outputscale"])
-    pool = gmm_pool(N, d, WORKLOAD["pool_seed"])                     # every rank regenerates the same pool
+    # pools of seeds 0-4, all resident in HBM before the clock starts (5 x 80 MB); step k uses pool k % 5.
+    # Every rank regenerates the same pools (bit-reproducible generator) and keeps its contiguous slice.
     off, Rl = initial_shards(N, world)[rank]
-    pts_nys = pool[:m].to(dev)                                       # PriorSampler: prefix of the pool
-    pts_local = pool[off:off + Rl].to(dev)                           # resident before the clock starts
-    if world == 1:
-        pool_dev = pts_local
+    pools_dev = []
+    pool = None
+    for sd in POOL_SEEDS:
+        p = gmm_pool(N, d, sd)
+        if sd == POOL_SEEDS[0]:
+            pool = p                                                 # host copy of seed 0: the CPU baseline's input
+        pools_dev.append((p[:m].to(dev), p[off:off + Rl].to(dev)))   # PriorSampler: pts_nys = prefix of the pool
+        del p
 
-    def one_batch(trace=None):
+    def one_batch(trace=None, k=0):
+        pts_nys, pts_local = pools_dev[k % len(pools_dev)]
         torch.manual_seed(1)                                         # manual_seed(1) before each call
         if world == 1 and not force_dist:
-            return basq_amd.recombination(pool_dev, pts_nys, n, kern, dev, trace=trace)
+            return basq_amd.recombination(pts_local, pts_nys, n, kern, dev, trace=trace)
         return basq_amd.recombination_sharded(pts_local, off, N, pts_nys, n, kern, dev, trace=trace)
 
     def barrier():
@@ -101,18 +113,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_batch()
+    for k in range(args.warmup):
+        one_batch(k=k)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        idx, w = one_batch()
+    for k in range(args.steps):
+        idx, w = one_batch(k=k)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+
+    # ---- per-seed latencies (outside the timed region): one synchronised batch per pool seed, median reported ----
+    per_seed_ms = []
+    for k in range(len(POOL_SEEDS)):
+        barrier()
+        t1 = time.perf_counter()
+        one_batch(k=k)
+        barrier()
+        per_seed_ms.append(1e3 * (time.perf_counter() - t1))
 
     # ---- kernel-level roofline: one extra traced batch (HIP events on the launch stream, no host syncs) ----
     tr = basq_amd.EngineTrace(time_kernels=True, host_sync=False)
@@ -147,19 +168,31 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle.cpu_baseline import sampled_batch_seconds
+        from oracle.cpu_baseline import baseline_matrix
         from oracle.kernels_oracle import StationaryOracle
 
-        stride = args.cpu_stride or max(1, N // 50_000)             # ~10-30 s of CPU work at N=1e6
-        torch.manual_seed(1)
-        res = sampled_batch_seconds(pool, pool[:m], n, StationaryOracle(WORKLOAD["family"], WORKLOAD["lengthscale"],
-                                                                        WORKLOAD["outputscale"]), stride)
+        # SURVEY §8d matrix: {float64, float32} x {8 threads, all host cores}; ~5 s of CPU work per cell at N=1e6
+        stride = args.cpu_stride or max(1, N // 25_000)
+        ncpu = os.cpu_count() or 1
+        threads = [int(t) for t in args.cpu_threads.split(",") if t] or sorted({min(8, ncpu), ncpu})
+        cells = baseline_matrix(pool, pool[:m], n, StationaryOracle(WORKLOAD["family"], WORKLOAD["lengthscale"],
+                                                                    WORKLOAD["outputscale"]), stride, seed=1,
+                                thread_counts=threads)
+        f64 = [c for c in cells if c["dtype"] == "float64"]
+        f32 = [c for c in cells if c["dtype"] == "float32"]
+        best = min(f64, key=lambda c: c["seconds_per_batch"])        # parity-mode arithmetic (same as the GPU path)
+        best32 = min(f32, key=lambda c: c["seconds_per_batch"])
         cpu = dict(
-            value=1.0 / res["seconds_per_batch"], unit="batches/s", cores=torch.get_num_threads(), kind="port",
-            sample=(f"oracle (reference op sequence, float64, torch CPU) on the same pool: Gram+svd_lowrank, all "
-                    f"{res['n_rounds']} rounds' projection/SVD/elimination in full; hot loop every {stride}th block "
-                    f"({res['kernel_calls_run']}/{res['kernel_calls_total']} kernel calls), loop time scaled; "
-                    f"{res['measured_seconds']:.1f}s measured -> {res['seconds_per_batch']:.1f}s/batch"),
+            value=1.0 / best["seconds_per_batch"], unit="batches/s", cores=best["threads"], kind="port",
+            dtype="f64", host_cores=ncpu,
+            value_f32=1.0 / best32["seconds_per_batch"], cores_f32=best32["threads"],
+            matrix=[dict(dtype=c["dtype"], threads=c["threads"], seconds_per_batch=round(c["seconds_per_batch"], 2),
+                         measured_seconds=round(c["measured_seconds"], 2)) for c in cells],
+            sample=(f"oracle (reference op sequence, torch CPU) on pool seed 0: Gram+svd_lowrank, all "
+                    f"{best['n_rounds']} rounds' projection/SVD/elimination in full; hot loop every {stride}th block "
+                    f"({best['kernel_calls_run']}/{best['kernel_calls_total']} kernel calls), loop time scaled; value = "
+                    f"fastest float64 cell ({best['threads']} threads: {best['measured_seconds']:.1f}s measured -> "
+                    f"{best['seconds_per_batch']:.1f}s/batch); un-sampled anchor: profiles/r02_cpu_full_batch.txt"),
         )
 
     if rank == 0:
@@ -172,21 +205,31 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
+            "median_ms_per_seed": sorted(per_seed_ms)[len(per_seed_ms) // 2],
+            "ms_per_seed": [round(v, 3) for v in per_seed_ms],
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"RBF kernel l=2, N={N} candidates, d={d}, n={n} recombination, m={m} Nystrom points, "
-                                   f"float64, pool sharded over {world} GPU(s)",
+                                   f"float64, pool sharded over {world} GPU(s); pool seeds {list(POOL_SEEDS)} cycled over steps",
                        "N": N, "d": d, "n": n, "m": m, "kernel": "rbf", "parallelism": f"pool-sharded x{world}"},
             "roofline": {
-                "bound": "mfma",
+                # contract vocabulary is hbm|mfma: this kernel is bound by the fp64 PIPE, which f64 MFMA and fp64 VALU share
+                # on gfx950 (roughly half of its busy cycles are MFMA, half the VALU exp epilogue) -- neither HBM nor a
+                # GEMM-shaped MFMA bound; "bound_detail" says so.
+                "bound": "mfma", "bound_detail": "fp64 pipe (f64 MFMA + fp64 VALU share one datapath); not HBM",
                 "kernel": "blocksum_kernel (fused pairwise-kernel block sums, BASQ/_rchq.py:79-99)",
                 "achieved": achieved_tf, "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tf / PEAK_FP64_VECTOR_TFLOPS,
+                "peak_measured": MEASURED_FP64_TFLOPS["mixed_fma_mfma"],
+                "frac_of_measured_peak": achieved_tf / MEASURED_FP64_TFLOPS["mixed_fma_mfma"],
+                "peak_measured_source": "profiles/r01_microbench_fp64_rates.txt (fma-only 69.6, mfma-only 48.3, mixed 61.4 TF/s)",
                 "traffic": traffic,
+                "traffic_source": ("committed PMC pass, not measured in this run: " + traffic_src) if traffic_src else None,
                 "fp64_pipe_busy_pmc": pipe_busy,
+                "fp64_pipe_busy_source": "committed PMC pass (same file), not measured in this run" if pipe_busy else None,
                 "launches_per_batch": k_launches, "kernel_ms_per_batch": k_ms, "pairs_per_batch": k_pairs,
                 "flops_per_pair": 3 * d + 3,
                 "hbm_algorithmic_GBs": bytes_alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,

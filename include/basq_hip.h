@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BASQ_ABI_VERSION 2
+#define BASQ_ABI_VERSION 3
 
 /* error codes */
 #define BASQ_OK            0
@@ -190,15 +190,20 @@ int basq_reweight_compact_f64(const double* cand, const double* mu, const int64_
 int basq_init_state_f64(double* mu, int64_t* gid, int64_t Rl, int64_t gid0, int64_t n_total, void* stream);
 
 /*
- * WSABI-M extra term (BASQ/_wsabi.py:227-249: CLy = mu_x cov mu_y + 0.5 cov^2; the first product is linear in
- * the block sums and runs through basq_blocksum_f64, the square is not):
- *     E[j][s] += scale * sum over the nc candidates p of this chunk with set(p) = s of  mu[p] * C[j][p]^2
- * C [m, nc] (row stride ldc) = posterior covariances of the Nystrom rows against nc consecutive candidates
- * whose first GLOBAL position is pg0 (set(p) = p % S below n_full, S-1 from n_full on); mu is indexed from
- * the chunk start.  E [m, S] is accumulated into (zero it first); chunks must be submitted in position order.
+ * Block sums of a dense per-pair matrix the CALLER evaluated (two users):
+ *   square == 0: the hot loop BASQ/_rchq.py:79-99 for an opaque `kernel` callable (the reference accepts ANY Python
+ *                callable (X[a,d], Y[b,d]) -> Tensor[a,b], BASQ/_rchq.py:8,16; tutorial 02 "arbitrary kernel"):
+ *                C = kernel(pts_nys, chunk) is produced by the callable on the device, chunk by chunk, and
+ *                    E[j][s] += scale * sum over the nc candidates p of this chunk with set(p) = s of  mu[p] * C[j][p]
+ *   square != 0: WSABI-M's extra term (BASQ/_wsabi.py:227-249: CLy = mu_x cov mu_y + 0.5 cov^2; the first product is
+ *                linear in the block sums and runs through basq_blocksum_f64, the square is not):
+ *                    E[j][s] += scale * sum ... mu[p] * C[j][p]^2
+ * C [m, nc] (row stride ldc) = values of the Nystrom rows against nc consecutive candidates whose first GLOBAL
+ * position is pg0 (set(p) = p % S below n_full, S-1 from n_full on); mu is indexed from the chunk start.
+ * E [m, S] is accumulated into (zero it first); chunks must be submitted in position order (fixed summation order).
  */
-int basq_dense_sq_blocksum_f64(const double* C, int32_t m, int64_t nc, int64_t ldc, const double* mu, int64_t pg0,
-                               int64_t n_full, int32_t S, double scale, double* E, void* stream);
+int basq_dense_blocksum_f64(const double* C, int32_t m, int64_t nc, int64_t ldc, const double* mu, int64_t pg0,
+                            int64_t n_full, int32_t S, double scale, int32_t square, double* E, void* stream);
 
 /*
  * Gaussian test matrix of torch.svd_lowrank (BASQ/_rchq.py:29 -> torch._lowrank: R = torch.randn(m, q)): the

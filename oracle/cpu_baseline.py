@@ -10,6 +10,12 @@ scaled by the inverse of the executed fraction.  Everything else -- Gram matrix,
 every round's projection, SVD and elimination, the re-weighting -- runs and is timed as is.  Skipping
 blocks changes the block sums, hence which sets survive, but not the round structure (each round keeps
 <= n of 2n sets), so the per-round sizes and the number of rounds are those of a real batch.
+
+SURVEY §8d asks for the matrix {float64, float32} x {8 threads, all host cores}: ``baseline_matrix``.
+The hot loop is thousands of ``[m, 2n]`` kernel blocks: with every core of a many-core host in the MKL/OpenMP
+team they thrash (round 1 recorded 547 s vs 31 s for the same batch), so the thread count is part of the
+result and the faster setting is the one reported.  ``python -m oracle.cpu_baseline --full`` runs ONE
+un-sampled batch (``stride=1``) to anchor the extrapolation (``profiles/r02_cpu_full_batch.txt``).
 """
 from __future__ import annotations
 
@@ -20,28 +26,59 @@ import torch
 from .rchq_oracle import caratheodory_reduce, nystrom_basis
 
 
-def sampled_batch_seconds(pts_rec, pts_nys, num_pts, kernel, stride: int = 8):
-    """-> dict(seconds_per_batch, measured_seconds, loop_fraction, n_rounds, kernel_calls_total, kernel_calls_run)."""
+def sampled_batch_seconds(pts_rec, pts_nys, num_pts, kernel, stride: int = 8, dtype=torch.float64,
+                          threads: int | None = None):
+    """-> dict(seconds_per_batch, measured_seconds, loop_fraction, n_rounds, kernel_calls_total, kernel_calls_run,
+    threads, dtype).  ``threads``: ``torch.set_num_threads`` for the duration of the call (None = leave as is)."""
     prev = torch.get_default_dtype()
-    torch.set_default_dtype(torch.float64)
+    prev_threads = torch.get_num_threads()
+    torch.set_default_dtype(dtype)
+    if threads:
+        torch.set_num_threads(int(threads))
     try:
-        return _run(pts_rec, pts_nys, num_pts, kernel, max(1, int(stride)))
+        # warm-up at this dtype / team size (first-use costs of MKL's thread team and LAPACK workspaces: ~1 s otherwise
+        # lands in the Gram + svd_lowrank timer of the first cell)
+        nw = min(len(pts_rec), 4000)
+        _run(pts_rec[:nw].to(dtype), pts_nys[:max(1, min(len(pts_nys), nw // 20))].to(dtype), num_pts, kernel, 1)
+        res = _run(pts_rec.to(dtype), pts_nys.to(dtype), num_pts, kernel, max(1, int(stride)))
+        res["threads"] = torch.get_num_threads()
+        res["dtype"] = str(dtype).replace("torch.", "")
+        return res
     finally:
         torch.set_default_dtype(prev)
+        if threads:
+            torch.set_num_threads(prev_threads)
+
+
+def baseline_matrix(pts_rec, pts_nys, num_pts, kernel, stride: int, seed: int = 1, thread_counts=None,
+                    dtypes=(torch.float64, torch.float32)):
+    """every (dtype, thread count) cell, same seed before each.  -> list of result dicts."""
+    import os
+
+    ncpu = os.cpu_count() or 1
+    if thread_counts is None:
+        thread_counts = sorted({min(8, ncpu), ncpu})
+    out = []
+    for dt in dtypes:
+        for th in thread_counts:
+            torch.manual_seed(seed)
+            out.append(sampled_batch_seconds(pts_rec, pts_nys, num_pts, kernel, stride, dt, th))
+    return out
 
 
 def _run(samp, pt, num_pts, kernel, stride):
     t_wall = time.perf_counter()
     t0 = time.perf_counter()
     _, U = nystrom_basis(pt, num_pts - 1, kernel)
-    t_fixed = time.perf_counter() - t0
+    t_basis = time.perf_counter() - t0
+    t_fixed = t_basis
     N = len(samp)
     q, m = U.shape
     S = 2 * (q + 1)
     mu = torch.ones(N) / N
     live = torch.arange(N)
     R = N
-    t_loop_est = 0.0
+    t_loop_est = t_loop_run = 0.0
     calls_total = calls_run = rounds = 0
     while R > S:
         rounds += 1
@@ -55,6 +92,7 @@ def _run(samp, pt, num_pts, kernel, stride):
             acc += torch.multiply(kernel(pt, samp[blk]), mu[blk].unsqueeze(0))
             ran += 1
         dt = time.perf_counter() - t0
+        t_loop_run += dt
         t_loop_est += dt * nb / ran
         calls_total += nb
         calls_run += ran
@@ -94,8 +132,50 @@ def _run(samp, pt, num_pts, kernel, stride):
     return dict(
         seconds_per_batch=t_fixed + t_loop_est,
         measured_seconds=time.perf_counter() - t_wall,
+        basis_seconds=t_basis,
+        fixed_seconds=t_fixed,
+        loop_seconds_run=t_loop_run,
+        loop_seconds_scaled=t_loop_est,
         loop_fraction=calls_run / max(calls_total, 1),
         n_rounds=rounds,
         kernel_calls_total=calls_total,
         kernel_calls_run=calls_run,
     )
+
+
+def main():
+    """``python -m oracle.cpu_baseline [--full] [--threads 8] [--dtype float64] [--stride K]``: one cell, JSON to stdout.
+
+    ``--full`` = stride 1: the whole batch is executed (the anchor of the sampled estimate)."""
+    import argparse
+    import json
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from basq_amd.pools import gmm_pool          # seeded pool generator (pure torch, no GPU)
+    from oracle.kernels_oracle import StationaryOracle
+
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--N", type=int, default=1_000_000)
+    ap.add_argument("--d", type=int, default=10)
+    ap.add_argument("--n", type=int, default=100)
+    ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--dtype", default="float64", choices=["float64", "float32"])
+    ap.add_argument("--stride", type=int, default=20)
+    ap.add_argument("--full", action="store_true")
+    ap.add_argument("--pool-seed", type=int, default=0)
+    a = ap.parse_args()
+    pool = gmm_pool(a.N, a.d, a.pool_seed)
+    m = int(a.N * 1e-2)
+    torch.manual_seed(1)
+    res = sampled_batch_seconds(pool, pool[:m], a.n, StationaryOracle("rbf", 2.0, 1.0), 1 if a.full else a.stride,
+                                getattr(torch, a.dtype), a.threads)
+    res.update(N=a.N, d=a.d, n=a.n, m=m, host_cores=os.cpu_count(), stride=1 if a.full else a.stride)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

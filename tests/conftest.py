@@ -18,7 +18,9 @@ def hip_ops():
     import torch
 
     if not torch.cuda.is_available():
-        pytest.fail("GPU test selected but no HIP device is visible")
+        # plain `pytest` on a CPU box: the GPU tests are skipped, not errors.  On a GPU box the HIP library itself is
+        # mandatory: HipOps() raises if libbasq_hip.so is missing (no fallback), so a broken build cannot pass silently.
+        pytest.skip("no HIP device visible (run with -m gpu on an MI355X)")
     from basq_amd._ops import HipOps
 
     return HipOps(torch.device("cuda", 0))

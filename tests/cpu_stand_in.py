@@ -250,12 +250,12 @@ class CpuStandInOps:
         gid = gid0 + torch.arange(max(Rl, 1), dtype=torch.int64)
         return mu, gid
 
-    def dense_sq_blocksum(self, Cmat, mu_chunk, pg0, n_full, S, scale, E):
-        self._count("dense_sq")
+    def dense_blocksum(self, Cmat, mu_chunk, pg0, n_full, S, scale, E, square=False):
+        self._count("dense_sq" if square else "dense")
         m, nc = Cmat.shape
         pg = pg0 + torch.arange(nc)
         sets = torch.where(pg < n_full, pg % S, torch.full_like(pg, S - 1))
-        E.index_add_(1, sets, scale * (Cmat * Cmat) * mu_chunk[:nc].unsqueeze(0))
+        E.index_add_(1, sets, scale * ((Cmat * Cmat) if square else Cmat) * mu_chunk[:nc].unsqueeze(0))
 
     def box_muller(self, u, u_tail=None):
         def bm(v):

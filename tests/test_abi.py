@@ -69,8 +69,10 @@ def test_product_has_no_cpu_path():
     with pytest.raises(BasqHipError):
         basq_amd.recombination(torch.zeros(10, 2), torch.zeros(5, 2), 3, basq_amd.kernels.StationaryKernel("rbf", 1.0),
                                torch.device("cpu"))
+    with pytest.raises(BasqHipError):     # an opaque callable is accepted (chunked dense path) -- but never on the CPU
+        basq_amd.recombination(torch.zeros(10, 2), torch.zeros(5, 2), 3, lambda a, b: a @ b.T, torch.device("cpu"))
     with pytest.raises(TypeError):
-        basq_amd.recombination(torch.zeros(10, 2), torch.zeros(5, 2), 3, lambda a, b: a @ b.T, torch.device("cuda"))
+        basq_amd.recombination(torch.zeros(10, 2), torch.zeros(5, 2), 3, 3.0, torch.device("cpu"))
 
 
 def test_product_does_not_import_oracle():

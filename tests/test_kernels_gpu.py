@@ -282,17 +282,21 @@ def test_chol_inv_flags_rank_deficiency(hip_ops):
 
 @pytest.mark.parametrize("m,nc,pg0,n_full,S", [(70, 1000, 0, 1000, 50), (70, 777, 1234, 1800, 60), (33, 150, 4003, 4000, 40),
                                                (10, 500, 100, 396, 22)])
-def test_dense_sq_blocksum_vs_standin(hip_ops, m, nc, pg0, n_full, S):
-    """WSABI-M's squared block sums, incl. a chunk that starts mid-block and one that lies wholly in the tail."""
+@pytest.mark.parametrize("square", [False, True])
+def test_dense_blocksum_vs_standin(hip_ops, m, nc, pg0, n_full, S, square):
+    """Dense block sums (opaque-callable path; squared: WSABI-M), incl. a chunk that starts mid-block, one that lies
+    wholly in the tail, and a row-strided view of a wider buffer."""
     cpu = CpuStandInOps()
     Cm = _rand(m, nc, 31)
     g = torch.Generator().manual_seed(2)
     mu = torch.rand(nc, generator=g, dtype=torch.float64) + 0.1
     E0 = _rand(m, S, 32)
     Ec = E0.clone()
-    cpu.dense_sq_blocksum(Cm, mu, pg0, n_full, S, 0.5, Ec)
+    cpu.dense_blocksum(Cm, mu, pg0, n_full, S, 0.5, Ec, square=square)
     Eg = hip_ops.to_device(E0.clone())
-    hip_ops.dense_sq_blocksum(hip_ops.to_device(Cm), hip_ops.to_device(mu), pg0, n_full, S, 0.5, Eg)
+    wide = hip_ops.zeros(m, nc + 7)
+    wide[:, :nc] = hip_ops.to_device(Cm)
+    hip_ops.dense_blocksum(wide[:, :nc], hip_ops.to_device(mu), pg0, n_full, S, 0.5, Eg, square=square)
     assert (Eg.cpu() - Ec).abs().max().item() <= 1e-12 * Ec.abs().max().item()
 
 

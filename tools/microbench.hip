@@ -3,11 +3,14 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/microbench tools/microbench.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <algorithm>
 #include <vector>
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 template <int MODE>   // 0 = fma only, 1 = mfma only, 2 = both interleaved (1 mfma : 20 fma)
-__global__ void __launch_bounds__(256) rate_kernel(double* out, int iters, double seed) {
+__global__ void __launch_bounds__(256) rate_kernel(double* out, int iters, double seed, unsigned long long* stamps) {
+    // in-kernel clock (MI355X_MICROARCH.md, DVFS item 6): d(s_memtime) / d(s_memrealtime) x 100 MHz
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     double a0 = seed + threadIdx.x, a1 = a0 * 0.5, a2 = a0 * 0.25, a3 = a0 * 0.125;
     double a4 = a0 + 1, a5 = a0 + 2, a6 = a0 + 3, a7 = a0 + 4;
     const double m = 0.999999, c = 1e-9;
@@ -29,20 +32,30 @@ __global__ void __launch_bounds__(256) rate_kernel(double* out, int iters, doubl
         }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + D0[0] + D1[1] + D2[2] + D3[3];
+    if (stamps && threadIdx.x == 0) {
+        stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - c0;
+        stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
 }
 
 template <int MODE>
-static void run(const char* name, int waves_per_simd, double fma_per_iter, double mfma_per_iter) {
+static void run(const char* name, int waves_per_simd, double fma_per_iter, double mfma_per_iter, int warm_reps) {
     const int blocks = 256 * waves_per_simd;   // 256 CUs x (4 waves = 1 per SIMD) per block
     const int iters = 20000;
     double* out;
     hipMalloc(&out, (size_t)blocks * 256 * 8);
+    unsigned long long* stamps;
+    hipMalloc(&stamps, (size_t)blocks * 16);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL(rate_kernel<MODE>, dim3(blocks), dim3(256), 0, 0, out, 100, 1.0);
+    // >= 2 s of back-to-back launches first: the clock the chip HOLDS under this load, not the boost of a cold start
+    hipLaunchKernelGGL(rate_kernel<MODE>, dim3(blocks), dim3(256), 0, 0, out, 100, 1.0, (unsigned long long*)nullptr);
+    hipDeviceSynchronize();
+    for (int rep = 0; rep < warm_reps; ++rep)
+        hipLaunchKernelGGL(rate_kernel<MODE>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0, (unsigned long long*)nullptr);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL(rate_kernel<MODE>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0);
+    hipLaunchKernelGGL(rate_kernel<MODE>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0, stamps);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -53,9 +66,20 @@ static void run(const char* name, int waves_per_simd, double fma_per_iter, doubl
     const double tf_mfma = mfma * 2048 / (ms * 1e-3) / 1e12;
     // cycles per wave-instruction per SIMD at 2.4 GHz nominal
     const double simd_cycles = ms * 1e-3 * 2.4e9;
-    printf("%-22s waves/SIMD=%d  %8.3f ms  VALU %7.2f TF/s (%.2f cyc/fma/SIMD)  MFMA %7.2f TF/s (%.1f cyc/mfma/SIMD)\n", name,
-           waves_per_simd, ms, tf_valu, fma > 0 ? simd_cycles / (fma / 1024.0) : 0.0, tf_mfma,
-           mfma > 0 ? simd_cycles / (mfma / 1024.0) : 0.0);
+    std::vector<unsigned long long> h((size_t)blocks * 2);
+    hipMemcpy(h.data(), stamps, (size_t)blocks * 16, hipMemcpyDeviceToHost);
+    std::vector<double> ghz;
+    for (int b = 0; b < blocks; ++b)
+        if (h[2 * b + 1]) ghz.push_back((double)h[2 * b] / (double)h[2 * b + 1] * 0.1);
+    std::sort(ghz.begin(), ghz.end());
+    const double clk = ghz.empty() ? 0.0 : ghz[ghz.size() / 2];      // median over work-groups, GHz
+    const double real_cycles = ms * 1e-3 * clk * 1e9;
+    printf("%-22s waves/SIMD=%d  %8.3f ms  in-kernel clock %.3f GHz | VALU %7.2f TF/s (%.2f nominal / %.2f real cyc/fma/SIMD)  "
+           "MFMA %7.2f TF/s (%.1f nominal / %.1f real cyc/mfma/SIMD)\n", name,
+           waves_per_simd, ms, clk, tf_valu, fma > 0 ? simd_cycles / (fma / 1024.0) : 0.0,
+           fma > 0 ? real_cycles / (fma / 1024.0) : 0.0, tf_mfma,
+           mfma > 0 ? simd_cycles / (mfma / 1024.0) : 0.0, mfma > 0 ? real_cycles / (mfma / 1024.0) : 0.0);
+    hipFree(stamps);
     hipFree(out);
 }
 
@@ -63,9 +87,10 @@ int main() {
     hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
     printf("device: %s  CUs=%d  clock=%d kHz\n", p.name, p.multiProcessorCount, p.clockRate);
     for (int w = 1; w <= 4; w *= 2) {
-        run<0>("fma_f64 only", w, 128, 0);
-        run<1>("mfma_f64 16x16x4 only", w, 0, 4);
-        run<2>("both (80 fma : 4 mfma)", w, 80, 4);
+        const int warm = (w == 4) ? 100 : 0;     // the 4-waves/SIMD rows are measured after ~2 s at load
+        run<0>("fma_f64 only", w, 128, 0, warm);
+        run<1>("mfma_f64 16x16x4 only", w, 0, 4, warm);
+        run<2>("both (80 fma : 4 mfma)", w, 80, 4, warm);
     }
     return 0;
 }
