@@ -1,4 +1,4 @@
-"""Gaussian-mixture density with a shared covariance, on the HIP pairwise kernel.
+"""Gaussian mixtures with ONE shared covariance, on the HIP pairwise kernel.
 
     pdf(x_i) = sum_k w_k N(x_i; mu_k, Sigma)
 
@@ -10,10 +10,14 @@ is what the reference evaluates at ``BASQ/_acquisition_function.py:64-97`` (``jo
 
 is an RBF kernel (lengthscale 1) between whitened points, so the whole mixture is ONE kernel mat-vec
 (``basq_kernel_matvec_f64``): nothing of size ``n_x * n_k`` is stored.
+
+``SharedCovMixture`` is the object the acquisition and the samplers are built from: weights, means, one covariance;
+``pdf`` (device mat-vec) and ``draw`` (per-component sample counts ``int(n w_k)``, components in order).
 """
 from __future__ import annotations
 
 import math
+from dataclasses import dataclass
 
 import torch
 
@@ -41,3 +45,53 @@ def mixture_pdf(ops, x, means, weights, cov):
     s = ops.matvec(spec, pa, n, pb, means.shape[0], weights, 0.0)
     norm = (2.0 * math.pi) ** (-0.5 * d) / torch.diagonal(L).prod()
     return s * norm
+
+
+def gauss_logpdf(x, mean, cov):
+    """``log N(x_i; mean, cov)`` for rows of ``x`` ([n, d]); ``mean`` [d] or [n, d].  Small (n_obs-sized) inputs: plain torch."""
+    L = torch.linalg.cholesky(cov)
+    z = torch.linalg.solve_triangular(L, (x - mean).T, upper=False)
+    d = x.shape[-1]
+    return -0.5 * (z * z).sum(0) - torch.log(torch.diagonal(L)).sum() - 0.5 * d * math.log(2.0 * math.pi)
+
+
+def mvn_draw(mean, cov, count, device, generator_parity=True):
+    """``count`` samples of N(mean, cov) -> ``[count, d]`` on ``device``.
+
+    ``generator_parity`` (default): drawn with ``MultivariateNormal.sample`` from the CPU global generator -- where and
+    how the reference draws when it runs on the CPU, so ``torch.manual_seed`` reproduces its pools -- then moved.
+    Otherwise drawn on the device (torch's device generator: Philox; no host work, no H2D copy of the pool)."""
+    count = int(count)
+    if generator_parity:
+        from torch.distributions.multivariate_normal import MultivariateNormal
+
+        mvn = MultivariateNormal(mean.detach().to("cpu", torch.float64), cov.detach().to("cpu", torch.float64))
+        return mvn.sample(torch.Size([count])).to(device)
+    mean = mean.detach().to(device, torch.float64)
+    L = torch.linalg.cholesky(cov.detach().to(device, torch.float64))
+    z = torch.randn(count, mean.shape[-1], dtype=torch.float64, device=device)
+    return mean + z @ L.T
+
+
+@dataclass
+class SharedCovMixture:
+    weights: torch.Tensor        # [k]  (sum to the mixture's total mass; may be empty)
+    means: torch.Tensor          # [k, d]
+    cov: torch.Tensor            # [d, d]
+
+    def __len__(self):
+        return int(self.means.shape[0])
+
+    def pdf(self, ops, x):
+        return mixture_pdf(ops, x, self.means, self.weights, self.cov)
+
+    def counts(self, n):
+        """Samples per component when ``n`` are requested: ``int(n w_k)`` each (truncation, as the reference)."""
+        return (n * self.weights).type(torch.int).tolist()
+
+    def draw(self, n, device, generator_parity=True):
+        """Component by component, in order -> ``[sum_k int(n w_k), d]``."""
+        parts = [mvn_draw(self.means[k], self.cov, c, device, generator_parity) for k, c in enumerate(self.counts(n))]
+        if not parts:
+            return torch.zeros(0, self.means.shape[-1], dtype=torch.float64, device=device)
+        return torch.cat(parts)

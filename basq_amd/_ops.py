@@ -151,9 +151,20 @@ class HipOps:
         V = self.empty(s, M)
         tau = self.empty(s)
         PhiT = self.empty(M - s, M)
-        check(self.lib.basq_nullspace_f64(_ptr(XcarT), s, M, _ptr(V), _ptr(tau), _ptr(PhiT), self._stream()),
-              "basq_nullspace_f64")
+        check(self.lib.basq_nullspace_f64(_ptr(XcarT), s, M, _ptr(V), _ptr(tau), _ptr(PhiT),
+                                          _ptr(self._reduction_ws(s, M)), self._stream()), "basq_nullspace_f64")
         return PhiT
+
+    def _reduction_ws(self, s, M):
+        """Cached workspace of the cluster kernels (message ring + flag words), None when the shape needs none."""
+        n = int(self.lib.basq_reduction_ws_doubles(int(s), int(M)))
+        if n <= 0:
+            return None
+        cache = self.__dict__.setdefault("_ws_cache", {})
+        buf = cache.get(n)
+        if buf is None:
+            buf = cache[n] = self.zeros(n)
+        return buf
 
     def car_eliminate(self, PhiT, mu, M, s):
         """In place on PhiT/mu.  -> (keep_rank[M] i32, kept[s] i32, w_star[s] f64, info[2] i32)."""
@@ -164,7 +175,8 @@ class HipOps:
         info, kept = ik[:2], ik[2:]                             #  stopped early, status 1)
         w_star = self.empty(M)
         check(self.lib.basq_car_eliminate_f64(_ptr(PhiT), _ptr(mu), M, s, _ptr(keep_rank), _ptr(kept), _ptr(w_star),
-                                              _ptr(info), self._stream()), "basq_car_eliminate_f64")
+                                              _ptr(info), _ptr(self._reduction_ws(s, M)), self._stream()),
+              "basq_car_eliminate_f64")
         return keep_rank, kept, w_star, info
 
     def reweight_compact(self, cand, mu, gid, wx, Rl, off, n_full, S, kp, keep_rank, w_star, tot, n_keep, new_off,

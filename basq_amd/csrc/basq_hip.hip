@@ -1281,6 +1281,255 @@ __global__ void __launch_bounds__(1024) car_eliminate_lds_kernel(const double* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// Cluster kernels for the two per-round reductions (null space, elimination).
+//
+// Both reductions are chains of s (resp. M - s) dependent steps over a [rows x M] matrix; what a step costs is its
+// synchronisation, not its arithmetic.  Common layout: the matrix lives in REGISTERS, row r in wave (r % W), slot
+// (r / W); lanes own column PAIRS (slot k of a lane holds column 2 lane + (k & 1) + 128 (k >> 1)); a work-group is
+// BASQ_WPG = 8 waves (two per SIMD) and a cluster is NCU work-groups (W = 8 NCU waves) that exchange ONE message
+// per step:
+//   NCU = 1: through LDS (ring buffer + one counter word, no s_barrier in the elimination);
+//   NCU > 1: through a ring in global memory, written with agent-scope (sc1, write-through) 8-byte stores, each
+//            storing wave draining vmcnt before ITS OWN counter/flag store, read with agent-scope (sc1) loads by the
+//            wave that polled (MI355X_MICROARCH.md, visibility: "8-B agent atomics both sides", every wave signals
+//            and polls for itself).  Spins are bounded: a timeout aborts every wave of the cluster with status 2.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) unsigned long long basq_gu64;
+typedef __attribute__((address_space(1))) unsigned int basq_gu32;
+#define BASQ_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+#define BASQ_PAIRCOL(k) (2 * lane + ((k) & 1) + 128 * ((k) >> 1))
+#define BASQ_WPG 8                        // waves per work-group of the cluster kernels: two per SIMD, 256 VGPRs each -- the
+                                          // 100 x 200 matrix is 56 doubles per lane and stays in directly addressable VGPRs
+                                          // (4 waves of 512 registers would park half of it in AGPRs: two moves per use)
+#define BASQ_SPIN_LIMIT (1u << 22)       // polls (with s_sleep) before a cluster kernel gives up: ~0.3 s
+#define BASQ_ABORT_COUNT 0x40000000
+
+__device__ __forceinline__ void agent_store_f64(double* p, double v) {
+    __hip_atomic_store((basq_gu64*)p, (unsigned long long)__double_as_longlong(v), BASQ_RLX_AGENT);
+}
+__device__ __forceinline__ double agent_load_f64(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load((basq_gu64*)p, BASQ_RLX_AGENT));
+}
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+    const int BIG = 0x7fffffff;
+    v = min(v, __builtin_amdgcn_update_dpp(BIG, v, 0x111, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(BIG, v, 0x112, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(BIG, v, 0x114, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(BIG, v, 0x118, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(BIG, v, 0x142, 0xa, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(BIG, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// slot kj (wave-uniform) of a register row
+// (the empty asm pins each element in a VGPR first: left alone, LLVM rewrites the select chain into ONE load with a
+// selected address, which forces the whole register-resident matrix into scratch memory)
+template <int NV>
+__device__ __forceinline__ double pick_slot(const double (&r)[NV], int kj) {
+    double v = r[0];
+    asm("" : "+v"(v));
+#pragma unroll
+    for (int k = 1; k < NV; ++k) {
+        double x = r[k];
+        asm("" : "+v"(x));
+        v = (kj == k) ? x : v;
+    }
+    return v;
+}
+
+// Monotone counter shared by the waves of a cluster (LDS word for one work-group, global word otherwise).
+template <bool GLOBAL>
+__device__ __forceinline__ void counter_publish(int* cnt, int value, int lane) {
+    if (GLOBAL) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's payload stores have left the CU
+        if (lane == 0) __hip_atomic_store((basq_gu32*)cnt, (unsigned)value, BASQ_RLX_AGENT);
+    } else {
+        if (lane == 0) __hip_atomic_store(cnt, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+}
+// wait until *cnt > k; returns the value seen (>= BASQ_ABORT_COUNT: another wave gave up)
+template <bool GLOBAL>
+__device__ __forceinline__ int counter_wait_gt(int* cnt, int k) {
+    unsigned spins = 0;
+    int c;
+    for (;;) {
+        if (GLOBAL) c = (int)__hip_atomic_load((basq_gu32*)cnt, BASQ_RLX_AGENT);
+        else c = __hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c > k) break;
+        if (++spins > BASQ_SPIN_LIMIT) {                           // never in a healthy run: abort the whole cluster
+            if (GLOBAL) __hip_atomic_store((basq_gu32*)cnt, (unsigned)BASQ_ABORT_COUNT, BASQ_RLX_AGENT);
+            else __hip_atomic_store(cnt, BASQ_ABORT_COUNT, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            c = BASQ_ABORT_COUNT;
+            break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");        // no instruction: keeps the payload loads below the poll
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Caratheodory elimination (BASQ/_rchq.py:146-175), cluster form: bit-identical to the reference's op order
+// (mul, Markstein quotient, sub per entry; IEEE divides in the ratio test; first-index argmin).
+//   * null vector c lives in the registers of wave c % W; every wave keeps its own copy of the weights;
+//   * the owner of row k+1 updates THAT row first, runs the ratio test of step k+1 on it and publishes
+//     {row, j, alpha, 1/phi_j, phi_j} in a ring slot -- then catches up with its other rows.  The other waves only
+//     consume: the dependent chain of a step is publish -> read -> one row update -> ratio test, while the rank-1
+//     updates of the (M-s-k) remaining rows run beside it on the other SIMDs / CUs.  No barrier;
+//   * ring of 2 W slots: a slot is rewritten W+1 steps later at the earliest, by which time every wave (each owns
+//     one row in any W consecutive steps, and publishing needs the previous pivot) has consumed it.
+// ------------------------------------------------------------------------------------------------
+template <int NV, int NR, int NCU>
+__global__ void __launch_bounds__(BASQ_WPG * 64) car_eliminate_cluster_kernel(const double* __restrict__ PhiT_g,
+                                                                    double* __restrict__ mu_g, int M, int s,
+                                                                    int* __restrict__ keep_rank, int* __restrict__ kept,
+                                                                    double* __restrict__ w_star, int* __restrict__ info,
+                                                                    double* ws, int cluster_stride) {
+#pragma clang fp contract(off)   // plain operators: the reference rounds after every mul / sub / div
+    constexpr int WPG = BASQ_WPG, W = WPG * NCU, NC = NV * 64, D = 2 * W, SLOT = NC + 8;
+    constexpr bool GLOBAL = NCU > 1;
+    if (blockIdx.x % cluster_stride) return;       // cluster members share `blockIdx.x % 8`: one XCD under round-robin
+    const int cu = blockIdx.x / cluster_stride;    // placement -- speed only, nothing depends on it
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gw = cu * WPG + wv;
+    const int nrows = M - s;
+    const double INF = __builtin_huge_val();
+    __shared__ __attribute__((aligned(16))) double ring_l[GLOBAL ? 2 : D * SLOT];
+    __shared__ int count_l;
+    double* ring = GLOBAL ? (ws + 16) : ring_l;
+    int* count = GLOBAL ? (int*)ws : &count_l;     // NCU > 1: zeroed by the launcher (memset node ahead of the launch)
+    if (!GLOBAL) {
+        if (threadIdx.x == 0) count_l = 0;
+        __syncthreads();
+    }
+    double a[NR][NV], mu[NV];
+    unsigned deadmask = 0;                          // bit k: column of slot k is eliminated (or padding)
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int col = BASQ_PAIRCOL(k);
+        mu[k] = (col < M) ? mu_g[col] : 0.0;
+        if (col >= M) deadmask |= 1u << k;
+    }
+#pragma unroll
+    for (int jr = 0; jr < NR; ++jr) {
+        const int c = gw + W * jr;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int col = BASQ_PAIRCOL(k);
+            a[jr][k] = (c < nrows && col < M) ? PhiT_g[(size_t)c * M + col] : 0.0;
+        }
+    }
+    // ratio test of one null vector (:148-152) + publication as pivot `kp`
+    auto test_and_publish = [&](const double (&r)[NV], int kp) {
+        double best = INF, brphi = 0.0, bphi = 0.0;
+        int bcol = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const bool pos = !((deadmask >> k) & 1u) && (r[k] > 0.0);
+            const double av = pos ? (mu[k] / r[k]) : INF;
+            const double rp = pos ? (1.0 / r[k]) : 0.0;           // RN(1/phi): the pivot's reciprocal, one IEEE divide
+            if (pos && (av < best || bcol == 0x7fffffff)) { best = av; bcol = BASQ_PAIRCOL(k); brphi = rp; bphi = r[k]; }
+        }
+        const double wmin = wave_min_f64(best);
+        const int j = wave_min_i32((bcol != 0x7fffffff && best == wmin) ? bcol : 0x7fffffff);   // first index (:152)
+        const int lane_j = (j & 127) >> 1;
+        const double rphij = (j == 0x7fffffff) ? 0.0 : readlane_f64(brphi, lane_j);
+        const double phij = (j == 0x7fffffff) ? 0.0 : readlane_f64(bphi, lane_j);
+        double* slot = ring + (size_t)(kp % D) * SLOT;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (GLOBAL) agent_store_f64(slot + BASQ_PAIRCOL(k), r[k]);
+            else slot[BASQ_PAIRCOL(k)] = r[k];
+        }
+        if (lane < 4) {
+            const double v = (lane == 0) ? wmin : (lane == 1) ? rphij : (lane == 2) ? phij : __longlong_as_double((long long)j);
+            if (GLOBAL) agent_store_f64(slot + NC + lane, v);
+            else slot[NC + lane] = v;
+        }
+        counter_publish<GLOBAL>(count, kp + 1, lane);
+    };
+    if (nrows > 0 && gw == 0) test_and_publish(a[0], 0);
+    int status = 0;
+    for (int k = 0; k < nrows; ++k) {
+        const int seen = counter_wait_gt<GLOBAL>(count, k);
+        if (seen >= BASQ_ABORT_COUNT) { status = 2; break; }
+        const double* slot = ring + (size_t)(k % D) * SLOT;
+        double phi[NV];
+#pragma unroll
+        for (int kk = 0; kk < NV; ++kk) phi[kk] = GLOBAL ? agent_load_f64(slot + BASQ_PAIRCOL(kk)) : slot[BASQ_PAIRCOL(kk)];
+        double hdr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) hdr[u] = GLOBAL ? agent_load_f64(slot + NC + u) : slot[NC + u];
+        const double aj = hdr[0], rphij = hdr[1], phij = hdr[2];
+        const int j = __builtin_amdgcn_readfirstlane((int)__double_as_longlong(hdr[3]));
+        if (j == 0x7fffffff) { status = 1; break; }               // uniform: no positive entry (the reference raises)
+        const int kj = (j & 1) + 2 * (j >> 7), lane_j = (j & 127) >> 1;
+#pragma unroll
+        for (int kk = 0; kk < NV; ++kk) {                                               // :158-159
+            const double step = aj * phi[kk];
+            mu[kk] = mu[kk] - step;
+            if (kk == kj && lane == lane_j) { mu[kk] = 0.0; deadmask |= 1u << kk; }
+        }
+        auto update_row = [&](double (&r)[NV]) {                                        // :165-171
+            const double pj = readlane_f64(pick_slot<NV>(r, kj), lane_j);
+#pragma unroll
+            for (int kk = 0; kk < NV; ++kk) {
+                const double o = div_by_recip(pj * phi[kk], phij, rphij);               // == (pj * phi) / phij, bit for bit
+                r[kk] = r[kk] - o;
+            }
+        };
+        if (k + 1 < nrows && gw == (k + 1) % W) {                  // my row is next: update it first, test, publish
+            double rt[NV];
+#pragma unroll
+            for (int jr = 0; jr < NR; ++jr)
+                if (gw + W * jr == k + 1) {
+                    update_row(a[jr]);
+#pragma unroll
+                    for (int kk = 0; kk < NV; ++kk) rt[kk] = a[jr][kk];
+                }
+            test_and_publish(rt, k + 1);
+        }
+#pragma unroll
+        for (int jr = 0; jr < NR; ++jr) {
+            const int c = gw + W * jr;
+            if (c > k + 1 && c < nrows) update_row(a[jr]);         // wave-uniform
+        }
+    }
+    if (gw == 0) {
+        // survivors: mu > 0 (:173-174), ascending column order; slot pair (2h, 2h+1) covers columns [128 h, 128 h + 128)
+        unsigned long long bal[NV];
+        bool keep[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            keep[k] = (BASQ_PAIRCOL(k) < M) && (mu[k] > 0.0);
+            bal[k] = __ballot(keep[k]);
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        int base = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) total += __popcll(bal[k]);
+#pragma unroll
+        for (int h = 0; h < NV / 2; ++h) {
+            const int r0 = base + __popcll(bal[2 * h] & below) + __popcll(bal[2 * h + 1] & below);
+            const int r1 = r0 + (keep[2 * h] ? 1 : 0);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int k = 2 * h + b, col = BASQ_PAIRCOL(k), rank = b ? r1 : r0;
+                if (col < M) {
+                    keep_rank[col] = keep[k] ? rank : -1;
+                    mu_g[col] = mu[k];
+                    if (keep[k]) { kept[rank] = col; w_star[rank] = mu[k]; }
+                }
+            }
+            base += __popcll(bal[2 * h]) + __popcll(bal[2 * h + 1]);
+        }
+        if (lane == 0) { info[0] = total; info[1] = status; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Null space of the wide [m, n] Caratheodory matrix (BASQ/_rchq.py:140-143) without an SVD iteration.
 //
 // The reference takes Phi = Vh[-(n-m):].T from torch.linalg.svd(X) (LAPACK gesdd).  gesdd first reduces X to
@@ -1810,6 +2059,231 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
 #undef BASQ_COL
 }
 
+// ------------------------------------------------------------------------------------------------
+// Bidiagonalisation reflectors, cluster form (same reflectors as dgebd2 / bidiag_reflectors_reg_kernel; layout and
+// exchange as described above car_eliminate_cluster_kernel).  ONE synchronisation per step t:
+//   bulk (every wave, its live rows r > t): apply the previous left reflector H_{t-1} (deferred), the dot products
+//       with v_t (reduced four rows at a time), the rank-1 update by G_t; column t of the updated rows is read back
+//       and accumulated into this wave's share of column_t^T A and |column_t|^2; the owner of row t+1 publishes it;
+//   exchange: the waves' partial rows through LDS + one s_barrier; clusters add one hop through global memory (the
+//       work-group's sum, published write-through by wave 0 behind the barrier, one flag per work-group);
+//   chain (EVERY wave, redundantly and bit-identically -- nothing is handed back): sum the partials in a fixed order,
+//       H_t's parameters, w = u^T A, row t+1 after H_t, then G_{t+1} from it -> v_{t+1}, tau_{t+1}.
+// ------------------------------------------------------------------------------------------------
+template <int NV, int NR, int NCU>
+__global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const double* __restrict__ X, int m, int n,
+                                                             double* __restrict__ V, double* __restrict__ tau_g,
+                                                             double* ws, int cluster_stride) {
+    static_assert(NV % 2 == 0, "lanes own column pairs");
+    constexpr int WPG = BASQ_WPG, W = WPG * NCU, NC = NV * 64, NG = (NR + 3) / 4, MSG = NC + 8;
+    constexpr bool GLOBAL = NCU > 1;
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    if (blockIdx.x % cluster_stride) return;
+    const int cu = blockIdx.x / cluster_stride;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gw = cu * WPG + wv;
+    __shared__ __attribute__((aligned(16))) double wpart_l[2 * WPG * MSG];   // [parity][local wave]: partial row | ssp
+    __shared__ __attribute__((aligned(16))) double r1_l[2 * MSG];          // [parity]: row t+1 after G_t | its column-t entry
+    __shared__ int abort_l;
+    // global (clusters): ws = [flags: NCU words in the first 128 B][2][NCU][MSG] work-group sums [2][MSG] row t+1
+    unsigned* flags = (unsigned*)ws;
+    double* gsum = GLOBAL ? (ws + 16) : nullptr;
+    double* gr1 = GLOBAL ? (gsum + 2 * NCU * MSG) : nullptr;
+
+    double a[NG * 4][NV], cprev[NG * 4];
+#pragma unroll
+    for (int jr = 0; jr < NG * 4; ++jr) {
+        const int r = gw + W * jr;
+        cprev[jr] = 0.0;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = BASQ_PAIRCOL(k);
+            a[jr][k] = (jr < NR && r < m && c < n) ? X[(size_t)r * n + c] : 0.0;
+        }
+    }
+    double vr[NV], wc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { vr[k] = 0.0; wc[k] = 0.0; }
+    double tau = 0.0, kappa = 0.0;
+    bool aborted = false;
+    for (int t = -1; t + 1 < m; ++t) {
+        const int par = (t + 1) & 1;
+        double* my_msg = wpart_l + (size_t)(par * WPG + wv) * MSG;
+        double* r1buf = GLOBAL ? (gr1 + (size_t)par * MSG) : (r1_l + (size_t)par * MSG);
+        double pw[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) pw[k] = 0.0;
+        double ssp = 0.0;
+        BASQ_NS_STAMP(t + 1, 0);
+        if (t >= 0) {   // ---- bulk ----
+            const int tk = (t & 1) + 2 * (t >> 7), tl = (t & 127) >> 1;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (gw + W * (4 * g + 3) <= t) continue;           // wave-uniform: the whole group is dead
+                double dot[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int jr = 4 * g + j, r = gw + W * jr;
+                    dot[j] = 0.0;
+                    if (jr < NR && r > t && r < m) {                // wave-uniform
+                        const double tu = kappa * cprev[jr];        // H_{t-1}: tauq u_r, u_r = column_{t-1}[r] * scale
+#pragma unroll
+                        for (int k = 0; k < NV; ++k) {
+                            a[jr][k] -= tu * wc[k];
+                            dot[j] += a[jr][k] * vr[k];
+                        }
+                    }
+                }
+                wave_sum4(dot[0], dot[1], dot[2], dot[3]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int jr = 4 * g + j, r = gw + W * jr;
+                    if (jr < NR && r > t && r < m) {
+                        const double td = tau * dot[j];             // G_t
+#pragma unroll
+                        for (int k = 0; k < NV; ++k) a[jr][k] -= td * vr[k];
+                        const double cr = readlane_f64(pick_slot<NV>(a[jr], tk), tl);   // A[r][t] after G_t
+                        cprev[jr] = cr;
+                        if (r == t + 1) {
+#pragma unroll
+                            for (int k = 0; k < NV; ++k) {
+                                if (GLOBAL) agent_store_f64(r1buf + BASQ_PAIRCOL(k), a[jr][k]);
+                                else r1buf[BASQ_PAIRCOL(k)] = a[jr][k];
+                            }
+                            if (lane == 0) {
+                                if (GLOBAL) agent_store_f64(r1buf + NC, cr);
+                                else r1buf[NC] = cr;
+                            }
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < NV; ++k) pw[k] += cr * a[jr][k];
+                            ssp += cr * cr;
+                        }
+                    }
+                }
+            }
+        } else if (gw == 0) {   // prologue: row 0 as it stands is "row t+1"
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                if (GLOBAL) agent_store_f64(r1buf + BASQ_PAIRCOL(k), a[0][k]);
+                else r1buf[BASQ_PAIRCOL(k)] = a[0][k];
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < NV / 2; ++h)
+            *reinterpret_cast<d2_t*>(my_msg + 2 * lane + 128 * h) = (d2_t){pw[2 * h], pw[2 * h + 1]};
+        if (lane == 0) my_msg[NC] = ssp;
+        BASQ_NS_STAMP(t + 1, 1);
+        if (GLOBAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the owner's row stores have left the CU
+        __syncthreads();
+        BASQ_NS_STAMP(t + 1, 2);
+        // ---- chain (every wave) ----
+        double accs[NV], ss2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) accs[k] = 0.0;
+        if (t >= 0) {
+#pragma unroll
+            for (int w = 0; w < WPG; ++w) {                         // local partials, wave order
+                const double* src = wpart_l + (size_t)(par * WPG + w) * MSG;
+#pragma unroll
+                for (int h = 0; h < NV / 2; ++h) {
+                    const d2_t v = *reinterpret_cast<const d2_t*>(src + 2 * lane + 128 * h);
+                    accs[2 * h] += v.x;
+                    accs[2 * h + 1] += v.y;
+                }
+                ss2 += src[NC];
+            }
+        }
+        if (GLOBAL) {
+            // publish this work-group's sum (wave 0), then gather every work-group's sum in cluster order
+            const unsigned epoch = (unsigned)(t + 2);
+            double* mine = gsum + (size_t)(par * NCU + cu) * MSG;
+            if (wv == 0) {                                          // ONE wave publishes and polls; the others wait at the barrier
+#pragma unroll
+                for (int k = 0; k < NV; ++k) agent_store_f64(mine + BASQ_PAIRCOL(k), accs[k]);
+                if (lane == 0) agent_store_f64(mine + NC, ss2);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store((basq_gu32*)(flags + cu), epoch, BASQ_RLX_AGENT);
+                unsigned spins = 0;
+                bool bad = false;
+                for (;;) {
+                    const unsigned f = (lane < NCU) ? __hip_atomic_load((basq_gu32*)(flags + lane), BASQ_RLX_AGENT) : epoch;
+                    if (__all(f >= epoch)) { bad = __any(f >= (unsigned)BASQ_ABORT_COUNT); break; }
+                    if (++spins > BASQ_SPIN_LIMIT) {                // never in a healthy run: abort the whole cluster
+                        if (lane == 0) __hip_atomic_store((basq_gu32*)(flags + cu), (unsigned)BASQ_ABORT_COUNT, BASQ_RLX_AGENT);
+                        bad = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (lane == 0) abort_l = bad ? 1 : 0;
+            }
+            __syncthreads();                                        // verdict of wave 0: uniform over the work-group
+            aborted = abort_l != 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: the gathers stay below the poll
+            if (aborted) break;                                     // work-group uniform: no wave is left at a barrier
+            double tot[NV], sst = 0.0;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) tot[k] = 0.0;
+#pragma unroll
+            for (int c2 = 0; c2 < NCU; ++c2) {
+                const double* src = gsum + (size_t)(par * NCU + c2) * MSG;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) tot[k] += agent_load_f64(src + BASQ_PAIRCOL(k));
+                sst += agent_load_f64(src + NC);
+            }
+#pragma unroll
+            for (int k = 0; k < NV; ++k) accs[k] = tot[k];
+            ss2 = sst;
+        }
+        double r1[NV], rn[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) r1[k] = GLOBAL ? agent_load_f64(r1buf + BASQ_PAIRCOL(k)) : r1buf[BASQ_PAIRCOL(k)];
+        if (t >= 0) {
+            const double alphaH = GLOBAL ? agent_load_f64(r1buf + NC) : r1buf[NC];
+            double tauq, uscale;
+            householder_params_fast(alphaH, ss2, tauq, uscale);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int c = BASQ_PAIRCOL(k);
+                const double w_c = (c > t) ? (r1[k] + uscale * accs[k]) : 0.0;     // u^T A with u = [1, column * scale]
+                wc[k] = w_c;
+                rn[k] = r1[k] - tauq * w_c;                                          // row t+1 after H_t
+            }
+            kappa = tauq * uscale;
+        } else {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) rn[k] = r1[k];
+        }
+        {   // right reflector G_{t+1} from rn
+            const int t1 = t + 1, tk = (t1 & 1) + 2 * (t1 >> 7), tl = (t1 & 127) >> 1;
+            double ss = 0.0;
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+                if (BASQ_PAIRCOL(k) > t1) ss += rn[k] * rn[k];
+            ss = wave_sum(ss);
+            const double alpha = readlane_f64(pick_slot<NV>(rn, tk), tl);
+            double scale;
+            householder_params_fast(alpha, ss, tau, scale);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int c = BASQ_PAIRCOL(k);
+                vr[k] = (c < t1) ? 0.0 : ((c == t1) ? 1.0 : rn[k] * scale);
+            }
+            if (gw == t1 % W) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const int c = BASQ_PAIRCOL(k);
+                    if (c < n) V[(size_t)t1 * n + c] = vr[k];
+                }
+                if (lane == 0) tau_g[t1] = tau;
+            }
+        }
+        BASQ_NS_STAMP(t + 1, 3);
+    }
+    if (aborted && gw == 0 && lane == 0) tau_g[0] = __builtin_nan("");   // poisons the null space: the caller's elimination fails loudly
+}
+
 template <int NV>
 __global__ void __launch_bounds__(256) nullspace_apply_kernel(const double* __restrict__ V,
                                                               const double* __restrict__ tau, int m, int n,
@@ -1855,6 +2329,70 @@ __global__ void __launch_bounds__(256) nullspace_apply_kernel(const double* __re
     for (int k = 0; k < NV; ++k) {
         const int c = lane + 64 * k;
         if (c < n) PhiT[(size_t)c0 * n + c] = y[k];
+    }
+}
+
+// Apply form with SIXTEEN lanes per null vector (4 null vectors per wave): the 100-step chain y -= tau_i (v_i . y) v_i
+// is latency-bound, and a 16-lane sum is four DPP steps inside one row instead of the six stages + readlane of a
+// 64-lane sum; the lanes of a row read consecutive columns (column = lane16 + 16 k), the four rows of a wave read the
+// same reflector row (one L1 line serves them all).
+template <int NV16>
+__global__ void __launch_bounds__(256) nullspace_apply16_kernel(const double* __restrict__ V,
+                                                                const double* __restrict__ tau, int m, int n,
+                                                                double* __restrict__ PhiT) {
+    constexpr int PF = 4;                                 // reflector rows in flight
+    const int lane = threadIdx.x & 63, l16 = lane & 15;
+    const int nvec = n - m;
+    int c0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    const bool live = c0 < nvec;
+    if (!live) c0 = nvec - 1;                             // idle rows of the last wave shadow a real vector (no divergence)
+    double y[NV16], v[PF][NV16], tv[PF];
+#pragma unroll
+    for (int k = 0; k < NV16; ++k) y[k] = (l16 + 16 * k == m + c0) ? 1.0 : 0.0;
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        const int i = m - 1 - p;
+        tv[p] = (i >= 0) ? tau[i] : 0.0;
+#pragma unroll
+        for (int k = 0; k < NV16; ++k) {
+            const int c = l16 + 16 * k;
+            v[p][k] = (i >= 0 && c < n) ? V[(size_t)i * n + c] : 0.0;
+        }
+    }
+    for (int i0 = m - 1; i0 >= 0; i0 -= PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {                    // static ring slot p holds row i0 - p
+            const int i = i0 - p;
+            if (i < 0) break;                             // uniform
+            double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+            for (int k = 0; k + 1 < NV16; k += 2) {
+                d0 += v[p][k] * y[k];
+                d1 += v[p][k + 1] * y[k + 1];
+            }
+            if (NV16 & 1) d0 += v[p][NV16 - 1] * y[NV16 - 1];
+            double dot = d0 + d1;
+            dot += dpp_perm_f64<0xB1>(dot);               // quad_perm [1,0,3,2]
+            dot += dpp_perm_f64<0x4E>(dot);               // quad_perm [2,3,0,1]
+            dot += dpp_perm_f64<0x141>(dot);              // row_half_mirror
+            dot += dpp_perm_f64<0x140>(dot);              // row_mirror: every lane of the row of 16 holds the sum
+            const double t = tv[p] * dot;
+            const int inext = i - PF;                     // refill the slot behind the reduction
+            tv[p] = (inext >= 0) ? tau[inext] : 0.0;
+#pragma unroll
+            for (int k = 0; k < NV16; ++k) {
+                const int c = l16 + 16 * k;
+                y[k] -= t * v[p][k];
+                v[p][k] = (inext >= 0 && c < n) ? V[(size_t)inext * n + c] : 0.0;
+            }
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < NV16; ++k) {
+            const int c = l16 + 16 * k;
+            if (c < n) PhiT[(size_t)c0 * n + c] = y[k];
+        }
     }
 }
 
@@ -2473,10 +3011,47 @@ int basq_finalize_f64(const double* parts, int32_t n_parts, int32_t msg_rows, in
     return BASQ_OK;
 }
 
+// workspace (doubles) of the cluster kernels for an [s, M] reduction: 16 counter/flag words + the message ring
+static inline size_t cluster_ws_doubles(int nv, int ncu) { return 16 + (size_t)(2 * BASQ_WPG * ncu) * (nv * 64 + 8); }
+
+#ifndef BASQ_CAR_CLUSTER
+#define BASQ_CAR_CLUSTER 1      // 0: the one-work-group LDS / global-memory kernels of round 1 (kept for A/B timing)
+#endif
+
+int64_t basq_reduction_ws_doubles(int32_t s, int32_t M) {
+    if (s < 1 || M <= s || M > 1024) return 0;
+    size_t need = 0;
+    // 4-CU clusters (elimination ring: 2 W slots; bidiagonalisation: 2 x (NCU + 1) messages -- the ring is the larger)
+    if (M > 256 && M <= 512 && (s <= 256 || (M - s) <= 256)) need = cluster_ws_doubles(8, 4);
+    return (int64_t)need;
+}
+
 int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32_t* keep_rank, int32_t* kept,
-                           double* w_star, int32_t* info, void* stream) {
+                           double* w_star, int32_t* info, double* ws, void* stream) {
     if (!PhiT || !mu || !keep_rank || !kept || !w_star || !info || M < 1 || M > 1024 || s < 1 || s > M)
         return BASQ_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nrows = M - s;
+#if BASQ_CAR_CLUSTER
+    constexpr int T = BASQ_WPG * 64;
+    if (nrows >= 1 && M <= 256 && nrows <= BASQ_WPG * 14) {        // one CU, rows in registers (n <= 112: M = 2n <= 224)
+        if (nrows <= BASQ_WPG * 4)
+            hipLaunchKernelGGL((car_eliminate_cluster_kernel<4, 4, 1>), dim3(1), dim3(T), 0, st, PhiT, mu, M, s,
+                               keep_rank, kept, w_star, info, (double*)nullptr, 1);
+        else
+            hipLaunchKernelGGL((car_eliminate_cluster_kernel<4, 14, 1>), dim3(1), dim3(T), 0, st, PhiT, mu, M, s,
+                               keep_rank, kept, w_star, info, (double*)nullptr, 1);
+        BASQ_CHECK_LAUNCH();
+        return BASQ_OK;
+    }
+    if (nrows >= 1 && M <= 512 && nrows <= 4 * BASQ_WPG * 8 && ws) {   // 4-CU cluster (n = 200: M = 400, 200 null vectors)
+        if (hipMemsetAsync(ws, 0, 16 * sizeof(double), st) != hipSuccess) return BASQ_ELAUNCH;
+        hipLaunchKernelGGL((car_eliminate_cluster_kernel<8, 8, 4>), dim3(4 * 8), dim3(T), 0, st, PhiT, mu, M, s,
+                           keep_rank, kept, w_star, info, ws, 8);
+        BASQ_CHECK_LAUNCH();
+        return BASQ_OK;
+    }
+#endif
     const size_t lds = (size_t)(M - s) * M * sizeof(double);
     if (s < M && lds <= 162560) {      // 163840 B per CU minus the kernel's static LDS
         if (hipFuncSetAttribute((const void*)car_eliminate_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2484,23 +3059,40 @@ int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32
             return BASQ_ELAUNCH;
         // 1024 threads: A/B-measured 4.8 ms per batch vs 5.6 (512) and 8.2 (256) -- the rank-1 updates dominate
         const int nthreads = (M <= BASQ_CAR_THREADS) ? BASQ_CAR_THREADS : ((M <= 512) ? 512 : 1024);
-        hipLaunchKernelGGL(car_eliminate_lds_kernel, dim3(1), dim3(nthreads), lds, (hipStream_t)stream, PhiT, mu, M, s,
+        hipLaunchKernelGGL(car_eliminate_lds_kernel, dim3(1), dim3(nthreads), lds, st, PhiT, mu, M, s,
                            keep_rank, kept, w_star, info);
         BASQ_CHECK_LAUNCH();
         return BASQ_OK;
     }
-    hipLaunchKernelGGL(car_eliminate_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, PhiT, mu, M, s, keep_rank,
+    hipLaunchKernelGGL(car_eliminate_kernel, dim3(1), dim3(1024), 0, st, PhiT, mu, M, s, keep_rank,
                        kept, w_star, info);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }
 
-int basq_nullspace_f64(const double* X, int32_t s, int32_t M, double* V, double* tau, double* PhiT, void* stream) {
+#ifndef BASQ_NS_CLUSTER
+#define BASQ_NS_CLUSTER 1       // 0: the one-work-group kernels of round 1 (kept for A/B timing)
+#endif
+#ifndef BASQ_NS_APPLY16
+#define BASQ_NS_APPLY16 1
+#endif
+
+int basq_nullspace_f64(const double* X, int32_t s, int32_t M, double* V, double* tau, double* PhiT, double* ws,
+                       void* stream) {
     if (!X || !V || !tau || !PhiT || s < 1 || M <= s || M > 1024) return BASQ_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const size_t LDS_MAX = 163840 - 64;                         // per-CU LDS minus the kernel's static scalar
     int rc;
-    if (M <= 256 && s <= 112) {                                 // whole matrix in registers
+    constexpr int T = BASQ_WPG * 64;
+    if (BASQ_NS_CLUSTER && M <= 256 && s <= BASQ_WPG * 14) {    // one CU, the whole matrix in registers
+        if (s <= BASQ_WPG * 4) hipLaunchKernelGGL((bidiag_cluster_kernel<4, 4, 1>), dim3(1), dim3(T), 0, st, X, s, M, V, tau, (double*)nullptr, 1);
+        else hipLaunchKernelGGL((bidiag_cluster_kernel<4, 14, 1>), dim3(1), dim3(T), 0, st, X, s, M, V, tau, (double*)nullptr, 1);
+        rc = (hipGetLastError() == hipSuccess) ? BASQ_OK : BASQ_ELAUNCH;
+    } else if (BASQ_NS_CLUSTER && M <= 512 && s <= 4 * BASQ_WPG * 8 && ws) {   // 4-CU cluster
+        if (hipMemsetAsync(ws, 0, 16 * sizeof(double), st) != hipSuccess) return BASQ_ELAUNCH;
+        hipLaunchKernelGGL((bidiag_cluster_kernel<8, 8, 4>), dim3(4 * 8), dim3(T), 0, st, X, s, M, V, tau, ws, 8);
+        rc = (hipGetLastError() == hipSuccess) ? BASQ_OK : BASQ_ELAUNCH;
+    } else if (M <= 256 && s <= 112) {                          // whole matrix in registers (16 waves)
         if (s <= 32) hipLaunchKernelGGL((bidiag_reflectors_reg_kernel<4, 2>), dim3(1), dim3(1024), 0, st, X, s, M, V, tau);
         else if (s <= 64) hipLaunchKernelGGL((bidiag_reflectors_reg_kernel<4, 4>), dim3(1), dim3(1024), 0, st, X, s, M, V, tau);
         else hipLaunchKernelGGL((bidiag_reflectors_reg_kernel<4, 7>), dim3(1), dim3(1024), 0, st, X, s, M, V, tau);
@@ -2517,6 +3109,15 @@ int basq_nullspace_f64(const double* X, int32_t s, int32_t M, double* V, double*
     }
     if (rc != BASQ_OK) return rc;
     const int nvec = M - s;
+    if (BASQ_NS_APPLY16 && M <= 512) {
+        const dim3 grid((nvec + 15) / 16), block(256);
+        if (M <= 208) hipLaunchKernelGGL(nullspace_apply16_kernel<13>, grid, block, 0, st, V, tau, s, M, PhiT);
+        else if (M <= 256) hipLaunchKernelGGL(nullspace_apply16_kernel<16>, grid, block, 0, st, V, tau, s, M, PhiT);
+        else if (M <= 400) hipLaunchKernelGGL(nullspace_apply16_kernel<25>, grid, block, 0, st, V, tau, s, M, PhiT);
+        else hipLaunchKernelGGL(nullspace_apply16_kernel<32>, grid, block, 0, st, V, tau, s, M, PhiT);
+        BASQ_CHECK_LAUNCH();
+        return BASQ_OK;
+    }
     const dim3 grid((nvec + 3) / 4), block(256);
     if (M <= 256) hipLaunchKernelGGL(nullspace_apply_kernel<4>, grid, block, 0, st, V, tau, s, M, PhiT);
     else if (M <= 512) hipLaunchKernelGGL(nullspace_apply_kernel<8>, grid, block, 0, st, V, tau, s, M, PhiT);

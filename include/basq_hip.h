@@ -149,13 +149,23 @@ int basq_finalize_f64(const double* parts, int32_t n_parts, int32_t msg_rows, in
  * LAPACK returns, not only on the null space; that basis is rows s..M-1 of P^T, P = G_0 ... G_{s-1} the product
  * of the right Householder reflectors of gesdd's bidiagonal reduction (dgebrd, m < n, dlarfg sign convention) --
  * the rotations that follow never touch those rows.  This entry generates the same reflectors on the GPU
- * (one work-group, rows resident in registers/LDS) and applies them to the unit vectors e_s..e_{M-1}:
+ * (matrix resident in registers: one work-group for M <= 256, a cluster of four exchanging one message per step
+ * through `ws` for M <= 512, see basq_reduction_ws_doubles) and applies them to the unit vectors e_s..e_{M-1}:
  *     PhiT [M-s, M]  (rows = null vectors, what basq_car_eliminate_f64 consumes).
  * Scratch: V [s, M] (reflector vectors; also row storage when s*M exceeds the LDS), tau [s].
  * Agreement with the host LAPACK rows is at rounding level (~1e-13); 1 <= s < M <= 1024.
  */
-int basq_nullspace_f64(const double* XcarT, int32_t s, int32_t M, double* V, double* tau, double* PhiT,
+int basq_nullspace_f64(const double* XcarT, int32_t s, int32_t M, double* V, double* tau, double* PhiT, double* ws,
                        void* stream);
+
+/*
+ * Workspace (in doubles) that basq_nullspace_f64 / basq_car_eliminate_f64 need in `ws` for an [s, M] reduction:
+ * 0 when the shape runs on one compute unit (M <= 256: ws may be NULL), otherwise the message ring + flag words of the
+ * 4-work-group cluster kernels (M = 2n = 400 at n = 200: the 200 x 400 matrix does not fit one CU's registers).  The
+ * caller owns the buffer (the library allocates nothing); the entries zero its flag words themselves.  Without a
+ * workspace (ws == NULL) such shapes fall back to slower single-work-group kernels.
+ */
+int64_t basq_reduction_ws_doubles(int32_t s, int32_t M);
 
 /*
  * Caratheodory elimination -- the loop of Tchernychova_Lyons_CAR, BASQ/_rchq.py:146-175, in the
@@ -164,11 +174,12 @@ int basq_nullspace_f64(const double* XcarT, int32_t s, int32_t M, double* V, dou
  * full Vh of the SVD at :140-143); it is destroyed.  mu [M] holds the set weights on entry and the
  * reduced weights on exit (zero for eliminated sets).  Outputs: keep_rank[M] (rank among survivors
  * or -1), kept[<=s] ascending survivor ids, w_star[<=s], info[0] = n_keep, info[1] = status
- * (0 ok, 1 = a null vector had no positive entry: the reference would raise at :152).
- * Single work-group kernel; M <= 1024.
+ * (0 ok, 1 = a null vector had no positive entry: the reference would raise at :152; 2 = a cluster kernel's
+ * bounded spin timed out -- never in a healthy run).  Null vectors live in registers (one work-group for M <= 256,
+ * a 4-work-group cluster through `ws` for M <= 512, see basq_reduction_ws_doubles; ws may be NULL otherwise); M <= 1024.
  */
 int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32_t* keep_rank, int32_t* kept,
-                           double* w_star, int32_t* info, void* stream);
+                           double* w_star, int32_t* info, double* ws, void* stream);
 
 /*
  * Survivor re-weighting and order-preserving compaction, BASQ/_rchq.py:107-130.

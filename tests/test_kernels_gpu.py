@@ -424,3 +424,36 @@ def test_fuzz_single_workgroup_kernels(hip_ops):
     from fuzz_reduction import run
 
     assert run(30, 7, hip_ops).startswith("fuzz ok")
+
+
+@pytest.mark.parametrize("s,M", [(200, 400), (100, 200), (150, 400), (256, 512), (101, 500)])
+def test_cluster_reductions_repeatable_under_load(hip_ops, s, M):
+    """The cluster kernels (one message per step through LDS, or through global memory between the four work-groups of
+    a cluster) hand data between waves / CUs by hand: run null space + elimination repeatedly while a second stream
+    keeps the chip busy with unrelated work (uneven load, warm caches) -- every repetition must return the LAPACK rows
+    and bit-identical survivors.  A stale or torn hand-off shows up as a differing last bit or a wrong pivot."""
+    g = torch.Generator().manual_seed(s + 7 * M)
+    X = torch.randn(s, M, generator=g, dtype=torch.float64)
+    X[0] = 1.0
+    ref = torch.linalg.svd(X)[2][s:]
+    mu = torch.rand(M, generator=g, dtype=torch.float64) + 0.05
+    mu = mu / mu.sum()
+    Xd, mud = hip_ops.to_device(X), hip_ops.to_device(mu)
+    side = torch.cuda.Stream()
+    A = torch.randn(4096, 4096, device=hip_ops.device, dtype=torch.float32)
+    first = None
+    for rep in range(12):
+        with torch.cuda.stream(side):                          # uneven background load: a few large GEMMs per repetition
+            for _ in range(1 + rep % 3):
+                A = torch.tanh(A @ A * 1e-3)
+        P = hip_ops.nullspace(Xd, s, M)
+        kr, kept, w, info = hip_ops.car_eliminate(P.clone(), mud.clone(), M, s)
+        out = (P.cpu(), kr.cpu(), w.cpu(), info.cpu().tolist())
+        assert out[3][1] == 0, "status"
+        assert (out[0] - ref).abs().max().item() <= 1e-11
+        if first is None:
+            first = out
+        else:
+            assert torch.equal(out[0], first[0]), f"repetition {rep}: null space differs bitwise"
+            assert torch.equal(out[1], first[1]) and torch.equal(out[2][: out[3][0]], first[2][: first[3][0]])
+    torch.cuda.synchronize()

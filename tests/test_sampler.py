@@ -73,3 +73,49 @@ def test_predict_oracle_is_the_gp_posterior():
     mean, var = predict_oracle(Xobs, model)
     assert (mean - y).abs().max().item() <= 1e-4
     assert (var > 0).all() and var.max().item() <= 1e-4
+
+
+def test_device_generation_statistics_host_logic():
+    """``generator_parity=False``: pools / mixture draws come from ``mvn_draw`` on the target device (here the CPU as a
+    stand-in): right shapes, first two moments of the prior."""
+    from torch.distributions.multivariate_normal import MultivariateNormal
+
+    from basq_amd._sampler import PriorSampler
+
+    cov = torch.tensor([[2.0, 0.3], [0.3, 0.5]], dtype=torch.float64)
+    prior = MultivariateNormal(torch.tensor([1.0, -2.0], dtype=torch.float64), cov)
+    torch.manual_seed(0)
+    nys, rec, w = PriorSampler(prior, 40_000, 1e-2, "cpu", generator_parity=False)(40_000)
+    assert rec.shape == (40_000, 2) and nys.shape == (400, 2) and torch.equal(nys, rec[:400])
+    assert (rec.mean(0) - prior.loc).abs().max().item() < 0.03
+    assert (torch.cov(rec.T) - cov).abs().max().item() < 0.05
+    assert abs(float(w.sum()) - 1.0) < 1e-12
+
+
+@pytest.mark.gpu
+def test_device_generation_leaves_the_host_generator_alone(hip_ops):
+    """SURVEY f4's purpose: with ``generator_parity=False`` the pool is generated on the GPU -- the CPU generator is not
+    consumed (no host RNG work) and the tensors are born on the device (no H2D copy); the uncertainty sampler runs
+    end to end the same way and returns a normalised weight vector."""
+    from torch.distributions.multivariate_normal import MultivariateNormal
+
+    from basq_amd._sampler import PriorSampler, UncertaintySampler
+
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        c = CASES[0]
+        prior = prior_of(c["d"])
+        torch.manual_seed(123)
+        before = torch.get_rng_state()
+        nys, rec, w = PriorSampler(prior, 100_000, 1e-2, "cuda:0", generator_parity=False)(100_000)
+        assert rec.is_cuda and nys.is_cuda and rec.shape == (100_000, c["d"])
+        assert (rec.mean(0).cpu() - prior.loc).abs().max().item() < 0.05
+        us = UncertaintySampler(prior, sampler_model(c), c["n"], c["nys_ratio"], "cuda:0", sampling_method="exact",
+                                ratio=0.5, ratio_super=20, n_gaussians=c["n_gaussians"], ops=hip_ops, generator_parity=False)
+        pts_nys, pts_rec, wts = us(c["n"])
+        assert pts_rec.is_cuda and abs(float(wts.sum()) - 1.0) < 1e-12 and bool((wts >= 0).all())
+        assert torch.equal(torch.get_rng_state(), before), "the CPU generator was consumed"
+        assert isinstance(prior, MultivariateNormal)
+    finally:
+        torch.set_default_dtype(prev)
