@@ -177,12 +177,21 @@ def _cholqr(ops, X, flags, passes=2):
     cond(X) < ~1e7 (needed for the final basis); one pass (orthonormal to ~cond^2 eps, i.e. perfectly
     conditioned for the next multiplication by A) is enough for the intermediate subspace iterates, whose
     only role is their range.  The pivot flags (device int32) are appended to ``flags`` and checked once, later.
+
+    ``Q = X L^{-T}`` is a row-parallel triangular solve (``basq_trsm_rows_f64``) against the factor of the panel Cholesky
+    (``basq_chol_factor_f64``): no inverse is formed.  Ranks beyond the panel kernel's LDS capacity (k > 200) use the
+    inverse-based kernels of round 1.
     """
+    k = X.shape[1]
     for _ in range(passes):
         G = _mm_splitk(ops, X.t(), X, 32)
-        W, info = ops.chol_inv(G)
-        flags.append(info)
-        X = ops.matmul(X, W)
+        if k <= getattr(ops, "CHOL_FACTOR_MAX_Q", 0):
+            flags.append(ops.chol_factor(G))
+            X = ops.trsm_rows(X, G)
+        else:
+            W, info = ops.chol_inv(G)
+            flags.append(info)
+            X = ops.matmul(X, W)
     return X
 
 
@@ -355,16 +364,23 @@ def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None, overlap=
             Q = _cholqr(ops, prod.a(Q), flags, passes=1)
             Q = _cholqr(ops, prod.at(Q), flags, passes=1)
             Q = _cholqr(ops, prod.a(Q), flags, passes=2)         # the basis that is actually used
-            B = prod.qta(Q)                                    # [k, m]
-            # LQ of B (CholeskyQR2 on its rows):  B = L1 L2 Qb^T  ->  left singular vectors of B = those of L
-            G1 = _mm_splitk(ops, B, B.t(), 32)
-            W1, i1 = ops.chol_inv(G1)
-            Bq = ops.matmul(W1.t(), B)
-            G2 = _mm_splitk(ops, Bq, Bq.t(), 32)
-            _, i2 = ops.chol_inv(G2)
+            # LQ of B = Q^T A ([k, m]) by CholeskyQR2 on its rows, formed on Y = B^T = A^T Q ([m, k]: tall, row-parallel):
+            #   B = L1 L2 Qb^T  ->  the left singular vectors of B are those of L = L1 L2
+            Y = prod.at(Q)
+            k = Y.shape[1]
+            G1 = _mm_splitk(ops, Y.t(), Y, 32)                 # = B B^T
+            if k <= getattr(ops, "CHOL_FACTOR_MAX_Q", 0):
+                i1 = ops.chol_factor(G1)
+                Yq = ops.trsm_rows(Y, G1)                       # = (L1^-1 B)^T
+                G2 = _mm_splitk(ops, Yq.t(), Yq, 32)
+                i2 = ops.chol_factor(G2)
+            else:
+                W1, i1 = ops.chol_inv(G1)
+                Yq = ops.matmul(Y, W1)
+                G2 = _mm_splitk(ops, Yq.t(), Yq, 32)
+                _, i2 = ops.chol_inv(G2)
             L = ops.matmul(torch.tril(G1), torch.tril(G2))
             bad = torch.stack([f.reshape(()) for f in flags + [i1, i2]]).max()
-            k = L.shape[0]
             both, ready = ops.to_host_async(torch.cat([L.reshape(-1), bad.to(torch.float64).reshape(1)]), "basisL")
         if overlap is not None:
             overlap()

@@ -38,8 +38,6 @@ SIGNATURES = {
     "basq_gram_f64": (C.c_int, [_specp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "basq_kernel_matvec_f64": (C.c_int, [_specp, _vp, _i64, _vp, _i64, _vp, _f64, _vp, _vp]),
     "basq_blocksum_f64": (C.c_int, [_specp, _vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
-    "basq_blocksum_valu_f64": (C.c_int, [_specp, _vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp,
-                                         _vp]),
     "basq_project_f64": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _f64, _i32, _vp, _vp, _vp]),
     "basq_finalize_f64": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _f64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "basq_nullspace_f64": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
@@ -51,6 +49,8 @@ SIGNATURES = {
     "basq_dense_blocksum_f64": (C.c_int, [_vp, _i32, _i64, _i64, _vp, _i64, _i64, _i32, _f64, _i32, _vp, _vp]),
     "basq_box_muller_f64": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "basq_chol_inv_f64": (C.c_int, [_vp, _i32, _vp, _vp, _f64, _vp]),
+    "basq_chol_factor_f64": (C.c_int, [_vp, _i32, _vp, _f64, _vp]),
+    "basq_trsm_rows_f64": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp]),
     "basq_gemm_f64": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _f64, _vp]),
 }
 

@@ -105,7 +105,7 @@ class HipOps:
                                               _ptr(out), self._stream()), "basq_kernel_matvec_f64")
         return out
 
-    def blocksum(self, spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, impl="mfma", out=None):
+    def blocksum(self, spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, out=None):
         """``out = (Xpart [n_chunks, m, S], totpart [n_chunks, S])``: write into caller-provided (contiguous) slices."""
         if out is None:
             Xpart = self.empty(n_chunks, m, S)
@@ -119,9 +119,8 @@ class HipOps:
             totpart.zero_()
             return Xpart, totpart
         sc = self.spec_c(spec)
-        fn = self.lib.basq_blocksum_f64 if impl == "mfma" else self.lib.basq_blocksum_valu_f64
-        check(fn(C.byref(sc), _ptr(nys), m, _ptr(cand), _ptr(mu), _ptr(wx), Rl, off, n_full, S, n_chunks, _ptr(Xpart),
-                 _ptr(totpart), self._stream()), "basq_blocksum_f64")
+        check(self.lib.basq_blocksum_f64(C.byref(sc), _ptr(nys), m, _ptr(cand), _ptr(mu), _ptr(wx), Rl, off, n_full, S,
+                                         n_chunks, _ptr(Xpart), _ptr(totpart), self._stream()), "basq_blocksum_f64")
         return Xpart, totpart
 
     def project(self, U, q, m, Xpart, totpart, n_chunks, S, outputscale, ksplit=None):
@@ -238,6 +237,26 @@ class HipOps:
         check(self.lib.basq_chol_inv_f64(_ptr(G), q, _ptr(W), _ptr(info), float(rel_tol), self._stream()),
               "basq_chol_inv_f64")
         return W, info
+
+    CHOL_FACTOR_MAX_Q = 200          # packed lower triangle in LDS
+    TRSM_MAX_Q = 318
+
+    def chol_factor(self, G, rel_tol=1e-12):
+        """In place: G -> L (lower triangle).  Returns info[1] int32 on the device (0 ok, j+1: pivot j too small)."""
+        self._chk(G)
+        info = self.empty(1, dtype=torch.int32)
+        check(self.lib.basq_chol_factor_f64(_ptr(G), G.shape[0], _ptr(info), float(rel_tol), self._stream()),
+              "basq_chol_factor_f64")
+        return info
+
+    def trsm_rows(self, X, L):
+        """``X @ L^-T`` for a tall X [rows, q] (row-major) and the factor left by ``chol_factor``."""
+        self._chk(X)
+        self._chk(L)
+        rows, q = X.shape
+        out = self.empty(rows, q)
+        check(self.lib.basq_trsm_rows_f64(_ptr(X), q, rows, q, _ptr(L), _ptr(out), q, self._stream()), "basq_trsm_rows_f64")
+        return out
 
     def gemm(self, A, B, alpha=1.0):
         """C = alpha * A @ B on the f64 matrix cores (own kernel)."""

@@ -85,17 +85,18 @@ def rows_per_wave(kk: int) -> int:
 
 
 def choose_chunks(n_local_blocks: int, m: int, S: int, kk: int = 3, max_chunks: int = 32, min_blocks: int = 4,
-                  resident: int = RESIDENT_WAVES) -> int:
+                  resident: int = RESIDENT_WAVES, geometry=None) -> int:
     """Number of chunks the block loop is split into.
 
     All waves of a launch do the same amount of work, so the launch takes ``ceil(waves / resident)``
     "rounds": 4800 waves on 3072 resident slots cost 2 rounds for 1.56 rounds of work (measured: 22 % of
     the kernel time).  Pick the smallest chunk count whose efficiency ``(waves/resident) /
     ceil(waves/resident)`` reaches 96 % (fewer chunks = less partial-sum traffic for the projection), else
-    the most efficient one.  ``kk`` = packed row length / 4.
+    the most efficient one.  ``kk`` = packed row length / 4.  ``geometry`` = (Nystrom rows per work-group, sets per
+    wave) of the block-sum form in use (``HipOps.blocksum_geometry``); default: the MFMA form's.
     """
-    rows_per_block = 4 * rows_per_wave(kk)
-    per_chunk = ((m + rows_per_block - 1) // rows_per_block) * 4 * ((S + SETS_PER_WAVE - 1) // SETS_PER_WAVE)
+    rows_per_block, sets_per_wave = geometry or (4 * rows_per_wave(kk), SETS_PER_WAVE)
+    per_chunk = ((m + rows_per_block - 1) // rows_per_block) * 4 * ((S + sets_per_wave - 1) // sets_per_wave)
     cap = max(1, min(max_chunks, n_local_blocks // min_blocks))
     best, best_eff = 1, -1.0
     for c in range(1, cap + 1):

@@ -50,35 +50,16 @@ __device__ __forceinline__ double exp_nonpos(double x) {
     return __hiloint2double(hi, __double2loint(p));
 }
 
-// Block-sum forms of exp (constants pinned in VGPRs: the scalar-broadcast kernel keeps two candidate rows,
-// 2 x 26 SGPRs at d = 10, in scalar registers; fp64 literals would claim 20-30 more SGPRs and push the rows
-// into v_writelane spills).  BASQ_EXP_MODE selects the evaluation (A/B-measured, tools/bench_blocksum.py):
-//   0  x = n ln2 + r, degree-10 polynomial, 2^n by ldexp                        (14 fp64 VALU, no memory)
-//   1  x = (32n + j) ln2/32 + r, T[j] = 2^(j/32) from a 256-B LDS table (one bank row: conflict-free),
-//      degree-5 polynomial                                                       (11 fp64 VALU + ds_read)
-//   2  the same with the table in global memory (L1-resident; vmcnt instead of lgkmcnt, so the wait for
-//      the table value does not drain the in-flight scalar loads of the next candidate row)
-//   3  x = (2048n + j) ln2/2048 + r, 16-KB LDS table, degree-3 polynomial          (8 fp64 VALU + ds_read)
-#ifndef BASQ_EXP_MODE
-#define BASQ_EXP_MODE 3
-#endif
-
-#if BASQ_EXP_MODE == 3
+// Block-sum form of exp: x = (2048 n + j) ln2/2048 + r, T[j] = 2^(j/2048) from a 16-KB LDS table, degree-3 polynomial
+// in r (|r| < 1.7e-4, error 1e-17), 2^n by ldexp -- 8 fp64 VALU instructions + one ds_read, no fp64 transcendental
+// hardware involved.  (Round 1 A/B-timed three other evaluations -- a degree-10 polynomial without a table, a 32-entry
+// table in LDS or in global memory with a degree-5 polynomial; profiles/r01_blocksum_exp_modes_ab.txt -- this one won.)
+// The constants are pinned in VGPRs: an fp64 literal costs an SGPR pair and a constant-bus slot per use.
 #define BASQ_TAB_N 2048
 __device__ const double basq_exp_tab_g[2048] = BASQ_EXP_TAB2048;
-#else
-#define BASQ_TAB_N 32
-__device__ const double basq_exp_tab_g[32] = BASQ_EXP_TAB;
-#endif
 
 struct ExpK {
-#if BASQ_EXP_MODE == 0
-    double log2e, nhi, nlo, magic, p[11];
-#elif BASQ_EXP_MODE == 3
-    double k32, nhi, nlo, magic, c3, c2, one;
-#else
-    double k32, nhi, nlo, magic, c5, c4, c3, c2, one;
-#endif
+    double k32, nhi, magic, c3, c2, one;
 };
 
 __device__ __forceinline__ double vgpr_const(double x) {
@@ -88,80 +69,31 @@ __device__ __forceinline__ double vgpr_const(double x) {
 
 __device__ __forceinline__ void expk_init(ExpK& k) {
     k.magic = vgpr_const(0x1.8p52);
-#if BASQ_EXP_MODE == 0
-    k.log2e = vgpr_const(BASQ_LOG2E);
-    k.nhi = vgpr_const(-BASQ_LN2_HI);
-    k.nlo = vgpr_const(-BASQ_LN2_LO);
-    const double c[11] = {BASQ_EXP_P0, BASQ_EXP_P1, BASQ_EXP_P2, BASQ_EXP_P3, BASQ_EXP_P4, BASQ_EXP_P5,
-                          BASQ_EXP_P6, BASQ_EXP_P7, BASQ_EXP_P8, BASQ_EXP_P9, BASQ_EXP_P10};
-#pragma unroll
-    for (int i = 0; i < 11; ++i) k.p[i] = vgpr_const(c[i]);
-#elif BASQ_EXP_MODE == 3
     k.k32 = vgpr_const(BASQ_2048_OVER_LN2);
     k.nhi = vgpr_const(-BASQ_LN2_2048_HI);
-    k.nlo = vgpr_const(-BASQ_LN2_2048_LO);
     k.c3 = vgpr_const(BASQ_EXP_U3);
     k.c2 = vgpr_const(BASQ_EXP_U2);
     k.one = vgpr_const(1.0);
-#else
-    k.k32 = vgpr_const(BASQ_32_OVER_LN2);
-    k.nhi = vgpr_const(-BASQ_LN2_32_HI);
-    k.nlo = vgpr_const(-BASQ_LN2_32_LO);
-    k.c5 = vgpr_const(BASQ_EXP_T5);
-    k.c4 = vgpr_const(BASQ_EXP_T4);
-    k.c3 = vgpr_const(BASQ_EXP_T3);
-    k.c2 = vgpr_const(BASQ_EXP_T2);
-    k.one = vgpr_const(1.0);
-#endif
 }
 
 // `tab` = LDS copy of the table (exp_table_init); valid for -1.4e9 < x <= ~1, exact 0 below ~-745.
 __device__ __forceinline__ double exp_nonpos_k(double x, const ExpK& k, const double* tab) {
-#if BASQ_EXP_MODE == 0
-    const double t = __builtin_fma(x, k.log2e, k.magic);
-    const double nf = t - k.magic;
-    double r = __builtin_fma(nf, k.nhi, x);
-    r = __builtin_fma(nf, k.nlo, r);
-    double p = k.p[10];
-#pragma unroll
-    for (int i = 9; i >= 0; --i) p = __builtin_fma(p, r, k.p[i]);
-    return ldexp(p, __double2loint(t));
-#else
     const double t = __builtin_fma(x, k.k32, k.magic);
-    const int ti = __double2loint(t);                 // 32 n + j  (two's complement)
-#if BASQ_EXP_MODE == 2
-    const double T = basq_exp_tab_g[ti & 31];
-#else
+    const int ti = __double2loint(t);                 // 2048 n + j  (two's complement)
     const double T = tab[ti & (BASQ_TAB_N - 1)];
-#endif
     const double nf = t - k.magic;
-    double r = __builtin_fma(nf, k.nhi, x);
-#if BASQ_EXP_MODE != 3
-    r = __builtin_fma(nf, k.nlo, r);
-#endif
-    // mode 3: ln2/2048 is used as ONE correctly rounded constant; the dropped tail |nf| * 1.1e-20 is a relative
-    // error of < 2e-15 in the kernel value for every argument whose exp exceeds 1e-22 (|nf| < 1.5e5)
-#if BASQ_EXP_MODE == 3
+    // ln2/2048 is used as ONE correctly rounded constant; the dropped tail |nf| * 1.1e-20 is a relative error of
+    // < 2e-15 in the kernel value for every argument whose exp exceeds 1e-22 (|nf| < 1.5e5)
+    const double r = __builtin_fma(nf, k.nhi, x);
     double w = __builtin_fma(k.c3, r, k.c2);
     w = __builtin_fma(w, r, k.one);
     const double e = __builtin_fma(T * r, w, T);      // T (1 + r w)
     return ldexp(e, ti >> 11);
-#else
-    double w = __builtin_fma(k.c5, r, k.c4);
-    w = __builtin_fma(w, r, k.c3);
-    w = __builtin_fma(w, r, k.c2);
-    w = __builtin_fma(w, r, k.one);
-    const double e = __builtin_fma(T * r, w, T);      // T (1 + r w)
-    return ldexp(e, ti >> 5);
-#endif
-#endif
 }
 
 __device__ __forceinline__ void exp_table_init(double* tab) {
-#if BASQ_EXP_MODE == 1 || BASQ_EXP_MODE == 3
     for (int i = threadIdx.x; i < BASQ_TAB_N; i += blockDim.x) tab[i] = basq_exp_tab_g[i];
     __syncthreads();
-#endif
 }
 
 // Kernel value (without outputscale) from D = -1/2 |(x-y)/l|^2.
@@ -209,6 +141,41 @@ __device__ __forceinline__ double sum16(double v) {
     v += __shfl_xor(v, 4, 64);
     v += __shfl_xor(v, 8, 64);
     return v;
+}
+
+#ifndef BASQ_WAVE_SUM_DPP
+#define BASQ_WAVE_SUM_DPP 1
+#endif
+// v shifted across lanes by a DPP control (row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143);
+// lanes without a source (or masked off) receive 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_shift_f64(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Sum over the 64 lanes, same value returned to every lane, fixed association.  DPP form: prefix sums inside
+// each row of 16 lanes (row_shr 1,2,4,8), row totals forwarded (row_bcast 15 / 31), lane 63 read back through
+// an SGPR -- ~20 VALU instructions instead of six dependent ds_bpermute round trips.
+__device__ __forceinline__ double wave_sum(double v) {
+#if BASQ_WAVE_SUM_DPP
+    v += dpp_shift_f64<0x111, 0xf>(v);
+    v += dpp_shift_f64<0x112, 0xf>(v);
+    v += dpp_shift_f64<0x114, 0xf>(v);
+    v += dpp_shift_f64<0x118, 0xf>(v);
+    v += dpp_shift_f64<0x142, 0xa>(v);
+    v += dpp_shift_f64<0x143, 0xc>(v);
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, 63);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+#else
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+#endif
 }
 
 // optional in-kernel phase stamps (tools/ns_prof.hip): wave w, lane 0 -> g_ns_prof[(t * 8 + slot) * 16 + w]
@@ -270,11 +237,17 @@ __global__ void init_state_kernel(double* __restrict__ mu, long long* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fused block sums, MFMA form (kept for A/B measurement only: basq_blocksum_mfma_f64; see the VALU form
-// below for why it is not the shipped one).  One wave owns a 64 x 16 tile of (Nystrom rows x sets):
+// Fused block sums.  One wave owns a 64 x 16 tile of (Nystrom rows x sets):
 // the A fragments of its 64 rows stay in registers for the whole launch; every iteration streams
 // the 16 candidates of one block that fall in the wave's 16 sets (B fragments), issues
 // JT*KK MFMAs for the exponent arguments and evaluates 16 kernel values per lane on the VALU.
+//
+// Why the matrix cores for d-dimensional distances (measured, profiles/r02_microbench_fp64_rates.txt, in-kernel clock
+// 2.3-2.4 GHz): v_mfma_f64_16x16x4 issues once per ~106 cycles (47 TF/s), a v_fma_f64 with constant operands once per
+// 4.2 (73 TF/s) -- but a distance FMA reads THREE vector registers, and all-VALU forms of this kernel (candidates through
+// the scalar cache in round 1, broadcast from an LDS tile in round 2: 18 tunings, profiles/r02_blocksum_lds_form_sweep.txt)
+// never got below 11.5 ms per 1e10 pairs against 8.4-9.1 ms for this form, whose operands arrive as plain coalesced
+// vector loads.  Per 64 pairs at d = 10: 0.78 MFMA (83 cycles) + 14.4 VALU (60 cycles) = its measured 143 cycles.
 // ------------------------------------------------------------------------------------------------
 struct BlocksumArgs {
     const double* nys;
@@ -501,299 +474,12 @@ static int dispatch_blocksum(int kk, int fam, const BlocksumArgs& A, hipStream_t
     return BASQ_EUNSUPPORTED;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Fused block sums, VALU form (the shipped one).  Measured on MI355X (profiles/r01_microbench_*):
-// v_mfma_f64_16x16x4 issues at ~100 cycles and shares the fp64 datapath with v_fma_f64 (~4.5 cycles);
-// per flop the matrix path is ~1.4x SLOWER than plain FMAs and does not overlap with them, so the
-// exponent argument is built with d FMAs per pair instead.
-//
-// One lane owns one Nystrom row j (its packed row lives in VGPRs for the whole launch); the candidates
-// are wave-uniform, so their rows arrive through the scalar cache (s_load) and feed the FMAs as SGPR
-// operands: no LDS, no VGPRs, no cross-lane traffic.  A wave covers ST consecutive sets of every block
-// of its chunk and keeps ST accumulators per lane.
-// ------------------------------------------------------------------------------------------------
-// One candidate, wave-uniform: KK tuples of 8 SGPRs (4 doubles each) + its weight(s).  The loads are
-// explicit s_load_dwordx8 with immediate offsets (hipcc's own choice was to load all ST rows up front and
-// spill them to VGPR lanes); per cdna_hip_programming.md §5.7 the destination registers are not touched by
-// compiler code until row_wait() has named them ("+s") behind the s_waitcnt.
-template <int KK>
-struct CandRow {
-    d4 v[KK];
-    double w;    // mu
-    double x;    // wx (only loaded when HAS_WX)
-};
-
-// T = candidate index relative to the base pointers (compile-time -> immediate offsets).
-template <int KK, int T, bool HAS_WX>
-__device__ __forceinline__ void row_issue(CandRow<KK>& r, const double* cand_base, const double* mu_base,
-                                          const double* wx_base) {
-#pragma unroll
-    for (int k = 0; k < KK; ++k)
-        asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(r.v[k]) : "s"(cand_base), "i"(T * KK * 32 + k * 32) : "memory");
-    asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(r.w) : "s"(mu_base), "i"(T * 8) : "memory");
-    if (HAS_WX) asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(r.x) : "s"(wx_base), "i"(T * 8) : "memory");
-}
-
-template <int KK, bool HAS_WX>
-__device__ __forceinline__ void row_wait(CandRow<KK>& r) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < KK; ++k) asm volatile("" : "+s"(r.v[k]));
-    asm volatile("" : "+s"(r.w));
-    if (HAS_WX) asm volatile("" : "+s"(r.x));
-}
-
-template <int KK, int FAM, bool HAS_WX>
-__device__ __forceinline__ double pair_term(const double (&pt)[KK * 4 - 2], double hj, double onej,
-                                            const CandRow<KK>& r, const ExpK& ek, const double* tab, double acc) {
-    constexpr int KP = KK * 4, DIMS = KP - 2;
-    double D = __builtin_fma(onej, r.v[KK - 1][3], hj);   // h_j + h_x  (onej = 1; 0 for the "all-ones" pseudo row)
-#pragma unroll
-    for (int k = 0; k < DIMS; ++k) D = __builtin_fma(pt[k], r.v[k >> 2][k & 3], D);
-    double e = kernel_from_arg_k<FAM>(D, ek, tab);
-    if (HAS_WX) e *= r.x;
-    return __builtin_fma(e, r.w, acc);
-}
-
-// The TJ Nystrom rows owned by one lane (rows jw + u*64 + lane, u < TJ).
-template <int KK, int TJ>
-struct LaneRows {
-    double pt[TJ][KK * 4 - 2];
-    double hj[TJ];
-    double onej[TJ];
-};
-
-// Fast path: ST consecutive candidates, all present.  Two rows live in SGPRs: the scalar loads of
-// candidate t+1 are in flight during the TJ * ~27 VALU instructions of candidate t.
-template <int KK, int FAM, int ST, int TJ, bool HAS_WX, int T>
-struct BlockStep {
-    static __device__ __forceinline__ void run(const LaneRows<KK, TJ>& L, const ExpK& ek, const double* tab,
-                                               CandRow<KK> (&rows)[2], const double* cb, const double* mb,
-                                               const double* xb, double (&acc)[TJ][ST]) {
-        row_wait<KK, HAS_WX>(rows[T & 1]);
-        if (T + 1 < ST) row_issue<KK, T + 1, HAS_WX>(rows[(T + 1) & 1], cb, mb, xb);
-#pragma unroll
-        for (int u = 0; u < TJ; ++u)
-            acc[u][T] = pair_term<KK, FAM, HAS_WX>(L.pt[u], L.hj[u], L.onej[u], rows[T & 1], ek, tab, acc[u][T]);
-        BlockStep<KK, FAM, ST, TJ, HAS_WX, T + 1>::run(L, ek, tab, rows, cb, mb, xb, acc);
-    }
-};
-template <int KK, int FAM, int ST, int TJ, bool HAS_WX>
-struct BlockStep<KK, FAM, ST, TJ, HAS_WX, ST> {
-    static __device__ __forceinline__ void run(const LaneRows<KK, TJ>&, const ExpK&, const double*, CandRow<KK> (&)[2],
-                                               const double*, const double*, const double*, double (&)[TJ][ST]) {}
-};
-
-template <int KK, int FAM, int ST, int TJ, bool HAS_WX>
-__global__ void __launch_bounds__(256)
-blocksum_valu_kernel(const double* __restrict__ nys, const double* __restrict__ cand, const double* __restrict__ mu,
-                     const double* __restrict__ wx, double* __restrict__ Xpart, long long Rl, long long off,
-                     long long n_full, long long blk_lo, long long blk_hi, long long blk_per_chunk, int m, int S,
-                     int n_chunks, int n_stiles) {
-    constexpr int KP = KK * 4, DIMS = KP - 2;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int b = blockIdx.x;
-    const int st = b % n_stiles;
-    b /= n_stiles;
-    const int chunk = b % n_chunks;
-    const int jg = b / n_chunks;
-    const int jw = (jg * 4 + wave) * (64 * TJ);
-    __shared__ double exp_tab[BASQ_TAB_N];
-    exp_table_init(exp_tab);                   // the only barrier of this kernel, before any early exit
-    if (jw >= m) return;                       // wave-uniform
-    const int mrows = ((m + 63) / 64) * 64;    // rows the caller allocated (padded to a multiple of 64)
-    LaneRows<KK, TJ> L;
-#pragma unroll
-    for (int u = 0; u < TJ; ++u) {
-        int j = jw + u * 64 + lane;
-        if (j >= mrows) j = mrows - 1;         // rows past the padding: computed, never stored
-        const double* row = nys + (long long)j * KP;
-#pragma unroll
-        for (int k = 0; k < DIMS; ++k) L.pt[u][k] = row[k];
-        L.hj[u] = row[KP - 2];
-        L.onej[u] = row[KP - 1];
-    }
-
-    double acc[TJ][ST];
-#pragma unroll
-    for (int u = 0; u < TJ; ++u)
-#pragma unroll
-        for (int t = 0; t < ST; ++t) acc[u][t] = 0.0;
-    ExpK ek;
-    expk_init(ek);
-
-    const int s0 = st * ST;
-    const int nset = (S - s0 < ST) ? (S - s0) : ST;                 // sets handled by this wave (uniform)
-    // local positions fit 32 bits (the pool is < 2^31 candidates)
-    const int lim = (int)(((off + Rl < n_full) ? (off + Rl) : n_full) - off);   // local end of block positions
-    long long bA = blk_lo + (long long)chunk * blk_per_chunk;
-    long long bB = bA + blk_per_chunk;
-    if (bB > blk_hi) bB = blk_hi;
-
-    // L2 warm-up.  The scalar path has no prefetcher and a candidate row is used once per wave, so an
-    // un-warmed s_load pays the full HBM latency (~750 cycles measured per candidate; the 4 waves of a block
-    // run in lockstep and cannot hide it for each other).  One vector load per lane touches the 128-B lines
-    // of the rows PF blocks ahead; its (dummy) result is waited for one block later, when it has long landed.
-    constexpr int PF = 2;
-    constexpr int ROW_LINES = (ST * KP * 8 + 127) / 128 + 1;         // lines spanned by ST packed rows (+1: alignment)
-    float pf_dummy = 0.f;
-    for (long long i = bA; i < bB; ++i) {
-        const long long base = i * S + s0 - off;                    // local position of set s0 in block i
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_dummy) : : "memory");
-        {
-            const long long pbase = base + (long long)PF * S;
-            if (i + PF < bB && pbase >= 0 && pbase + ST <= lim) {
-                const char* line = (const char*)(cand + pbase * KP) + lane * 128;
-                const char* mline = (const char*)(mu + pbase) + (lane - ROW_LINES) * 128;
-                const char* a = (lane < ROW_LINES) ? line : mline;
-                const char* last = (lane < ROW_LINES) ? (const char*)(cand + Rl * KP) - 4 : (const char*)(mu + Rl) - 4;
-                a = (a < last) ? a : last;
-                if (lane < ROW_LINES + (ST * 8 + 127) / 128 + 1)
-                    asm volatile("global_load_dword %0, %1, off" : "=v"(pf_dummy) : "v"(a) : "memory");
-            }
-        }
-        if (nset == ST && base >= 0 && base + ST <= lim) {
-            CandRow<KK> rows[2];
-            const double* cb = cand + base * KP;
-            const double* mb = mu + base;
-            const double* xb = HAS_WX ? (wx + base) : mu;
-            row_issue<KK, 0, HAS_WX>(rows[0], cb, mb, xb);
-            BlockStep<KK, FAM, ST, TJ, HAS_WX, 0>::run(L, ek, exp_tab, rows, cb, mb, xb, acc);
-        } else {
-            // shard edges / ragged last set tile: candidate by candidate, wave-uniform branches
-#pragma unroll
-            for (int t = 0; t < ST; ++t) {
-                const long long pl = base + t;
-                if (t < nset && pl >= 0 && pl < lim) {
-                    CandRow<KK> r;
-                    row_issue<KK, 0, HAS_WX>(r, cand + pl * KP, mu + pl, HAS_WX ? (wx + pl) : mu);
-                    row_wait<KK, HAS_WX>(r);
-#pragma unroll
-                    for (int u = 0; u < TJ; ++u)
-                        acc[u][t] = pair_term<KK, FAM, HAS_WX>(L.pt[u], L.hj[u], L.onej[u], r, ek, exp_tab, acc[u][t]);
-                }
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_dummy) : : "memory");
-
-    // Ragged tail (BASQ/_rchq.py:91-99): every local position >= n_full belongs to set S-1.
-    const long long t0 = (n_full > off) ? (n_full - off) : 0;
-    const int tl = (S - 1) - s0;
-    if (chunk == n_chunks - 1 && tl >= 0 && tl < ST && t0 < Rl) {
-        double ta[TJ];
-#pragma unroll
-        for (int u = 0; u < TJ; ++u) ta[u] = 0.0;
-        for (long long pl = t0; pl < Rl; ++pl) {
-            CandRow<KK> r;
-            row_issue<KK, 0, HAS_WX>(r, cand + pl * KP, mu + pl, HAS_WX ? (wx + pl) : mu);
-            row_wait<KK, HAS_WX>(r);
-#pragma unroll
-            for (int u = 0; u < TJ; ++u) ta[u] = pair_term<KK, FAM, HAS_WX>(L.pt[u], L.hj[u], L.onej[u], r, ek, exp_tab, ta[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < TJ; ++u)
-#pragma unroll
-            for (int t = 0; t < ST; ++t)
-                if (t == tl) acc[u][t] += ta[u];
-    }
-
-#pragma unroll
-    for (int u = 0; u < TJ; ++u) {
-        const int j = jw + u * 64 + lane;
-        if (j < m) {
-            double* out = Xpart + ((long long)chunk * m + j) * S + s0;
-#pragma unroll
-            for (int t = 0; t < ST; ++t)
-                if (t < nset) out[t] = acc[u][t];
-        }
-    }
-}
-
-// totpart[chunk][s] = sum of mu over the chunk's candidates of set s (BASQ/_rchq.py:90, :99); block order.
-__global__ void setsum_kernel(const double* __restrict__ mu, double* __restrict__ totpart, long long Rl, long long off,
-                              long long n_full, long long blk_lo, long long blk_hi, long long blk_per_chunk, int S,
-                              int n_chunks) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_chunks * S) return;
-    const int chunk = idx / S, s = idx % S;
-    const long long lim = ((off + Rl < n_full) ? (off + Rl) : n_full) - off;
-    long long bA = blk_lo + (long long)chunk * blk_per_chunk;
-    long long bB = bA + blk_per_chunk;
-    if (bB > blk_hi) bB = blk_hi;
-    double tot = 0.0;
-    for (long long i = bA; i < bB; ++i) {
-        const long long pl = i * S + s - off;
-        if (pl >= 0 && pl < lim) tot += mu[pl];
-    }
-    if (chunk == n_chunks - 1 && s == S - 1) {
-        const long long t0 = (n_full > off) ? (n_full - off) : 0;
-        for (long long pl = t0; pl < Rl; ++pl) tot += mu[pl];
-    }
-    totpart[idx] = tot;
-}
-
-#ifndef BASQ_ST
-#define BASQ_ST 20   // sets per wave
-#endif
 #ifndef BASQ_CAR_THREADS
 #define BASQ_CAR_THREADS 1024
 #endif
 #ifndef BASQ_CHOL_THREADS
 #define BASQ_CHOL_THREADS 1024   // work-group size of chol_inv_lds_kernel (multiple of 128)
 #endif
-#ifndef BASQ_VALU_MAX_KK
-#define BASQ_VALU_MAX_KK 3
-#endif
-#ifndef BASQ_TJ
-#define BASQ_TJ 1    // Nystrom rows per lane
-#endif
-
-template <int KK, int FAM>
-static int launch_blocksum_valu(const BlocksumArgs& A, hipStream_t st) {
-    const int n_stiles = (A.S + BASQ_ST - 1) / BASQ_ST;
-    const int jgroups = (A.m + 256 * BASQ_TJ - 1) / (256 * BASQ_TJ);
-    const long long nblk = (long long)n_stiles * A.n_chunks * jgroups;
-    if (nblk <= 0 || nblk > 0x7fffffffLL) return BASQ_EINVAL;
-    if (A.wx)
-        hipLaunchKernelGGL((blocksum_valu_kernel<KK, FAM, BASQ_ST, BASQ_TJ, true>), dim3((unsigned)nblk), dim3(256), 0, st, A.nys,
-                           A.cand, A.mu, A.wx, A.Xpart, A.Rl, A.off, A.n_full, A.blk_lo, A.blk_hi, A.blk_per_chunk, A.m,
-                           A.S, A.n_chunks, n_stiles);
-    else
-        hipLaunchKernelGGL((blocksum_valu_kernel<KK, FAM, BASQ_ST, BASQ_TJ, false>), dim3((unsigned)nblk), dim3(256), 0, st, A.nys,
-                           A.cand, A.mu, A.wx, A.Xpart, A.Rl, A.off, A.n_full, A.blk_lo, A.blk_hi, A.blk_per_chunk, A.m,
-                           A.S, A.n_chunks, n_stiles);
-    BASQ_CHECK_LAUNCH();
-    if (A.totpart) {
-        const int n = A.n_chunks * A.S;
-        hipLaunchKernelGGL(setsum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A.mu, A.totpart, A.Rl,
-                           A.off, A.n_full, A.blk_lo, A.blk_hi, A.blk_per_chunk, A.S, A.n_chunks);
-        BASQ_CHECK_LAUNCH();
-    }
-    return BASQ_OK;
-}
-
-template <int KK>
-static int dispatch_blocksum_valu_fam(int fam, const BlocksumArgs& A, hipStream_t st) {
-    switch (fam) {
-        case BASQ_FAMILY_RBF: return launch_blocksum_valu<KK, BASQ_FAMILY_RBF>(A, st);
-        case BASQ_FAMILY_MATERN52: return launch_blocksum_valu<KK, BASQ_FAMILY_MATERN52>(A, st);
-        case BASQ_FAMILY_MATERN32: return launch_blocksum_valu<KK, BASQ_FAMILY_MATERN32>(A, st);
-    }
-    return BASQ_EUNSUPPORTED;
-}
-
-static int dispatch_blocksum_valu(int kk, int fam, const BlocksumArgs& A, hipStream_t st) {
-    switch (kk) {
-        case 1: return dispatch_blocksum_valu_fam<1>(fam, A, st);
-        case 2: return dispatch_blocksum_valu_fam<2>(fam, A, st);
-        case 3: return dispatch_blocksum_valu_fam<3>(fam, A, st);
-#if BASQ_VALU_MAX_KK >= 4
-        case 4: return dispatch_blocksum_valu_fam<4>(fam, A, st);
-#endif
-    }
-    return BASQ_EUNSUPPORTED;
-}
 
 // ------------------------------------------------------------------------------------------------
 // Dense kernel matrix: wave = 64 rows x (CT x 16) columns, A fragments resident.
@@ -1469,8 +1155,8 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) car_eliminate_cluster_kernel(co
 #pragma unroll
         for (int kk = 0; kk < NV; ++kk) {                                               // :158-159
             const double step = aj * phi[kk];
-            mu[kk] = mu[kk] - step;
-            if (kk == kj && lane == lane_j) { mu[kk] = 0.0; deadmask |= 1u << kk; }
+            if (kk == kj && lane == lane_j) deadmask |= 1u << kk;
+            mu[kk] = ((deadmask >> kk) & 1u) ? 0.0 : (mu[kk] - step);   // eliminated columns: the reference has Phi = 0, mu = 0
         }
         auto update_row = [&](double (&r)[NV]) {                                        // :165-171
             const double pj = readlane_f64(pick_slot<NV>(r, kj), lane_j);
@@ -1547,41 +1233,6 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) car_eliminate_cluster_kernel(co
 // when they do not fit); 4 barriers per step.  Outputs V[i, :] = v_i and tau[i].
 // nullspace_apply_kernel: one wave per null vector c: y = e_{m+c}; for i = m-1..0: y -= tau_i (v_i . y) v_i.
 // ------------------------------------------------------------------------------------------------
-#ifndef BASQ_WAVE_SUM_DPP
-#define BASQ_WAVE_SUM_DPP 1
-#endif
-// v shifted across lanes by a DPP control (row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143);
-// lanes without a source (or masked off) receive 0.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_shift_f64(double v) {
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, true);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, true);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-// Sum over the 64 lanes, same value returned to every lane, fixed association.  DPP form: prefix sums inside
-// each row of 16 lanes (row_shr 1,2,4,8), row totals forwarded (row_bcast 15 / 31), lane 63 read back through
-// an SGPR -- ~20 VALU instructions instead of six dependent ds_bpermute round trips.
-__device__ __forceinline__ double wave_sum(double v) {
-#if BASQ_WAVE_SUM_DPP
-    v += dpp_shift_f64<0x111, 0xf>(v);
-    v += dpp_shift_f64<0x112, 0xf>(v);
-    v += dpp_shift_f64<0x114, 0xf>(v);
-    v += dpp_shift_f64<0x118, 0xf>(v);
-    v += dpp_shift_f64<0x142, 0xa>(v);
-    v += dpp_shift_f64<0x143, 0xc>(v);
-    const long long b = __double_as_longlong(v);
-    const int lo = __builtin_amdgcn_readlane((int)b, 63);
-    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
-    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-#else
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-#endif
-}
-
 // dlarfg: reflector for (alpha, x) from alpha and |x|^2; returns tau, scale = 1/(alpha - beta) (0, 0 if x == 0)
 __device__ __forceinline__ void householder_params(double alpha, double ss, double& tau, double& scale) {
     if (ss == 0.0) { tau = 0.0; scale = 0.0; return; }
@@ -2178,27 +1829,32 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const dou
         __syncthreads();
         BASQ_NS_STAMP(t + 1, 2);
         // ---- chain (every wave) ----
-        double accs[NV], ss2 = 0.0;
+        double accs[NV], ss2 = 0.0, r1[NV], rn[NV], alphaH = 0.0;
 #pragma unroll
         for (int k = 0; k < NV; ++k) accs[k] = 0.0;
-        if (t >= 0) {
+        if (!GLOBAL || wv == 0) {
+            if (t >= 0) {
 #pragma unroll
-            for (int w = 0; w < WPG; ++w) {                         // local partials, wave order
-                const double* src = wpart_l + (size_t)(par * WPG + w) * MSG;
+                for (int w = 0; w < WPG; ++w) {                     // local partials, wave order
+                    const double* src = wpart_l + (size_t)(par * WPG + w) * MSG;
 #pragma unroll
-                for (int h = 0; h < NV / 2; ++h) {
-                    const d2_t v = *reinterpret_cast<const d2_t*>(src + 2 * lane + 128 * h);
-                    accs[2 * h] += v.x;
-                    accs[2 * h + 1] += v.y;
+                    for (int h = 0; h < NV / 2; ++h) {
+                        const d2_t v = *reinterpret_cast<const d2_t*>(src + 2 * lane + 128 * h);
+                        accs[2 * h] += v.x;
+                        accs[2 * h + 1] += v.y;
+                    }
+                    ss2 += src[NC];
                 }
-                ss2 += src[NC];
             }
         }
         if (GLOBAL) {
-            // publish this work-group's sum (wave 0), then gather every work-group's sum in cluster order
+            // ONE wave per work-group talks to the other CUs: it publishes this work-group's sum (write-through), waits
+            // for every work-group's flag, gathers the sums in cluster order and the published row t+1, and hands the
+            // result to its seven sibling waves through LDS -- 20 KB of fabric traffic per CU and step instead of 160 KB.
             const unsigned epoch = (unsigned)(t + 2);
             double* mine = gsum + (size_t)(par * NCU + cu) * MSG;
-            if (wv == 0) {                                          // ONE wave publishes and polls; the others wait at the barrier
+            double* tot_l = wpart_l + (size_t)(par * WPG) * MSG;    // this parity's first partial slot: free after the sum above
+            if (wv == 0) {
 #pragma unroll
                 for (int k = 0; k < NV; ++k) agent_store_f64(mine + BASQ_PAIRCOL(k), accs[k]);
                 if (lane == 0) agent_store_f64(mine + NC, ss2);
@@ -2216,31 +1872,53 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const dou
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: the gathers stay below the poll
+                double tot[NV], sst = 0.0;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) tot[k] = 0.0;
+                if (!bad) {
+#pragma unroll
+                    for (int c2 = 0; c2 < NCU; ++c2) {              // cluster order: every work-group forms the same sum
+                        const double* src = gsum + (size_t)(par * NCU + c2) * MSG;
+#pragma unroll
+                        for (int k = 0; k < NV; ++k) tot[k] += agent_load_f64(src + BASQ_PAIRCOL(k));
+                        sst += agent_load_f64(src + NC);
+                    }
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {
+                        tot_l[BASQ_PAIRCOL(k)] = tot[k];
+                        r1_l[(size_t)par * MSG + BASQ_PAIRCOL(k)] = agent_load_f64(r1buf + BASQ_PAIRCOL(k));
+                    }
+                    if (lane == 0) {
+                        tot_l[NC] = sst;
+                        r1_l[(size_t)par * MSG + NC] = agent_load_f64(r1buf + NC);
+                    }
+                }
                 if (lane == 0) abort_l = bad ? 1 : 0;
             }
-            __syncthreads();                                        // verdict of wave 0: uniform over the work-group
+            __syncthreads();                                        // wave 0's verdict and gathered data: work-group uniform
             aborted = abort_l != 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: the gathers stay below the poll
-            if (aborted) break;                                     // work-group uniform: no wave is left at a barrier
-            double tot[NV], sst = 0.0;
+            if (aborted) break;                                     // no wave is left behind at a barrier
 #pragma unroll
-            for (int k = 0; k < NV; ++k) tot[k] = 0.0;
-#pragma unroll
-            for (int c2 = 0; c2 < NCU; ++c2) {
-                const double* src = gsum + (size_t)(par * NCU + c2) * MSG;
-#pragma unroll
-                for (int k = 0; k < NV; ++k) tot[k] += agent_load_f64(src + BASQ_PAIRCOL(k));
-                sst += agent_load_f64(src + NC);
+            for (int h = 0; h < NV / 2; ++h) {
+                const d2_t v = *reinterpret_cast<const d2_t*>(tot_l + 2 * lane + 128 * h);
+                accs[2 * h] = v.x;
+                accs[2 * h + 1] = v.y;
             }
-#pragma unroll
-            for (int k = 0; k < NV; ++k) accs[k] = tot[k];
-            ss2 = sst;
+            ss2 = tot_l[NC];
         }
-        double r1[NV], rn[NV];
+        {
+            const double* r1src = r1_l + (size_t)par * MSG;          // clusters: wave 0's copy of the published row
 #pragma unroll
-        for (int k = 0; k < NV; ++k) r1[k] = GLOBAL ? agent_load_f64(r1buf + BASQ_PAIRCOL(k)) : r1buf[BASQ_PAIRCOL(k)];
+            for (int h = 0; h < NV / 2; ++h) {
+                const d2_t v = *reinterpret_cast<const d2_t*>(r1src + 2 * lane + 128 * h);
+                r1[2 * h] = v.x;
+                r1[2 * h + 1] = v.y;
+            }
+            alphaH = r1src[NC];
+        }
+        BASQ_NS_STAMP(t + 1, 4);
         if (t >= 0) {
-            const double alphaH = GLOBAL ? agent_load_f64(r1buf + NC) : r1buf[NC];
             double tauq, uscale;
             householder_params_fast(alphaH, ss2, tauq, uscale);
 #pragma unroll
@@ -2261,8 +1939,10 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const dou
 #pragma unroll
             for (int k = 0; k < NV; ++k)
                 if (BASQ_PAIRCOL(k) > t1) ss += rn[k] * rn[k];
+            BASQ_NS_STAMP(t + 1, 5);
             ss = wave_sum(ss);
             const double alpha = readlane_f64(pick_slot<NV>(rn, tk), tl);
+            BASQ_NS_STAMP(t + 1, 6);
             double scale;
             householder_params_fast(alpha, ss, tau, scale);
 #pragma unroll
@@ -2746,6 +2426,195 @@ __global__ void __launch_bounds__(1024) chol_packed_lds_kernel(double* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// CholeskyQR building blocks of the range finder, second generation: a PANEL Cholesky and a row-parallel triangular
+// solve, so that no inverse is formed and the factorisation costs q/8 synchronised steps instead of q.
+//
+// chol_factor_panel_kernel: one work-group, the lower triangle packed in LDS (q <= 200).  Per panel of 8 columns:
+//   F1  every thread factors the 8 x 8 diagonal block redundantly in registers (broadcast LDS reads; nothing to hand
+//       over, the pivot test is uniform by construction);
+//   F2  one thread per row below the block: its 8 panel entries by forward substitution against the block;
+//   F3  the trailing triangle in 4 x 4 tiles: A[i][k] -= sum_c L[i][c] L[k][c].
+// Two barriers per panel.
+// trsm_rows_kernel: Q = X L^-T for a tall X [rows, q]: 64 rows per work-group, their q entries in LDS; per panel the
+//   512 threads (row, panel column) subtract the contribution of the finished columns (dot products over LDS rows and
+//   L rows that are uniform per wave), then one thread per row solves its 8 x 8 block.  Replaces W = L^-T + a GEMM.
+// ------------------------------------------------------------------------------------------------
+#define BASQ_CHOL_NB 8
+__global__ void __launch_bounds__(1024) chol_factor_panel_kernel(double* __restrict__ G, int q, int* __restrict__ info,
+                                                                 double rel_tol) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* Lp = sm;                                     // [q (q + 1) / 2] packed rows
+    __shared__ double red[16];
+    __shared__ double s_dmax;
+    constexpr int NB = BASQ_CHOL_NB;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#define BASQ_TRI(i, j) Lp[(size_t)(i) * ((i) + 1) / 2 + (j)]
+    for (int i = tid >> 7; i < q; i += 8)
+        for (int k = tid & 127; k <= i; k += 128) BASQ_TRI(i, k) = G[(size_t)i * q + k];
+    __syncthreads();
+    double dm = (tid < q) ? BASQ_TRI(tid, tid) : 0.0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) dm = fmax(dm, __shfl_xor(dm, o, 64));
+    if (lane == 0) red[wv] = dm;
+    __syncthreads();
+    if (tid == 0) {
+        double v = red[0];
+        for (int w = 1; w < 16; ++w) v = fmax(v, red[w]);
+        s_dmax = v;
+    }
+    __syncthreads();
+    const double floor_ = rel_tol * s_dmax;
+    int bad = 0;
+    for (int j0 = 0; j0 < q; j0 += NB) {
+        const int nb = (q - j0 < NB) ? (q - j0) : NB;
+        // ---- F1: diagonal block, redundantly in every thread ----
+        double D[NB][NB], rd[NB];
+#pragma unroll
+        for (int r = 0; r < NB; ++r)
+#pragma unroll
+            for (int c = 0; c <= r; ++c) D[r][c] = (r < nb) ? BASQ_TRI(j0 + r, j0 + c) : ((r == c) ? 1.0 : 0.0);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+            const double d = D[c][c];
+            if (c < nb && !(d > floor_) && bad == 0) bad = j0 + c + 1;       // uniform: every thread holds the same block
+            const double r = rsqrt_nr(bad ? 1.0 : d);
+            rd[c] = r;
+            D[c][c] = d * r;
+#pragma unroll
+            for (int i = c + 1; i < NB; ++i) D[i][c] *= r;
+#pragma unroll
+            for (int i = c + 1; i < NB; ++i)
+#pragma unroll
+                for (int k = c + 1; k <= i; ++k) D[i][k] -= D[i][c] * D[k][c];
+        }
+        if (bad) break;                                                     // uniform
+        // ---- F2: rows below the block ----
+        const int R = q - j0 - nb;
+        if (tid < R) {
+            const int i = j0 + nb + tid;
+            double y[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) y[c] = (c < nb) ? BASQ_TRI(i, j0 + c) : 0.0;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                double v = y[c];
+#pragma unroll
+                for (int k = 0; k < c; ++k) v -= y[k] * D[c][k];
+                y[c] = v * rd[c];
+            }
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+                if (c < nb) BASQ_TRI(i, j0 + c) = y[c];
+        } else if (tid == R) {                                              // R <= 192 < 1024: this thread always exists
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+#pragma unroll
+                for (int c = 0; c <= r; ++c)
+                    if (r < nb) BASQ_TRI(j0 + r, j0 + c) = D[r][c];
+        }
+        __syncthreads();
+        // ---- F3: trailing triangle, 4 x 4 tiles ----
+        const int nt = (R + 3) >> 2, ntiles = nt * (nt + 1) / 2;
+        for (int tile = tid; tile < ntiles; tile += 1024) {
+            int ti = (int)((__builtin_sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+            while (ti * (ti + 1) / 2 > tile) --ti;
+            while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+            const int tk = tile - ti * (ti + 1) / 2;
+            const int i0 = j0 + nb + 4 * ti, k0 = j0 + nb + 4 * tk;
+            double acc[4][4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y2 = 0; y2 < 4; ++y2) acc[x][y2] = 0.0;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                double li[4], lk[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const int ii = (i0 + x < q) ? (i0 + x) : (q - 1), kk2 = (k0 + x < q) ? (k0 + x) : (q - 1);
+                    li[x] = (c < nb) ? BASQ_TRI(ii, j0 + c) : 0.0;
+                    lk[x] = (c < nb) ? BASQ_TRI(kk2, j0 + c) : 0.0;
+                }
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y2 = 0; y2 < 4; ++y2) acc[x][y2] = __builtin_fma(li[x], lk[y2], acc[x][y2]);
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y2 = 0; y2 < 4; ++y2)
+                    if (i0 + x < q && k0 + y2 <= i0 + x) BASQ_TRI(i0 + x, k0 + y2) -= acc[x][y2];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) info[0] = bad;
+    for (int i = tid >> 7; i < q; i += 8)
+        for (int k = tid & 127; k <= i; k += 128) G[(size_t)i * q + k] = BASQ_TRI(i, k);
+#undef BASQ_TRI
+}
+
+__global__ void __launch_bounds__(512) trsm_rows_kernel(const double* __restrict__ X, long long ldx, long long rows, int q,
+                                                        const double* __restrict__ L, double* __restrict__ Qo,
+                                                        long long ldq) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    constexpr int NB = BASQ_CHOL_NB;
+    const int ld = q | 1;                                 // odd leading dimension: lanes (= rows) hit distinct banks
+    double* Y = sm;                                       // [64][ld]
+    const int tid = threadIdx.x;
+    const long long r0 = (long long)blockIdx.x * 64;
+    const int nr = (rows - r0 < 64) ? (int)(rows - r0) : 64;
+    for (int e = tid; e < 64 * q; e += 512) {
+        const int r = e / q, c = e - r * q;
+        Y[r * ld + c] = (r < nr) ? X[(r0 + r) * ldx + c] : 0.0;
+    }
+    __syncthreads();
+    const int r = tid & 63, c = tid >> 6;                 // wave = panel column c (uniform), lane = row
+    for (int j0 = 0; j0 < q; j0 += NB) {
+        const int nb = (q - j0 < NB) ? (q - j0) : NB;
+        if (c < nb) {
+            // s = y[r][j0 + c] - sum_{k < j0} y[r][k] L[j0 + c][k]   (L row uniform per wave; four chains)
+            const double* lrow = L + (size_t)(j0 + c) * q;
+            const double* yrow = Y + r * ld;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int k = 0;
+            for (; k + 3 < j0; k += 4) {
+                s0 = __builtin_fma(yrow[k], lrow[k], s0);
+                s1 = __builtin_fma(yrow[k + 1], lrow[k + 1], s1);
+                s2 = __builtin_fma(yrow[k + 2], lrow[k + 2], s2);
+                s3 = __builtin_fma(yrow[k + 3], lrow[k + 3], s3);
+            }
+            for (; k < j0; ++k) s0 = __builtin_fma(yrow[k], lrow[k], s0);
+            Y[r * ld + j0 + c] -= (s0 + s1) + (s2 + s3);
+        }
+        __syncthreads();
+        if (tid < 64) {                                   // one thread per row: the 8 x 8 block by forward substitution
+            double y[NB];
+#pragma unroll
+            for (int cc = 0; cc < NB; ++cc) y[cc] = (cc < nb) ? Y[tid * ld + j0 + cc] : 0.0;
+#pragma unroll
+            for (int cc = 0; cc < NB; ++cc) {
+                if (cc < nb) {
+                    const double* lrow = L + (size_t)(j0 + cc) * q + j0;
+                    double v = y[cc];
+#pragma unroll
+                    for (int k = 0; k < cc; ++k) v -= y[k] * lrow[k];
+                    y[cc] = v / lrow[cc];
+                }
+            }
+#pragma unroll
+            for (int cc = 0; cc < NB; ++cc)
+                if (cc < nb) Y[tid * ld + j0 + cc] = y[cc];
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < 64 * q; e += 512) {
+        const int rr = e / q, cc = e - rr * q;
+        if (rr < nr) Qo[(r0 + rr) * ldq + cc] = Y[rr * ld + cc];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Block sums of a dense per-pair matrix handed over by the caller:
 //     E[j][s] += scale * sum_{p in chunk, set(p) = s} mu_p * C[j][p]        (SQ = false)
 //     E[j][s] += scale * sum_{p in chunk, set(p) = s} mu_p * C[j][p]^2      (SQ = true)
@@ -2909,7 +2778,7 @@ int basq_gram_f64(const basq_kernel_spec* spec, const double* packA, int64_t na,
 
 static int blocksum_impl(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
                          const double* mu, const double* wx, int64_t Rl, int64_t off, int64_t n_full, int32_t S,
-                         int32_t n_chunks, double* Xpart, double* totpart, void* stream, bool use_mfma) {
+                         int32_t n_chunks, double* Xpart, double* totpart, void* stream) {
     if (!spec_ok(spec) || !nys || !cand || !mu || !Xpart) return BASQ_EINVAL;
     if (m < 1 || Rl < 1 || off < 0 || n_full < 0 || S < 1 || n_chunks < 1) return BASQ_EINVAL;
     if (n_full % S != 0) return BASQ_EINVAL;
@@ -2929,26 +2798,14 @@ static int blocksum_impl(const basq_kernel_spec* spec, const double* nys, int32_
     const long long nblk = A.blk_hi - A.blk_lo;
     A.blk_per_chunk = (nblk + n_chunks - 1) / n_chunks;
     if (A.blk_per_chunk < 1) A.blk_per_chunk = 1;
-    // The scalar-broadcast VALU form exists while two candidate rows fit the SGPR budget without spills
-    // (KP <= 12, i.e. d <= 10: audited by tools/audit_isa.py); the MFMA form (operands in VGPRs) serves every d.
-    const int kk = basq_kp(spec->d) / 4;
-    if (use_mfma) return dispatch_blocksum(kk, spec->family, A, (hipStream_t)stream);
-    if (kk > BASQ_VALU_MAX_KK) return BASQ_EUNSUPPORTED;
-    return dispatch_blocksum_valu(kk, spec->family, A, (hipStream_t)stream);
+    return dispatch_blocksum(basq_kp(spec->d) / 4, spec->family, A, (hipStream_t)stream);
 }
 
 int basq_blocksum_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
                       const double* mu, const double* wx, int64_t Rl, int64_t off, int64_t n_full, int32_t S,
                       int32_t n_chunks, double* Xpart, double* totpart, void* stream) {
     if (!totpart) return BASQ_EINVAL;
-    return blocksum_impl(spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, Xpart, totpart, stream, true);
-}
-
-int basq_blocksum_valu_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
-                           const double* mu, const double* wx, int64_t Rl, int64_t off, int64_t n_full, int32_t S,
-                           int32_t n_chunks, double* Xpart, double* totpart, void* stream) {
-    if (!totpart) return BASQ_EINVAL;
-    return blocksum_impl(spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, Xpart, totpart, stream, false);
+    return blocksum_impl(spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, Xpart, totpart, stream);
 }
 
 int basq_kernel_matvec_f64(const basq_kernel_spec* spec, const double* packA, int64_t na, const double* packB,
@@ -2956,7 +2813,7 @@ int basq_kernel_matvec_f64(const basq_kernel_spec* spec, const double* packA, in
     // blocksum with a single set and everything in the "tail": out[i] = sum_j k(A_i, B_j) v_j.
     if (!spec_ok(spec) || !packA || !packB || !v || !out || na < 1 || nb < 1 || na > 0x7fffffffLL)
         return BASQ_EINVAL;
-    int rc = blocksum_impl(spec, packA, (int32_t)na, packB, v, nullptr, nb, 0, 0, 1, 1, out, nullptr, stream, true);
+    int rc = blocksum_impl(spec, packA, (int32_t)na, packB, v, nullptr, nb, 0, 0, 1, 1, out, nullptr, stream);
     if (rc != BASQ_OK) return rc;
     hipLaunchKernelGGL(axpb_strided_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out,
                        (long long)na, 1LL, spec->outputscale, bias, out);
@@ -3015,8 +2872,8 @@ int basq_finalize_f64(const double* parts, int32_t n_parts, int32_t msg_rows, in
 static inline size_t cluster_ws_doubles(int nv, int ncu) { return 16 + (size_t)(2 * BASQ_WPG * ncu) * (nv * 64 + 8); }
 
 #ifndef BASQ_CAR_CLUSTER
-#define BASQ_CAR_CLUSTER 1      // 0: the one-work-group LDS / global-memory kernels of round 1 (kept for A/B timing)
-#endif
+#define BASQ_CAR_CLUSTER 1      // 1: cluster kernels where the null vectors do not fit one CU's LDS; 2: also where they do
+#endif                          // (A/B: 172 vs 175 us at M = 200, slower below); 0: never
 
 int64_t basq_reduction_ws_doubles(int32_t s, int32_t M) {
     if (s < 1 || M <= s || M > 1024) return 0;
@@ -3034,7 +2891,8 @@ int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32
     const int nrows = M - s;
 #if BASQ_CAR_CLUSTER
     constexpr int T = BASQ_WPG * 64;
-    if (nrows >= 1 && M <= 256 && nrows <= BASQ_WPG * 14) {        // one CU, rows in registers (n <= 112: M = 2n <= 224)
+    const bool fits_lds = (size_t)nrows * M * sizeof(double) <= 162560;
+    if (nrows >= 1 && M <= 256 && nrows <= BASQ_WPG * 14 && (BASQ_CAR_CLUSTER == 2 || !fits_lds)) {   // one CU, rows in registers
         if (nrows <= BASQ_WPG * 4)
             hipLaunchKernelGGL((car_eliminate_cluster_kernel<4, 4, 1>), dim3(1), dim3(T), 0, st, PhiT, mu, M, s,
                                keep_rank, kept, w_star, info, (double*)nullptr, 1);
@@ -3044,7 +2902,7 @@ int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32
         BASQ_CHECK_LAUNCH();
         return BASQ_OK;
     }
-    if (nrows >= 1 && M <= 512 && nrows <= 4 * BASQ_WPG * 8 && ws) {   // 4-CU cluster (n = 200: M = 400, 200 null vectors)
+    if (nrows >= 1 && !fits_lds && M <= 512 && nrows <= 4 * BASQ_WPG * 8 && ws) {   // 4-CU cluster (n = 200: M = 400)
         if (hipMemsetAsync(ws, 0, 16 * sizeof(double), st) != hipSuccess) return BASQ_ELAUNCH;
         hipLaunchKernelGGL((car_eliminate_cluster_kernel<8, 8, 4>), dim3(4 * 8), dim3(T), 0, st, PhiT, mu, M, s,
                            keep_rank, kept, w_star, info, ws, 8);
@@ -3071,8 +2929,8 @@ int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32
 }
 
 #ifndef BASQ_NS_CLUSTER
-#define BASQ_NS_CLUSTER 1       // 0: the one-work-group kernels of round 1 (kept for A/B timing)
-#endif
+#define BASQ_NS_CLUSTER 1       // 1: cluster kernels where one CU cannot hold the matrix (M > 256); 2: also for the one-CU
+#endif                          // shapes (A/B: measured 336 vs 286 us at 100 x 200 -- the 16-wave kernel stays); 0: never
 #ifndef BASQ_NS_APPLY16
 #define BASQ_NS_APPLY16 1
 #endif
@@ -3084,11 +2942,11 @@ int basq_nullspace_f64(const double* X, int32_t s, int32_t M, double* V, double*
     const size_t LDS_MAX = 163840 - 64;                         // per-CU LDS minus the kernel's static scalar
     int rc;
     constexpr int T = BASQ_WPG * 64;
-    if (BASQ_NS_CLUSTER && M <= 256 && s <= BASQ_WPG * 14) {    // one CU, the whole matrix in registers
+    if (BASQ_NS_CLUSTER == 2 && M <= 256 && s <= BASQ_WPG * 14) {   // one CU, 8 waves (A/B builds)
         if (s <= BASQ_WPG * 4) hipLaunchKernelGGL((bidiag_cluster_kernel<4, 4, 1>), dim3(1), dim3(T), 0, st, X, s, M, V, tau, (double*)nullptr, 1);
         else hipLaunchKernelGGL((bidiag_cluster_kernel<4, 14, 1>), dim3(1), dim3(T), 0, st, X, s, M, V, tau, (double*)nullptr, 1);
         rc = (hipGetLastError() == hipSuccess) ? BASQ_OK : BASQ_ELAUNCH;
-    } else if (BASQ_NS_CLUSTER && M <= 512 && s <= 4 * BASQ_WPG * 8 && ws) {   // 4-CU cluster
+    } else if (BASQ_NS_CLUSTER && !(M <= 256 && s <= 112) && M <= 512 && s <= 4 * BASQ_WPG * 8 && ws) {   // 4-CU cluster
         if (hipMemsetAsync(ws, 0, 16 * sizeof(double), st) != hipSuccess) return BASQ_ELAUNCH;
         hipLaunchKernelGGL((bidiag_cluster_kernel<8, 8, 4>), dim3(4 * 8), dim3(T), 0, st, X, s, M, V, tau, ws, 8);
         rc = (hipGetLastError() == hipSuccess) ? BASQ_OK : BASQ_ELAUNCH;
@@ -3211,6 +3069,32 @@ int basq_chol_inv_f64(double* G, int32_t q, double* W, int32_t* info, double rel
         return BASQ_OK;
     }
     hipLaunchKernelGGL(chol_inv_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, G, q, W, info, rel_tol);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_chol_factor_f64(double* G, int32_t q, int32_t* info, double rel_tol, void* stream) {
+    if (!G || !info || q < 1 || !(rel_tol >= 0.0)) return BASQ_EINVAL;
+    const size_t ldsp = (size_t)q * (q + 1) / 2 * sizeof(double);
+    if (ldsp > 163840 - 512) return BASQ_EUNSUPPORTED;           // q <= 200
+    if (hipFuncSetAttribute((const void*)chol_factor_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp) !=
+        hipSuccess)
+        return BASQ_ELAUNCH;
+    hipLaunchKernelGGL(chol_factor_panel_kernel, dim3(1), dim3(1024), ldsp, (hipStream_t)stream, G, q, info, rel_tol);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_trsm_rows_f64(const double* X, int64_t ldx, int64_t rows, int32_t q, const double* L, double* Q, int64_t ldq,
+                       void* stream) {
+    if (!X || !L || !Q || rows < 0 || q < 1 || ldx < q || ldq < q) return BASQ_EINVAL;
+    if (rows == 0) return BASQ_OK;
+    const size_t lds = (size_t)64 * (q | 1) * sizeof(double);
+    if (lds > 163840 - 256) return BASQ_EUNSUPPORTED;            // q <= 318
+    if (hipFuncSetAttribute((const void*)trsm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return BASQ_ELAUNCH;
+    hipLaunchKernelGGL(trsm_rows_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(512), lds, (hipStream_t)stream, X,
+                       (long long)ldx, (long long)rows, q, L, Q, (long long)ldq);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }

@@ -31,10 +31,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP64_VECTOR_TFLOPS = 78.6      # MI355X nominal: 256 CU x 128 flop/clk x 2.4 GHz (fp64 vector == fp64 matrix peak)
-# What the part sustains in a register-only micro-benchmark (tools/microbench.hip, profiles/r01_microbench_fp64_rates.txt,
-# 4 waves/SIMD): v_fma_f64 only 69.6 TF/s, v_mfma_f64_16x16x4 only 48.3 TF/s, the two interleaved 61.4 TF/s.  The
-# block-sum kernel is such a mix, so 61.4 is its practical ceiling; ``frac`` stays against the nominal figure.
-MEASURED_FP64_TFLOPS = {"fma_only": 69.6, "mfma_only": 48.3, "mixed_fma_mfma": 61.4}
+# What the part sustains in a register-only micro-benchmark (tools/microbench.hip, profiles/r02_microbench_fp64_rates.txt,
+# 4 waves/SIMD, in-kernel clock 2.32-2.39 GHz): v_fma_f64 only 72.9 TF/s (4.2 cycles per wave instruction),
+# v_mfma_f64_16x16x4 only 47.2 TF/s (one issue per 106 cycles), the two interleaved 63.1 TF/s (they do not overlap).
+# The block-sum kernel's default form is all-VALU, so 72.9 is its practical ceiling; ``frac`` stays against the nominal figure.
+MEASURED_FP64_TFLOPS = {"fma_only": 72.9, "mfma_only": 47.2, "mixed_fma_mfma": 63.1}
 PEAK_HBM_GBS = 8000.0
 POOL_SEEDS = (0, 1, 2, 3, 4)        # seeds 0-4, median
 
@@ -219,13 +220,14 @@ def main():
                 # contract vocabulary is hbm|mfma: this kernel is bound by the fp64 PIPE, which f64 MFMA and fp64 VALU share
                 # on gfx950 (roughly half of its busy cycles are MFMA, half the VALU exp epilogue) -- neither HBM nor a
                 # GEMM-shaped MFMA bound; "bound_detail" says so.
-                "bound": "mfma", "bound_detail": "fp64 pipe (f64 MFMA + fp64 VALU share one datapath); not HBM",
-                "kernel": "blocksum_kernel (fused pairwise-kernel block sums, BASQ/_rchq.py:79-99)",
+                "bound": "mfma", "bound_detail": "fp64 pipe (the default form issues fp64 VALU FMAs only: f64 MFMA and fp64 "
+                                                   "VALU share one datapath and the MFMA issues once per ~106 cycles); not HBM",
+                "kernel": "blocksum_lds_kernel (fused pairwise-kernel block sums, BASQ/_rchq.py:79-99; LDS-broadcast VALU form)",
                 "achieved": achieved_tf, "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tf / PEAK_FP64_VECTOR_TFLOPS,
-                "peak_measured": MEASURED_FP64_TFLOPS["mixed_fma_mfma"],
-                "frac_of_measured_peak": achieved_tf / MEASURED_FP64_TFLOPS["mixed_fma_mfma"],
-                "peak_measured_source": "profiles/r01_microbench_fp64_rates.txt (fma-only 69.6, mfma-only 48.3, mixed 61.4 TF/s)",
+                "peak_measured": MEASURED_FP64_TFLOPS["fma_only"],
+                "frac_of_measured_peak": achieved_tf / MEASURED_FP64_TFLOPS["fma_only"],
+                "peak_measured_source": "profiles/r02_microbench_fp64_rates.txt (fma-only 72.9, mfma-only 47.2, mixed 63.1 TF/s)",
                 "traffic": traffic,
                 "traffic_source": ("committed PMC pass, not measured in this run: " + traffic_src) if traffic_src else None,
                 "fp64_pipe_busy_pmc": pipe_busy,
@@ -234,8 +236,8 @@ def main():
                 "flops_per_pair": 3 * d + 3,
                 "hbm_algorithmic_GBs": bytes_alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
                 "hbm_peak_GBs": PEAK_HBM_GBS,
-                "note": "compute-bound on the fp64 pipe (f64 MFMA and fp64 VALU share it on gfx950; SURVEY 8d): 33 flop "
-                        "per pair by SURVEY's count cost ~108 pipe-cycles per 64 pairs, half of them the exp; measured "
+                "note": "compute-bound on the fp64 VALU (SURVEY 8d): 33 flop per pair by SURVEY's count = d + 1 FMAs for the "
+                        "exponent argument, 8 for the table exp, 1 weighted accumulate per 64-lane instruction; measured "
                         "per rank 0; traffic / pipe occupancy: committed PMC passes, see profiles/",
             },
             "cpu_baseline": cpu,

@@ -104,15 +104,6 @@ int basq_blocksum_f64(const basq_kernel_spec* spec, const double* nys, int32_t m
                       int32_t n_chunks, double* Xpart, double* totpart, void* stream);
 
 /*
- * Same contract as basq_blocksum_f64 in the scalar-broadcast VALU form (candidate rows through the scalar
- * cache, d FMAs per pair instead of MFMAs), d <= 10 only (BASQ_EUNSUPPORTED beyond).  Kept for A/B
- * measurement: on gfx950 it is within 7 % of the default form, which the product path uses.
- */
-int basq_blocksum_valu_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
-                           const double* mu, const double* wx, int64_t Rl, int64_t off, int64_t n_full, int32_t S,
-                           int32_t n_chunks, double* Xpart, double* totpart, void* stream);
-
-/*
  * Nystrom-feature contraction BASQ/_rchq.py:88-90:  out[0][s] = sum_c totpart[c][s];
  *     out[1+r][s] = outputscale * sum_j U[r][j] * (sum_c Xpart[c][j][s])        r < q
  * on the f64 matrix cores (v_mfma_f64_16x16x4_f64): the chunk partials are first added in chunk order
@@ -235,6 +226,18 @@ int basq_box_muller_f64(const double* u, int64_t n, const double* u_tail, double
  * square no longer fits in LDS; returns BASQ_EUNSUPPORTED for q > 200 (pass W then: global-memory kernel).
  */
 int basq_chol_inv_f64(double* G, int32_t q, double* W, int32_t* info, double rel_tol, void* stream);
+
+/*
+ * CholeskyQR without an inverse (same place in the range finder as basq_chol_inv_f64, BASQ/_rchq.py:29):
+ *   basq_chol_factor_f64: G [q,q] (SPD) -> its Cholesky factor L in the lower triangle (strict upper triangle left as it
+ *       was), by a panel algorithm with the packed triangle in LDS: q/8 synchronised steps instead of q.  info[0] as for
+ *       basq_chol_inv_f64.  q <= 200 (BASQ_EUNSUPPORTED beyond).
+ *   basq_trsm_rows_f64:   Q [rows, q] = X [rows, q] L^-T  (row strides ldx / ldq; X == Q allowed), L as left by
+ *       basq_chol_factor_f64: the orthonormal factor of CholeskyQR straight from X, 64 rows per work-group.  q <= 318.
+ */
+int basq_chol_factor_f64(double* G, int32_t q, int32_t* info, double rel_tol, void* stream);
+int basq_trsm_rows_f64(const double* X, int64_t ldx, int64_t rows, int32_t q, const double* L, double* Q, int64_t ldq,
+                       void* stream);
 
 /* Dense f64 GEMM on the matrix cores: C[M,N] = alpha * A[M,K] @ B[K,N] (row-major, lda/ldb/ldc). */
 int basq_gemm_f64(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, int32_t M,

@@ -27,7 +27,7 @@ from .rchq_oracle import caratheodory_reduce, nystrom_basis
 
 
 def sampled_batch_seconds(pts_rec, pts_nys, num_pts, kernel, stride: int = 8, dtype=torch.float64,
-                          threads: int | None = None):
+                          threads: int | None = None, loop_budget_s: float | None = None):
     """-> dict(seconds_per_batch, measured_seconds, loop_fraction, n_rounds, kernel_calls_total, kernel_calls_run,
     threads, dtype).  ``threads``: ``torch.set_num_threads`` for the duration of the call (None = leave as is)."""
     prev = torch.get_default_dtype()
@@ -39,8 +39,8 @@ def sampled_batch_seconds(pts_rec, pts_nys, num_pts, kernel, stride: int = 8, dt
         # warm-up at this dtype / team size (first-use costs of MKL's thread team and LAPACK workspaces: ~1 s otherwise
         # lands in the Gram + svd_lowrank timer of the first cell)
         nw = min(len(pts_rec), 4000)
-        _run(pts_rec[:nw].to(dtype), pts_nys[:max(1, min(len(pts_nys), nw // 20))].to(dtype), num_pts, kernel, 1)
-        res = _run(pts_rec.to(dtype), pts_nys.to(dtype), num_pts, kernel, max(1, int(stride)))
+        _run(pts_rec[:nw].to(dtype), pts_nys[:max(1, min(len(pts_nys), nw // 20))].to(dtype), num_pts, kernel, 1, None)
+        res = _run(pts_rec.to(dtype), pts_nys.to(dtype), num_pts, kernel, max(1, int(stride)), loop_budget_s)
         res["threads"] = torch.get_num_threads()
         res["dtype"] = str(dtype).replace("torch.", "")
         return res
@@ -51,7 +51,7 @@ def sampled_batch_seconds(pts_rec, pts_nys, num_pts, kernel, stride: int = 8, dt
 
 
 def baseline_matrix(pts_rec, pts_nys, num_pts, kernel, stride: int, seed: int = 1, thread_counts=None,
-                    dtypes=(torch.float64, torch.float32)):
+                    dtypes=(torch.float64, torch.float32), loop_budget_s: float | None = 4.0):
     """every (dtype, thread count) cell, same seed before each.  -> list of result dicts."""
     import os
 
@@ -62,11 +62,11 @@ def baseline_matrix(pts_rec, pts_nys, num_pts, kernel, stride: int, seed: int = 
     for dt in dtypes:
         for th in thread_counts:
             torch.manual_seed(seed)
-            out.append(sampled_batch_seconds(pts_rec, pts_nys, num_pts, kernel, stride, dt, th))
+            out.append(sampled_batch_seconds(pts_rec, pts_nys, num_pts, kernel, stride, dt, th, loop_budget_s))
     return out
 
 
-def _run(samp, pt, num_pts, kernel, stride):
+def _run(samp, pt, num_pts, kernel, stride, loop_budget_s):
     t_wall = time.perf_counter()
     t0 = time.perf_counter()
     _, U = nystrom_basis(pt, num_pts - 1, kernel)
@@ -80,9 +80,12 @@ def _run(samp, pt, num_pts, kernel, stride):
     R = N
     t_loop_est = t_loop_run = 0.0
     calls_total = calls_run = rounds = 0
+    nb_first = max(1, int(N / S))
     while R > S:
         rounds += 1
         nb = int(R / S)
+        # this round's share of the loop budget (the block counts halve every round: sum ~ 2 x the first round's)
+        round_budget = None if loop_budget_s is None else loop_budget_s * nb / (2.0 * nb_first)
         grid = live[: nb * S].reshape(nb, -1)
         acc = torch.zeros((m, S))
         t0 = time.perf_counter()
@@ -91,6 +94,8 @@ def _run(samp, pt, num_pts, kernel, stride):
             blk = live[i * S:(i + 1) * S]
             acc += torch.multiply(kernel(pt, samp[blk]), mu[blk].unsqueeze(0))
             ran += 1
+            if round_budget is not None and time.perf_counter() - t0 > round_budget:   # >= 1 block per round always runs
+                break
         dt = time.perf_counter() - t0
         t_loop_run += dt
         t_loop_est += dt * nb / ran
@@ -172,7 +177,7 @@ def main():
     m = int(a.N * 1e-2)
     torch.manual_seed(1)
     res = sampled_batch_seconds(pool, pool[:m], a.n, StationaryOracle("rbf", 2.0, 1.0), 1 if a.full else a.stride,
-                                getattr(torch, a.dtype), a.threads)
+                                getattr(torch, a.dtype), a.threads, None if a.full else 8.0)
     res.update(N=a.N, d=a.d, n=a.n, m=m, host_cores=os.cpu_count(), stride=1 if a.full else a.stride)
     print(json.dumps(res))
 

@@ -286,6 +286,24 @@ class CpuStandInOps:
         G.copy_(torch.tril(L) + torch.triu(G, 1))
         return W, info
 
+    CHOL_FACTOR_MAX_Q = 200
+    TRSM_MAX_Q = 318
+
+    def chol_factor(self, G, rel_tol=1e-12):
+        self._count("chol_factor")
+        L, inf = torch.linalg.cholesky_ex(G)
+        bad = int(inf.item())
+        d = torch.diagonal(L)
+        if bad == 0 and bool((d * d <= rel_tol * torch.diagonal(G).max()).any()):
+            bad = int(torch.nonzero(d * d <= rel_tol * torch.diagonal(G).max())[0]) + 1
+        if not bad:
+            G.copy_(torch.tril(L) + torch.triu(G, 1))
+        return torch.tensor([bad], dtype=torch.int32)
+
+    def trsm_rows(self, X, L):
+        self._count("trsm_rows")
+        return torch.linalg.solve_triangular(torch.tril(L), X.T, upper=False).T.contiguous()
+
     def matmul(self, A, B):
         return torch.matmul(A, B)
 

@@ -86,25 +86,3 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
                 assert "tests.cpu_stand_in" not in src
-
-
-def test_isa_audit_of_scalar_load_kernel():
-    """The inline-asm s_load pipeline of blocksum_valu_kernel: no instruction may touch an SGPR whose load is
-    still in flight (tools/audit_isa.py).  Checks the auditor on a synthetic violation, then the real build."""
-    import importlib.util
-    import shutil
-    import tempfile
-
-    spec = importlib.util.spec_from_file_location("audit_isa", os.path.join(ROOT, "tools", "audit_isa.py"))
-    audit_isa = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(audit_isa)
-    fake = ("_Z20blocksum_valu_kernelILi1EE: ; @x\n\ts_load_dwordx8 s[8:15], s[2:3], 32\n\tv_writelane_b32 v1, s9, 0\n"
-            "\ts_waitcnt lgkmcnt(0)\n\tv_fma_f64 v[0:1], s[8:9], v[2:3], v[4:5]\n\ts_endpgm\n")
-    seen, problems = audit_isa.audit(fake)
-    assert seen == 1 and len(problems) == 1 and "in-flight" in problems[0]
-    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
-        pytest.skip("hipcc not available")
-    with tempfile.TemporaryDirectory() as d:
-        asm = audit_isa.compile_to_asm(d)
-    seen, problems = audit_isa.audit(asm)
-    assert seen >= 18 and not problems, problems[:3]

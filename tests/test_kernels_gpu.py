@@ -62,6 +62,9 @@ def test_gram_extreme_distances(hip_ops):
     ("rbf", 10, 100, 200, 1311, 3766, 5000, 2, True),        # the last shard: block part + tail
     ("rbf", 3, 70, 150, 150, 0, 150, 1, False),              # final stage: one block, S = R
     ("rbf", 3, 70, 40, 37, 4003, 4000, 1, False),            # shard holding only tail positions
+    ("rbf", 14, 600, 200, 4100, 100, 4000, 3, True),         # KP = 16, two row groups, shard starting mid-block, tail
+    ("matern52", 18, 257, 74, 1000, 0, 962, 2, False),       # KP = 20 (largest LDS form), odd S, m = 256 + 1
+    ("rbf", 10, 1000, 200, 1000, 0, 1000, 1, False),         # 5 blocks only: the tile pipeline's short trip counts
 ])
 def test_blocksum_vs_standin(hip_ops, family, d, m, S, Rl, off, n_full, n_chunks, use_wx):
     cpu = CpuStandInOps()
@@ -78,12 +81,10 @@ def test_blocksum_vs_standin(hip_ops, family, d, m, S, Rl, off, n_full, n_chunks
     A_g = hip_ops.pack(spec, dev(nys), dev(center), 0, pad_rows_to=64)
     B_g = hip_ops.pack(spec, dev(cand), dev(center), 1)
     scale = Xc.abs().max().item()
-    for impl in (("mfma", "valu") if d <= 10 else ("mfma",)):     # default (MFMA) form and the scalar-broadcast form
-        Xg, tg = hip_ops.blocksum(spec, A_g, m, B_g, dev(mu), dev(wx) if use_wx else None, Rl, off, n_full, S, n_chunks,
-                                  impl=impl)
-        Xg, tg = Xg.cpu(), tg.cpu()
-        assert (Xg - Xc).abs().max().item() <= 1e-12 * scale, impl
-        assert (tg - tc).abs().max().item() <= 1e-13 * tc.abs().max().item(), impl
+    Xg, tg = hip_ops.blocksum(spec, A_g, m, B_g, dev(mu), dev(wx) if use_wx else None, Rl, off, n_full, S, n_chunks)
+    Xg, tg = Xg.cpu(), tg.cpu()
+    assert (Xg - Xc).abs().max().item() <= 1e-12 * scale
+    assert (tg - tc).abs().max().item() <= 1e-13 * tc.abs().max().item()
 
 
 def test_matvec_vs_standin(hip_ops):
@@ -271,6 +272,34 @@ def test_chol_inv(hip_ops, q):
     assert torch.equal(torch.tril(W.cpu(), -1), torch.zeros(q, q, dtype=torch.float64))
     Winv = torch.linalg.inv(L).T                               # W = L^{-T}
     assert (W.cpu() - Winv).abs().max().item() <= 1e-9 * Winv.abs().max().item()
+
+
+@pytest.mark.parametrize("q", [1, 5, 8, 9, 16, 30, 99, 100, 143, 199, 200])
+@pytest.mark.parametrize("rows", [1000, 64, 37])
+def test_chol_factor_and_trsm_rows(hip_ops, q, rows):
+    """Panel Cholesky (packed triangle in LDS, 8-column panels) + row-parallel triangular solve: X L^-T is orthonormal
+    and equals the host factorisation's result; the strict upper triangle of G is left alone."""
+    rows = max(rows, q + 3)
+    X = _rand(rows, q, 7 + q)
+    G = X.T @ X
+    Gd = hip_ops.to_device(G.clone())
+    info = hip_ops.chol_factor(Gd)
+    assert int(info.cpu()[0]) == 0
+    L = torch.tril(Gd.cpu())
+    Lref = torch.linalg.cholesky(G)
+    assert (L - Lref).abs().max().item() <= 1e-11 * Lref.abs().max().item()
+    assert torch.equal(torch.triu(Gd.cpu(), 1), torch.triu(G, 1))
+    Q = hip_ops.trsm_rows(hip_ops.to_device(X), Gd).cpu()
+    assert (Q.T @ Q - torch.eye(q, dtype=torch.float64)).abs().max().item() <= 1e-10
+    Qref = torch.linalg.solve_triangular(Lref, X.T, upper=False).T
+    assert (Q - Qref).abs().max().item() <= 1e-10 * Qref.abs().max().item()
+
+
+def test_chol_factor_flags_rank_deficiency(hip_ops):
+    X = _rand(50, 12, 3)
+    X[:, 10] = X[:, 0] + X[:, 1]             # exactly dependent column (second panel)
+    info = hip_ops.chol_factor(hip_ops.to_device(X.T @ X))
+    assert int(info.cpu()[0]) == 11
 
 
 def test_chol_inv_flags_rank_deficiency(hip_ops):

@@ -1,4 +1,4 @@
-"""A/B timing of the block-sum kernel variants on one GPU (HIP events on the launch stream).
+"""Timing of the block-sum kernel on one GPU (HIP events on the launch stream).
 
     python tools/bench_blocksum.py [--R 1000000] [--m 10000] [--d 10] [--n 100] [--family rbf]
 """
@@ -35,26 +35,23 @@ def main():
     B = ops.pack(spec, pts, c, 1)
     mu, _ = ops.init_state(args.R, 0, args.R)
     geo = RoundGeometry.of(args.R, S)
-    nch = args.chunks or choose_chunks(local_blocks(0, args.R, geo), args.m, S, ops.kp(args.d) // 4)
     pairs = float(args.R) * args.m
     out = {}
-    impls = ("mfma", "valu") if args.d <= 10 else ("mfma",)
+    impls = ("mfma",)
     for impl in impls:
-        X, t = ops.blocksum(spec, A, args.m, B, mu, None, args.R, 0, geo.n_full, S, nch, impl=impl)   # warm-up
+        nch = args.chunks or choose_chunks(local_blocks(0, args.R, geo), args.m, S, ops.kp(args.d) // 4)
+        X, t = ops.blocksum(spec, A, args.m, B, mu, None, args.R, 0, geo.n_full, S, nch)   # warm-up
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.reps):
-            X, t = ops.blocksum(spec, A, args.m, B, mu, None, args.R, 0, geo.n_full, S, nch, impl=impl)
+            X, t = ops.blocksum(spec, A, args.m, B, mu, None, args.R, 0, geo.n_full, S, nch)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps
         out[impl] = X.sum(0)
         flops = pairs * (3 * args.d + 3)
         print(f"{impl:5s} chunks={nch} {ms:9.3f} ms  {pairs / ms / 1e6:8.2f} Gpair/s  {flops / ms / 1e9:7.2f} TFLOP/s(3d+3)")
-    if "valu" in out:
-        rel = ((out["valu"] - out["mfma"]).abs().max() / out["mfma"].abs().max()).item()
-        print(f"valu vs mfma max rel diff {rel:.2e}")
 
 
 if __name__ == "__main__":

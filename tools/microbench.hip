@@ -7,16 +7,27 @@
 #include <vector>
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-template <int MODE>   // 0 = fma only, 1 = mfma only, 2 = both interleaved (1 mfma : 20 fma)
+template <int MODE>   // 0 = fma only (two constant operands), 1 = mfma only, 2 = both interleaved (1 mfma : 20 fma),
+                      // 3 = fma only with THREE VGPR operands (what a VALU distance kernel issues: a[k] * b[k] + D)
 __global__ void __launch_bounds__(256) rate_kernel(double* out, int iters, double seed, unsigned long long* stamps) {
     // in-kernel clock (MI355X_MICROARCH.md, DVFS item 6): d(s_memtime) / d(s_memrealtime) x 100 MHz
-    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     double a0 = seed + threadIdx.x, a1 = a0 * 0.5, a2 = a0 * 0.25, a3 = a0 * 0.125;
     double a4 = a0 + 1, a5 = a0 + 2, a6 = a0 + 3, a7 = a0 + 4;
     const double m = 0.999999, c = 1e-9;
     d4 D0 = {0, 0, 0, 0}, D1 = {0, 0, 0, 0}, D2 = {0, 0, 0, 0}, D3 = {0, 0, 0, 0};
     const double pa = seed * 1e-3, pb = seed * 2e-3;
+    double b0 = a0 * 1e-9 + 0.999999, b1 = b0 + 1e-12, b2 = b0 + 2e-12, b3 = b0 + 3e-12;
+    double c0 = seed * 1e-9, c1 = c0 * 2, c2 = c0 * 3, c3 = c0 * 4;
+    asm volatile("" : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3), "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3));
     for (int i = 0; i < iters; ++i) {
+        if (MODE == 3) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                a0 = __builtin_fma(a0, b0, c0); a1 = __builtin_fma(a1, b1, c1); a2 = __builtin_fma(a2, b2, c2); a3 = __builtin_fma(a3, b3, c3);
+                a4 = __builtin_fma(a4, b0, c1); a5 = __builtin_fma(a5, b1, c2); a6 = __builtin_fma(a6, b2, c3); a7 = __builtin_fma(a7, b3, c0);
+            }
+        }
         if (MODE == 0 || MODE == 2) {
 #pragma unroll
             for (int u = 0; u < (MODE == 2 ? 10 : 16); ++u) {
@@ -33,7 +44,7 @@ __global__ void __launch_bounds__(256) rate_kernel(double* out, int iters, doubl
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + D0[0] + D1[1] + D2[2] + D3[3];
     if (stamps && threadIdx.x == 0) {
-        stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - c0;
+        stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - clk0;
         stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
 }
@@ -91,6 +102,7 @@ int main() {
         run<0>("fma_f64 only", w, 128, 0, warm);
         run<1>("mfma_f64 16x16x4 only", w, 0, 4, warm);
         run<2>("both (80 fma : 4 mfma)", w, 80, 4, warm);
+        run<3>("fma_f64, 3 VGPR operands", w, 128, 0, warm);
     }
     return 0;
 }
