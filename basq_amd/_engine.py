@@ -235,6 +235,23 @@ def _skip_test_matrix_draw(ops, m, q):
 REPLICATED_REDUCTION = True
 SHARDED_BASIS = True             # multi-rank: split the range finder's Gram products over the ranks (False: rank 0 only)
 LATE_CHUNKS = 1                  # chunks of the round-1 block sums deferred behind the range finder (0 = none)
+# Residue-class block sums: evaluate the pairwise kernel once per EPOCH of log2(C) + 1 rounds.  The chunks of the block
+# sums are the residue classes of the block index modulo C; a round that keeps exactly half of the sets sends the
+# survivor of (block b, kept rank k) to (block b // 2, set (b % 2) * n + k), so the next round's sums -- again per class,
+# modulo C / 2 -- are a gather + rescale of this round's (``basq_regroup_classes_f64``): no candidate is touched.  Only
+# the blocks beyond a multiple of C and the ragged tail (< (C + 1) * S points, halving every round) are evaluated directly.
+CLASS_SUMS = True
+MAX_CLASSES = 16                 # classes at the start of an epoch (power of two): 16 -> the kernel runs in rounds 1, 6, 11
+
+
+def _classes_for(nb_global: int, m: int, S: int, kk: int) -> int:
+    """Number of residue classes (a power of two, 1 = none) for an evaluation over ``nb_global`` full blocks."""
+    if not CLASS_SUMS:
+        return 1
+    c = MAX_CLASSES
+    while c > 1 and nb_global < 4 * c:           # at least four blocks per class (the classes are also the chunks)
+        c //= 2
+    return c
 
 
 def _late_split(off: int, Rl: int, n_full: int, S: int, n_chunks: int, n_late: int):
@@ -576,29 +593,67 @@ class RecombinationEngine:
         #      for the range finder then overlaps with the largest kernel of the batch -----------------------
         pre = None
         late = None                                             # deferred part of the round-1 block sums
+        cls = None                                              # inherited class partials: dict(T, tot, C, reg_blocks)
+        use_classes = CLASS_SUMS and not opaque and not sober and warp != "wsabim"
+
+        def timed_blocksum(p_lo, p_hi, geo_, S_, n_ch, out, class_mod=0, class0=0):
+            """One block-sum launch over the local positions [p_lo, p_hi) (+ HIP events for the roofline line)."""
+            ev0 = ops.record_event() if (trace is not None and trace.time_kernels) else None
+            ops.blocksum(spec, nys_ext, m_ext, cand[p_lo:], mu[p_lo:], None if wx is None else wx[p_lo:], p_hi - p_lo,
+                         off + p_lo, geo_.n_full, S_, n_ch, out=out, class_mod=class_mod, class0=class0)
+            if ev0 is not None and p_hi > p_lo:
+                # pairs this launch evaluates: one class launch covers n_ch of class_mod classes of its range
+                frac = (n_ch / class_mod) if class_mod else 1.0
+                trace.kernel_events.append((ev0, ops.record_event(), dict(pairs=float(p_hi - p_lo) * m_ext * frac,
+                                                                         R=(p_hi - p_lo) * frac, m=m_ext, S=S_, chunks=n_ch)))
+
+        def evaluate_block_sums(geo_, S_, inherited, defer_last=False):
+            """Block sums of one round -> ``(Xbuf [n, m_ext, S], totbuf [n, S], n, C, reg_blocks, late_fn)``.
+
+            ``inherited`` (class partials regrouped from the previous round) covers the regular region; otherwise the
+            regular region -- the first ``reg_blocks`` (a multiple of C) blocks -- is evaluated per residue class.  The
+            rest (further blocks + ragged tail) is one contiguous chunk, slot ``n - 1``.  ``defer_last``: the last
+            class and the irregular chunk are returned as ``late_fn`` instead of being launched (round 1: they run
+            behind the range finder's GPU work)."""
+            if inherited is not None:
+                C, reg_blocks = inherited["C"], inherited["reg_blocks"]
+                Xbuf, totbuf = inherited["X"], inherited["tot"]          # [C + 1, ...]: last slot reserved
+            else:
+                C = _classes_for(geo_.nb, m_ext, S_, kp // 4) if (use_classes and S_ == S) else 1
+                if C == 1:                                               # plain contiguous chunks (small rounds)
+                    n_ch = choose_chunks(local_blocks(off, Rl, geo_), m_ext, S_, kp // 4)
+                    Xbuf, totbuf = ops.empty(n_ch, m_ext, S_), ops.empty(n_ch, S_)
+                    p_split = _late_split(off, Rl, geo_.n_full, S_, n_ch, LATE_CHUNKS) if (defer_last and Rl > 0) else None
+                    if p_split is None:
+                        timed_blocksum(0, Rl, geo_, S_, n_ch, (Xbuf, totbuf))
+                        return Xbuf, totbuf, n_ch, 1, 0, None
+                    # the last chunk(s) are launched behind the range finder's GPU work; same chunk boundaries, same sums
+                    timed_blocksum(0, p_split, geo_, S_, n_ch - LATE_CHUNKS, (Xbuf[:n_ch - LATE_CHUNKS], totbuf[:n_ch - LATE_CHUNKS]))
+                    return (Xbuf, totbuf, n_ch, 1, 0,
+                            lambda: timed_blocksum(p_split, Rl, geo_, S_, LATE_CHUNKS, (Xbuf[n_ch - LATE_CHUNKS:], totbuf[n_ch - LATE_CHUNKS:])))
+                reg_blocks = (geo_.nb // C) * C
+                Xbuf, totbuf = ops.empty(C + 1, m_ext, S_), ops.empty(C + 1, S_)
+            reg_hi = min(max(reg_blocks * S_ - off, 0), Rl)              # local end of the regular region
+            irregular = lambda: timed_blocksum(reg_hi, Rl, geo_, S_, 1, (Xbuf[C:C + 1], totbuf[C:C + 1]))   # noqa: E731
+            if inherited is not None:
+                irregular()
+                return Xbuf, totbuf, C + 1, C, reg_blocks, None
+            if defer_last and C >= 2:
+                timed_blocksum(0, reg_hi, geo_, S_, C - 1, (Xbuf[:C - 1], totbuf[:C - 1]), class_mod=C, class0=0)
+
+                def late_fn():
+                    timed_blocksum(0, reg_hi, geo_, S_, 1, (Xbuf[C - 1:C], totbuf[C - 1:C]), class_mod=C, class0=C - 1)
+                    irregular()
+
+                return Xbuf, totbuf, C + 1, C, reg_blocks, late_fn
+            timed_blocksum(0, reg_hi, geo_, S_, C, (Xbuf[:C], totbuf[:C]), class_mod=C, class0=0)
+            irregular()
+            return Xbuf, totbuf, C + 1, C, reg_blocks, None
+
         if R > S and not opaque:
             geo = RoundGeometry.of(R, S)
-            n_chunks = choose_chunks(local_blocks(off, Rl, geo), m_ext, S, kp // 4)
-            Xpart, totpart = ops.empty(n_chunks, m_ext, S), ops.empty(n_chunks, S)
-
-            def launch(c_lo, c_hi, p_lo, p_hi):
-                ev0 = ops.record_event() if (trace is not None and trace.time_kernels) else None
-                ops.blocksum(spec, nys_ext, m_ext, cand[p_lo:], mu[p_lo:], None if wx is None else wx[p_lo:], p_hi - p_lo,
-                             off + p_lo, geo.n_full, S, c_hi - c_lo, out=(Xpart[c_lo:c_hi], totpart[c_lo:c_hi]))
-                if ev0 is not None:
-                    trace.kernel_events.append((ev0, ops.record_event(), dict(pairs=float(p_hi - p_lo) * m_ext,
-                                                                             R=p_hi - p_lo, m=m_ext, S=S,
-                                                                             chunks=c_hi - c_lo)))
-
-            p_split = _late_split(off, Rl, geo.n_full, S, n_chunks, LATE_CHUNKS) if Rl > 0 else None
-            if p_split is None:
-                launch(0, n_chunks, 0, Rl)
-            else:
-                # the last chunk(s) are launched behind the range finder's GPU work: they run while the host does the
-                # k x k SVD of the basis (~1 ms during which the GPU would idle); same chunk boundaries, same sums
-                launch(0, n_chunks - LATE_CHUNKS, 0, p_split)
-                late = lambda: launch(n_chunks - LATE_CHUNKS, n_chunks, p_split, Rl)      # noqa: E731
-            pre = (Xpart, totpart, n_chunks)
+            pre = evaluate_block_sums(geo, S, None, defer_last=True)
+            late = pre[5]
 
         # ---- Nystrom basis (one Gaussian draw on rank 0, as in the reference) ----------------------------
         if SHARDED_BASIS and comm.world > 1 and not sober and not opaque:
@@ -670,22 +725,20 @@ class RecombinationEngine:
             S_r = R if final else S
             geo = RoundGeometry.of(R, S_r)
             t0 = time.perf_counter()
+            C_cur, reg_blocks = 1, 0
             if opaque:
                 with _Timer(ops, trace, "blocksum"):
                     Xpart, totpart = self._opaque_block_sums(kernel, pts_nys, cand, mu, Rl, off, geo.n_full, S_r, m)
                 n_chunks = 1
-            elif pre is not None:
-                Xpart, totpart, n_chunks = pre
-                pre = None
             else:
-                n_chunks = choose_chunks(local_blocks(off, Rl, geo), m_ext, S_r, kp // 4)
-                ev0 = ops.record_event() if (trace is not None and trace.time_kernels) else None
                 with _Timer(ops, trace, "blocksum"):
-                    Xpart, totpart = ops.blocksum(spec, nys_ext, m_ext, cand, mu, wx, Rl, off, geo.n_full, S_r,
-                                                  n_chunks)
-                if ev0 is not None:
-                    trace.kernel_events.append((ev0, ops.record_event(), dict(pairs=float(Rl) * m_ext, R=Rl, m=m_ext,
-                                                                             S=S_r, chunks=n_chunks)))
+                    if pre is not None:
+                        Xpart, totpart, n_chunks, C_cur, reg_blocks = pre[:5]
+                        pre = None
+                    else:
+                        Xpart, totpart, n_chunks, C_cur, reg_blocks, _ = evaluate_block_sums(
+                            geo, S_r, cls if (not final and S_r == S) else None)
+                cls = None
             if sober and not final and geo.n_tail > 0:
                 # SOBER/_rchq.py:127-135: the remainder's kernel columns also go to sets 0..N_rest-1 (no weight added)
                 t0l = max(geo.n_full - off, 0)                   # first local tail position
@@ -789,6 +842,13 @@ class RecombinationEngine:
                 idx, w = gids[kept_t], w_star[:n_keep].clone()   # :69-73
                 break
             t0 = time.perf_counter()
+            if C_cur >= 2 and 2 * n_keep == S_r and status == 0:
+                # exactly half of the sets survived: the next round's class partials are a gather + rescale of this round's
+                kept_dev = kept if (comm.world == 1 or replicate) else res[2:2 + M].to(torch.int32)
+                Xn, totn = ops.empty(C_cur // 2 + 1, m_ext, S_r), ops.empty(C_cur // 2 + 1, S_r)
+                ops.regroup_classes(Xpart[:C_cur], totpart[:C_cur], kept_dev, w_star, tot,
+                                    out=(Xn[:C_cur // 2], totn[:C_cur // 2]))
+                cls = dict(X=Xn, tot=totn, C=C_cur // 2, reg_blocks=reg_blocks // 2)
             new_off, new_Rl = next_shard(off, Rl, geo, kept_list)
             cand, mu, gid, wx = ops.reweight_compact(cand, mu, gid, wx, Rl, off, geo.n_full, S_r, kp, keep_rank, w_star,
                                                      tot, n_keep, new_off, new_Rl)

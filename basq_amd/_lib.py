@@ -37,7 +37,9 @@ SIGNATURES = {
     "basq_pack_points_f64": (C.c_int, [_specp, _vp, _i64, _vp, C.c_int, _vp, _vp]),
     "basq_gram_f64": (C.c_int, [_specp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "basq_kernel_matvec_f64": (C.c_int, [_specp, _vp, _i64, _vp, _i64, _vp, _f64, _vp, _vp]),
-    "basq_blocksum_f64": (C.c_int, [_specp, _vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "basq_blocksum_f64": (C.c_int, [_specp, _vp, _i32, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp,
+                                    _vp]),
+    "basq_regroup_classes_f64": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "basq_project_f64": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _f64, _i32, _vp, _vp, _vp]),
     "basq_finalize_f64": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _f64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "basq_nullspace_f64": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),

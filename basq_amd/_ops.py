@@ -105,8 +105,11 @@ class HipOps:
                                               _ptr(out), self._stream()), "basq_kernel_matvec_f64")
         return out
 
-    def blocksum(self, spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, out=None):
-        """``out = (Xpart [n_chunks, m, S], totpart [n_chunks, S])``: write into caller-provided (contiguous) slices."""
+    def blocksum(self, spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, out=None, class_mod=0, class0=0):
+        """``out = (Xpart [n_chunks, m, S], totpart [n_chunks, S])``: write into caller-provided (contiguous) slices.
+
+        ``class_mod > 0``: chunk c = the blocks ``b % class_mod == class0 + c`` (residue classes) instead of contiguous
+        block ranges; the range must then hold full blocks only."""
         if out is None:
             Xpart = self.empty(n_chunks, m, S)
             totpart = self.empty(n_chunks, S)
@@ -120,8 +123,23 @@ class HipOps:
             return Xpart, totpart
         sc = self.spec_c(spec)
         check(self.lib.basq_blocksum_f64(C.byref(sc), _ptr(nys), m, _ptr(cand), _ptr(mu), _ptr(wx), Rl, off, n_full, S,
-                                         n_chunks, _ptr(Xpart), _ptr(totpart), self._stream()), "basq_blocksum_f64")
+                                         n_chunks, int(class_mod), int(class0), _ptr(Xpart), _ptr(totpart),
+                                         self._stream()), "basq_blocksum_f64")
         return Xpart, totpart
+
+    def regroup_classes(self, T, totT, kept, w_star, tot, out=None):
+        """Class partials of the next round from this round's (``basq_regroup_classes_f64``): ``T [C, m, S]``,
+        ``totT [C, S]`` -> ``([C/2, m, S], [C/2, S])`` (``out``: caller-provided contiguous slices).  ``kept`` int32
+        (first S/2 entries), ``w_star``, ``tot`` on the device."""
+        Cn, m, S = T.shape
+        assert T.is_contiguous() and totT.is_contiguous()
+        To, toto = out if out is not None else (self.empty(Cn // 2, m, S), self.empty(Cn // 2, S))
+        assert To.is_contiguous() and toto.is_contiguous() and tuple(To.shape) == (Cn // 2, m, S)
+        check(self.lib.basq_regroup_classes_f64(_ptr(T), m, S, Cn, _ptr(kept), _ptr(w_star), _ptr(tot), _ptr(To),
+                                                self._stream()), "basq_regroup_classes_f64")
+        check(self.lib.basq_regroup_classes_f64(_ptr(totT), 1, S, Cn, _ptr(kept), _ptr(w_star), _ptr(tot), _ptr(toto),
+                                                self._stream()), "basq_regroup_classes_f64")
+        return To, toto
 
     def project(self, U, q, m, Xpart, totpart, n_chunks, S, outputscale, ksplit=None):
         self._chk(U)

@@ -258,6 +258,7 @@ struct BlocksumArgs {
     double* totpart;
     long long Rl, off, n_full;
     long long blk_lo, blk_hi, blk_per_chunk;   // global block-index range touched by this rank
+    int class_mod, class0;                     // > 0: chunk c = the blocks b with b % class_mod == class0 + c (residue classes)
     int m, S, n_chunks, n_stiles;
 };
 
@@ -327,49 +328,58 @@ __global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A) {
 
     const bool col_ok = (s0 + c) < A.S;
     const long long lim = (A.off + A.Rl < A.n_full) ? (A.off + A.Rl) : A.n_full;   // end of block positions held here
-    long long bA = A.blk_lo + (long long)chunk * A.blk_per_chunk;
-    long long bB = bA + A.blk_per_chunk;
-    if (bB > A.blk_hi) bB = A.blk_hi;
+    // blocks of this chunk: a contiguous range (step 1), or -- residue-class mode -- every class_mod-th block of the
+    // rank's range, starting at the first block congruent to this chunk's class
+    long long bA, bB, bstep;
+    if (A.class_mod > 0) {
+        bstep = A.class_mod;
+        const long long cls = A.class0 + chunk;
+        bA = A.blk_lo + ((cls - A.blk_lo % bstep) % bstep + bstep) % bstep;
+        bB = A.blk_hi;
+    } else {
+        bstep = 1;
+        bA = A.blk_lo + (long long)chunk * A.blk_per_chunk;
+        bB = bA + A.blk_per_chunk;
+        if (bB > A.blk_hi) bB = A.blk_hi;
+    }
 
     if (bA < bB) {
         // Blocks whose 16 columns all lie inside this rank's block positions take the fast path: the lane's
-        // row pointer just advances by S rows per block (no masks, no 64-bit index arithmetic).  [bF0, bF1) is
-        // that wave-uniform range; the (at most two) edge blocks before/after it use the masked path.
+        // row pointer just advances by bstep * S rows per block (no masks, no 64-bit index arithmetic).  The (at most
+        // two) edge blocks before / after that wave-uniform range use the masked path.
         const long long first_ok = (A.off - s0 + A.S - 1) / A.S;                 // smallest i with i*S + s0 >= off
         const long long last_ok = (lim - s0 - 16 >= 0) ? ((lim - s0 - 16) / A.S) : -1;   // largest i with i*S+s0+15 < lim
         const bool tile_full = (s0 + 16) <= A.S;
-        long long bF0 = tile_full ? (first_ok > bA ? first_ok : bA) : bB;
-        long long bF1 = tile_full ? ((last_ok + 1 < bB) ? (last_ok + 1) : bB) : bB;
-        if (bF1 < bF0) bF1 = bF0;
-        if (bF0 > bB) bF0 = bF1 = bB;
-        // masked prologue blocks [bA, bF0)
-        for (long long i = bA; i < bF0; ++i) {
+        long long i = bA;
+        // masked prologue blocks
+        for (; i < bB && (!tile_full || i < first_ok); i += bstep) {
             const long long pg = i * A.S + s0 + c;
             CandFrag<KK> f;
             load_cand<KK>(f, A, pg - A.off, col_ok && pg >= A.off && pg < lim, g);
             tile_accumulate<KK, FAM, JT>(a, f, acc, ek, exp_tab);
             tot += f.wm;
         }
-        if (bF0 < bF1) {
-            const long long p0 = bF0 * A.S + s0 + c - A.off;                     // local row of this lane, block bF0
+        const long long bF1 = (last_ok + 1 < bB) ? (last_ok + 1) : bB;           // end of the fast range
+        if (tile_full && i < bF1) {
+            const long long p0 = i * A.S + s0 + c - A.off;                       // local row of this lane, block i
             const double* rp = A.cand + p0 * KP + g;
             const double* mp = A.mu + p0;
             const double* xp = A.wx ? (A.wx + p0) : nullptr;
-            const long long rstep = (long long)A.S * KP;
+            const long long rstep = bstep * (long long)A.S * KP, mstep = bstep * (long long)A.S;
             CandFrag<KK> cur, nxt;
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) cur.b[kk] = rp[kk * 4];
             cur.wm = mp[0];
             cur.w = xp ? cur.wm * xp[0] : cur.wm;
-            for (long long i = bF0; i < bF1; ++i) {
-                const bool more = (i + 1 < bF1);
+            for (; i < bF1; i += bstep) {
+                const bool more = (i + bstep < bF1);
                 const double* rn = more ? (rp + rstep) : rp;                     // last trip re-reads its own row
-                const double* mn = more ? (mp + A.S) : mp;
+                const double* mn = more ? (mp + mstep) : mp;
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk) nxt.b[kk] = rn[kk * 4];
                 nxt.wm = mn[0];
                 if (xp) {
-                    const double* xn = more ? (xp + A.S) : xp;
+                    const double* xn = more ? (xp + mstep) : xp;
                     nxt.w = nxt.wm * xn[0];
                     xp = xn;
                 } else {
@@ -382,8 +392,8 @@ __global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A) {
                 mp = mn;
             }
         }
-        // masked epilogue blocks [bF1, bB)
-        for (long long i = bF1; i < bB; ++i) {
+        // masked epilogue blocks
+        for (; i < bB; i += bstep) {
             const long long pg = i * A.S + s0 + c;
             CandFrag<KK> f;
             load_cand<KK>(f, A, pg - A.off, col_ok && pg >= A.off && pg < lim, g);
@@ -2505,14 +2515,17 @@ __global__ void __launch_bounds__(1024) chol_factor_panel_kernel(double* __restr
 #pragma unroll
             for (int c = 0; c < NB; ++c)
                 if (c < nb) BASQ_TRI(i, j0 + c) = y[c];
-        } else if (tid == R) {                                              // R <= 192 < 1024: this thread always exists
+        }
+        __syncthreads();
+        // the factored block goes back only now: before the barrier a slower wave may still be READING the unfactored
+        // block in F1 (F3 below touches neither the block nor these rows' panel entries)
+        if (tid == 1023) {
 #pragma unroll
             for (int r = 0; r < NB; ++r)
 #pragma unroll
                 for (int c = 0; c <= r; ++c)
                     if (r < nb) BASQ_TRI(j0 + r, j0 + c) = D[r][c];
         }
-        __syncthreads();
         // ---- F3: trailing triangle, 4 x 4 tiles ----
         const int nt = (R + 3) >> 2, ntiles = nt * (nt + 1) / 2;
         for (int tile = tid; tile < ntiles; tile += 1024) {
@@ -2778,13 +2791,17 @@ int basq_gram_f64(const basq_kernel_spec* spec, const double* packA, int64_t na,
 
 static int blocksum_impl(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
                          const double* mu, const double* wx, int64_t Rl, int64_t off, int64_t n_full, int32_t S,
-                         int32_t n_chunks, double* Xpart, double* totpart, void* stream) {
+                         int32_t n_chunks, int32_t class_mod, int32_t class0, double* Xpart, double* totpart,
+                         void* stream) {
     if (!spec_ok(spec) || !nys || !cand || !mu || !Xpart) return BASQ_EINVAL;
     if (m < 1 || Rl < 1 || off < 0 || n_full < 0 || S < 1 || n_chunks < 1) return BASQ_EINVAL;
     if (n_full % S != 0) return BASQ_EINVAL;
+    if (class_mod < 0 || class0 < 0 || (class_mod > 0 && class0 + n_chunks > class_mod)) return BASQ_EINVAL;
+    if (class_mod > 0 && off + Rl > n_full) return BASQ_EINVAL;   // residue classes cover full blocks only (no ragged tail)
     BlocksumArgs A;
     A.nys = nys; A.cand = cand; A.mu = mu; A.wx = wx; A.Xpart = Xpart; A.totpart = totpart;
     A.Rl = Rl; A.off = off; A.n_full = n_full; A.m = m; A.S = S; A.n_chunks = n_chunks;
+    A.class_mod = class_mod; A.class0 = class0;
     A.n_stiles = (S + 15) / 16;
     // global blocks that intersect [off, min(off+Rl, n_full))
     const long long lim = (off + Rl < n_full) ? (off + Rl) : n_full;
@@ -2803,9 +2820,38 @@ static int blocksum_impl(const basq_kernel_spec* spec, const double* nys, int32_
 
 int basq_blocksum_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
                       const double* mu, const double* wx, int64_t Rl, int64_t off, int64_t n_full, int32_t S,
-                      int32_t n_chunks, double* Xpart, double* totpart, void* stream) {
+                      int32_t n_chunks, int32_t class_mod, int32_t class0, double* Xpart, double* totpart, void* stream) {
     if (!totpart) return BASQ_EINVAL;
-    return blocksum_impl(spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, Xpart, totpart, stream);
+    return blocksum_impl(spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, class_mod, class0, Xpart, totpart,
+                         stream);
+}
+
+// Next round's class partials from this round's, without touching a candidate (see include/basq_hip.h):
+//   Tout[c'][j][par * H + k] = (Tin[2 c' + par][j][kept[k]] * w_star[k]) / tot[kept[k]],   H = n_keep = S / 2
+__global__ void regroup_classes_kernel(const double* __restrict__ Tin, int rows, int S, int C, const int* __restrict__ kept,
+                                       const double* __restrict__ w_star, const double* __restrict__ tot,
+                                       double* __restrict__ Tout) {
+#pragma clang fp contract(off)
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = (long long)(C / 2) * rows * S;
+    if (e >= n) return;
+    const int sp = (int)(e % S);
+    const long long rest = e / S;
+    const int j = (int)(rest % rows), cp = (int)(rest / rows);
+    const int H = S / 2, par = sp / H, k = sp - par * H;
+    const int s = kept[k];
+    const double v = Tin[((long long)(2 * cp + par) * rows + j) * S + s];
+    Tout[e] = (v * w_star[k]) / tot[s];                                        // the order of BASQ/_rchq.py:113-114
+}
+
+int basq_regroup_classes_f64(const double* Tin, int32_t rows, int32_t S, int32_t C, const int32_t* kept,
+                             const double* w_star, const double* tot, double* Tout, void* stream) {
+    if (!Tin || !kept || !w_star || !tot || !Tout || rows < 1 || S < 2 || (S & 1) || C < 2 || (C & 1)) return BASQ_EINVAL;
+    const long long n = (long long)(C / 2) * rows * S;
+    hipLaunchKernelGGL(regroup_classes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Tin,
+                       rows, S, C, kept, w_star, tot, Tout);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
 }
 
 int basq_kernel_matvec_f64(const basq_kernel_spec* spec, const double* packA, int64_t na, const double* packB,
@@ -2813,7 +2859,7 @@ int basq_kernel_matvec_f64(const basq_kernel_spec* spec, const double* packA, in
     // blocksum with a single set and everything in the "tail": out[i] = sum_j k(A_i, B_j) v_j.
     if (!spec_ok(spec) || !packA || !packB || !v || !out || na < 1 || nb < 1 || na > 0x7fffffffLL)
         return BASQ_EINVAL;
-    int rc = blocksum_impl(spec, packA, (int32_t)na, packB, v, nullptr, nb, 0, 0, 1, 1, out, nullptr, stream);
+    int rc = blocksum_impl(spec, packA, (int32_t)na, packB, v, nullptr, nb, 0, 0, 1, 1, 0, 0, out, nullptr, stream);
     if (rc != BASQ_OK) return rc;
     hipLaunchKernelGGL(axpb_strided_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out,
                        (long long)na, 1LL, spec->outputscale, bias, out);
@@ -2967,7 +3013,7 @@ int basq_nullspace_f64(const double* X, int32_t s, int32_t M, double* V, double*
     }
     if (rc != BASQ_OK) return rc;
     const int nvec = M - s;
-    if (BASQ_NS_APPLY16 && M <= 512) {
+    if (BASQ_NS_APPLY16 && M > 256 && M <= 512) {   // M <= 256: the 64-lane form is faster (31 vs 49 us at 100 x 200)
         const dim3 grid((nvec + 15) / 16), block(256);
         if (M <= 208) hipLaunchKernelGGL(nullspace_apply16_kernel<13>, grid, block, 0, st, V, tau, s, M, PhiT);
         else if (M <= 256) hipLaunchKernelGGL(nullspace_apply16_kernel<16>, grid, block, 0, st, V, tau, s, M, PhiT);

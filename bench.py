@@ -188,7 +188,8 @@ def main():
             dtype="f64", host_cores=ncpu,
             value_f32=1.0 / best32["seconds_per_batch"], cores_f32=best32["threads"],
             matrix=[dict(dtype=c["dtype"], threads=c["threads"], seconds_per_batch=round(c["seconds_per_batch"], 2),
-                         measured_seconds=round(c["measured_seconds"], 2)) for c in cells],
+                         measured_seconds=round(c["measured_seconds"], 2), abbreviated=bool(c.get("abbreviated", False)))
+                    for c in cells],
             sample=(f"oracle (reference op sequence, torch CPU) on pool seed 0: Gram+svd_lowrank, all "
                     f"{best['n_rounds']} rounds' projection/SVD/elimination in full; hot loop every {stride}th block "
                     f"({best['kernel_calls_run']}/{best['kernel_calls_total']} kernel calls), loop time scaled; value = "

@@ -98,10 +98,30 @@ int basq_kernel_matvec_f64(const basq_kernel_spec* spec, const double* packA, in
  * adds the chunks in index order, so results do not depend on scheduling).  Chunk n_chunks-1 also
  * receives the tail.  Xpart: [n_chunks, m, S], totpart: [n_chunks, S]; both fully overwritten.
  * The output is NOT multiplied by outputscale (basq_project_f64 applies it).
+ *
+ * Residue classes (class_mod > 0): chunk c sums the blocks b with  b % class_mod == class0 + c  instead of a contiguous
+ * range (class0 + n_chunks <= class_mod; the rank's range must hold full blocks only, off + Rl <= n_full).  Summing
+ * all class_mod classes gives the same block sums; keeping them apart makes the NEXT rounds free, see
+ * basq_regroup_classes_f64.
  */
 int basq_blocksum_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
                       const double* mu, const double* wx, int64_t Rl, int64_t off, int64_t n_full, int32_t S,
-                      int32_t n_chunks, double* Xpart, double* totpart, void* stream);
+                      int32_t n_chunks, int32_t class_mod, int32_t class0, double* Xpart, double* totpart, void* stream);
+
+/*
+ * Block sums of the next round WITHOUT evaluating the kernel again.  When a round keeps exactly n_keep = S/2 sets
+ * (BASQ/_rchq.py:107-130), the survivor at (block b, kept set of rank k) moves to position b*S/2 + k: block b/2, set
+ * (b % 2) * S/2 + k, and its weight is rescaled by w_star[k] / tot[kept[k]] (:113-114).  So with the sums of this round
+ * held per residue class of the block index,
+ *     Tin[c][j][s] = sum over blocks b == c (mod C) of k(nys_j, x_{b,s}) mu_{b,s},
+ * the next round's are a gather and a rescale:
+ *     Tout[c'][j][par * S/2 + k] = (Tin[2c' + par][j][kept[k]] * w_star[k]) / tot[kept[k]],      c' < C/2, par in {0, 1}
+ * -- half as many classes, so C classes pay for log2(C) rounds.  rows = rows of each [rows, S] class matrix (the caller
+ * regroups the set weights, rows = 1, with a second call).  Valid for the blocks the classes cover; the caller evaluates
+ * the few remaining candidates (blocks beyond a multiple of C, the ragged tail) directly.  C even, S even.
+ */
+int basq_regroup_classes_f64(const double* Tin, int32_t rows, int32_t S, int32_t C, const int32_t* kept,
+                             const double* w_star, const double* tot, double* Tout, void* stream);
 
 /*
  * Nystrom-feature contraction BASQ/_rchq.py:88-90:  out[0][s] = sum_c totpart[c][s];

@@ -65,6 +65,9 @@ CASES = [
     # BASELINE config 5: WSABI-L, N=5e5, d=10, n=100, m=5e3, n_obs=202.
     case("cfg5_wsabil_5e5", 500_000, 10, 5_000, 100, K("rbf", 2.0, 1.0, posterior=POST_W, warp="wsabil"),
          pool_seed=9, slow=True),
+    # the same size with the WSABI-M warp (tutorial 03's model): its 0.5 cov^2 term is not linear in the block sums
+    case("cfg5m_wsabim_5e5", 500_000, 10, 5_000, 100, K("rbf", 2.0, 1.0, posterior=POST_W, warp="wsabim"),
+         pool_seed=9, slow=True),
 ]
 
 BY_NAME = {c["name"]: c for c in CASES}

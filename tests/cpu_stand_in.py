@@ -126,7 +126,27 @@ class CpuStandInOps:
         self._count("matvec")
         return bias + spec.outputscale * (self._kfun(spec, packA[:na] @ packB[:nb].T) @ v)
 
-    def blocksum(self, spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, out=None):
+    def regroup_classes(self, T, totT, kept, w_star, tot, out=None):
+        self._count("regroup")
+        Cn, m, S = T.shape
+        H = S // 2
+        kk = kept[:H].to(torch.int64)
+        scale_w, scale_t = w_star[:H], tot[kk]
+
+        def one(X):                                            # X [C, rows, S] -> [C/2, rows, S]
+            out = torch.empty(Cn // 2, X.shape[1], S, dtype=torch.float64)
+            for par in (0, 1):
+                out[:, :, par * H:(par + 1) * H] = (X[par::2][:, :, kk] * scale_w) / scale_t
+            return out
+
+        To, toto = one(T), one(totT.unsqueeze(1)).squeeze(1)
+        if out is not None:
+            out[0].copy_(To)
+            out[1].copy_(toto)
+            return out
+        return To, toto
+
+    def blocksum(self, spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, out=None, class_mod=0, class0=0):
         self._count("blocksum")
         Xpart = torch.zeros(n_chunks, m, S, dtype=torch.float64)
         totpart = torch.zeros(n_chunks, S, dtype=torch.float64)
@@ -146,7 +166,17 @@ class CpuStandInOps:
             blk_lo = blk_hi = 0
         per = max(1, -(-(blk_hi - blk_lo) // n_chunks))
         chunk = torch.where(pg < n_full, (pg // S - blk_lo) // per, torch.full_like(pg, n_chunks - 1))
+        sel = None
+        if class_mod > 0:                                      # residue classes of the GLOBAL block index
+            assert off + Rl <= n_full and class0 + n_chunks <= class_mod
+            cls = (pg // S) % class_mod - class0
+            sel = (cls >= 0) & (cls < n_chunks)                # blocks of other classes are not part of this launch
+            chunk = cls.clamp(0, n_chunks - 1)
         w = mu[:Rl] * (wx[:Rl] if wx is not None else 1.0)
+        mu_eff = mu[:Rl]
+        if sel is not None:
+            w = torch.where(sel, w, torch.zeros_like(w))
+            mu_eff = torch.where(sel, mu_eff, torch.zeros_like(mu_eff))
         flat = chunk * S + sets
         Xf = torch.zeros(m, n_chunks * S, dtype=torch.float64)
         step = 8192
@@ -156,7 +186,7 @@ class CpuStandInOps:
             Xf.index_add_(1, flat[lo:hi], Kw)
         Xpart = Xf.reshape(m, n_chunks, S).permute(1, 0, 2).contiguous()
         tf = torch.zeros(n_chunks * S, dtype=torch.float64)
-        tf.index_add_(0, flat, mu[:Rl])
+        tf.index_add_(0, flat, mu_eff)
         totpart = tf.reshape(n_chunks, S)
         if out is not None:
             out[0].copy_(Xpart)

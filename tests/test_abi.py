@@ -51,7 +51,11 @@ def test_argument_validation_without_gpu(lib_path):
     lib = _lib.load()
     spec = _lib.KernelSpecC(0, 10, 2.0, 1.0)
     assert lib.basq_pack_points_f64(ctypes.byref(spec), None, 5, None, 0, None, None) == -1
-    assert lib.basq_blocksum_f64(ctypes.byref(spec), None, 1, None, None, None, 1, 0, 0, 1, 1, None, None, None) == -1
+    assert lib.basq_blocksum_f64(ctypes.byref(spec), None, 1, None, None, None, 1, 0, 0, 1, 1, 0, 0, None, None, None) == -1
+    assert lib.basq_blocksum_f64(ctypes.byref(spec), 1, 1, 1, 1, None, 10, 0, 8, 4, 2, 4, 3, 1, 1, None) == -1   # class0 + n_chunks > class_mod
+    assert lib.basq_blocksum_f64(ctypes.byref(spec), 1, 1, 1, 1, None, 10, 0, 8, 4, 2, 4, 0, 1, 1, None) == -1   # classes: no ragged tail
+    assert lib.basq_regroup_classes_f64(None, 1, 4, 2, None, None, None, None, None) == -1
+    assert lib.basq_regroup_classes_f64(1, 1, 4, 3, 1, 1, 1, 1, None) == -1                                       # C must be even
     bad = _lib.KernelSpecC(7, 10, 2.0, 1.0)
     assert lib.basq_gram_f64(ctypes.byref(bad), None, 1, None, 1, None, 1, None) == -1
     assert lib.basq_car_eliminate_f64(None, None, 2000, 10, None, None, None, None, None, None) == -1

@@ -486,3 +486,49 @@ def test_cluster_reductions_repeatable_under_load(hip_ops, s, M):
             assert torch.equal(out[0], first[0]), f"repetition {rep}: null space differs bitwise"
             assert torch.equal(out[1], first[1]) and torch.equal(out[2][: out[3][0]], first[2][: first[3][0]])
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("family,d,m,S,Rl,off,n_full,C,class0,n_ch", [
+    ("rbf", 10, 100, 200, 6400, 0, 6400, 8, 0, 8),           # 32 blocks, all 8 classes in one launch
+    ("rbf", 10, 100, 200, 6400, 0, 6400, 8, 7, 1),           # the last class alone (deferred launch of round 1)
+    ("rbf", 10, 130, 200, 3000, 1300, 6400, 4, 0, 4),        # a middle shard starting and ending mid-block
+    ("matern52", 32, 64, 400, 4000, 0, 4000, 2, 0, 2),       # d = 32 (2 row tiles per wave), S = 400
+    ("rbf", 2, 50, 22, 880, 0, 880, 4, 1, 2),                # S not a multiple of 16; classes 1..2 of 4
+])
+def test_blocksum_residue_classes_vs_standin(hip_ops, family, d, m, S, Rl, off, n_full, C, class0, n_ch):
+    """Residue-class chunks: chunk c = the blocks with (global block index) % C == class0 + c."""
+    cpu = CpuStandInOps()
+    spec = _spec(family, d)
+    nys, cand = _rand(m, d, 3), _rand(Rl, d, 4)
+    g = torch.Generator().manual_seed(5)
+    mu = torch.rand(Rl, generator=g, dtype=torch.float64) + 0.1
+    wx = torch.rand(Rl, generator=g, dtype=torch.float64) + 0.5
+    center = nys.mean(0)
+    A_c, B_c = cpu.pack(spec, nys, center, 0, pad_rows_to=64), cpu.pack(spec, cand, center, 1)
+    Xc, tc = cpu.blocksum(spec, A_c, m, B_c, mu, wx, Rl, off, n_full, S, n_ch, class_mod=C, class0=class0)
+    dev = hip_ops.to_device
+    A_g = hip_ops.pack(spec, dev(nys), dev(center), 0, pad_rows_to=64)
+    B_g = hip_ops.pack(spec, dev(cand), dev(center), 1)
+    Xg, tg = hip_ops.blocksum(spec, A_g, m, B_g, dev(mu), dev(wx), Rl, off, n_full, S, n_ch, class_mod=C, class0=class0)
+    scale = Xc.abs().max().item()
+    assert (Xg.cpu() - Xc).abs().max().item() <= 1e-12 * scale
+    assert (tg.cpu() - tc).abs().max().item() <= 1e-13 * tc.abs().max().item()
+    if class0 == 0 and n_ch == C:                              # all classes together = the plain block sums
+        X1, t1 = cpu.blocksum(spec, A_c, m, B_c, mu, wx, Rl, off, n_full, S, 1)
+        assert (Xg.cpu().sum(0) - X1[0]).abs().max().item() <= 1e-12 * scale
+
+
+@pytest.mark.parametrize("C,m,S", [(8, 70, 200), (2, 33, 22), (16, 5, 400)])
+def test_regroup_classes_vs_standin(hip_ops, C, m, S):
+    cpu = CpuStandInOps()
+    T, totT = _rand(C * m, S, 11).reshape(C, m, S).contiguous(), _rand(C, S, 12).abs() + 0.1
+    g = torch.Generator().manual_seed(3)
+    kept = torch.sort(torch.randperm(S, generator=g)[: S // 2]).values.to(torch.int32)
+    kept_full = torch.zeros(S, dtype=torch.int32)
+    kept_full[: S // 2] = kept
+    w_star = torch.rand(S, generator=g, dtype=torch.float64) + 0.01
+    tot = torch.rand(S, generator=g, dtype=torch.float64) + 0.5
+    Tc, tc = cpu.regroup_classes(T, totT, kept_full, w_star, tot)
+    dev = hip_ops.to_device
+    Tg, tg = hip_ops.regroup_classes(dev(T), dev(totT), dev(kept_full), dev(w_star), dev(tot))
+    assert torch.equal(Tg.cpu(), Tc) and torch.equal(tg.cpu(), tc)           # mul then div, same order: bit-exact
