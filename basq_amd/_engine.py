@@ -593,7 +593,7 @@ class RecombinationEngine:
         #      for the range finder then overlaps with the largest kernel of the batch -----------------------
         pre = None
         late = None                                             # deferred part of the round-1 block sums
-        cls = None                                              # inherited class partials: dict(T, tot, C, reg_blocks)
+        cls = None                                              # inherited class MESSAGES: dict(M [C + 1, rows, S], C, reg_blocks)
         use_classes = CLASS_SUMS and not opaque and not sober and warp != "wsabim"
 
         def timed_blocksum(p_lo, p_hi, geo_, S_, n_ch, out, class_mod=0, class0=0):
@@ -607,38 +607,39 @@ class RecombinationEngine:
                 trace.kernel_events.append((ev0, ops.record_event(), dict(pairs=float(p_hi - p_lo) * m_ext * frac,
                                                                          R=(p_hi - p_lo) * frac, m=m_ext, S=S_, chunks=n_ch)))
 
-        def evaluate_block_sums(geo_, S_, inherited, defer_last=False):
-            """Block sums of one round -> ``(Xbuf [n, m_ext, S], totbuf [n, S], n, C, reg_blocks, late_fn)``.
+        def irregular_block_sums(geo_, S_, reg_blocks):
+            """Block sums of the candidates the class partials do not cover (global positions >= reg_blocks * S: further
+            blocks + the ragged tail), one chunk -> ``(Xirr [1, m_ext, S], totirr [1, S])``."""
+            Xirr, totirr = ops.empty(1, m_ext, S_), ops.empty(1, S_)
+            reg_hi = min(max(reg_blocks * S_ - off, 0), Rl)              # local end of the regular region
+            timed_blocksum(reg_hi, Rl, geo_, S_, 1, (Xirr, totirr))
+            return Xirr, totirr
 
-            ``inherited`` (class partials regrouped from the previous round) covers the regular region; otherwise the
-            regular region -- the first ``reg_blocks`` (a multiple of C) blocks -- is evaluated per residue class.  The
-            rest (further blocks + ragged tail) is one contiguous chunk, slot ``n - 1``.  ``defer_last``: the last
-            class and the irregular chunk are returned as ``late_fn`` instead of being launched (round 1: they run
+        def evaluate_block_sums(geo_, S_, defer_last=False):
+            """A fresh evaluation of one round's block sums -> ``(Xbuf [n, m_ext, S], totbuf [n, S], n, C, reg_blocks, late_fn)``.
+
+            C >= 2: the regular region -- the first ``reg_blocks`` (a multiple of C) blocks -- is summed per residue
+            class (slots 0..C-1), the rest (further blocks + ragged tail) is one contiguous chunk (slot C = n - 1).
+            C == 1 (small rounds, variants without class sums): plain contiguous chunks.  ``defer_last``: the last chunk
+            / class (and the irregular chunk) are returned as ``late_fn`` instead of being launched (round 1: they run
             behind the range finder's GPU work)."""
-            if inherited is not None:
-                C, reg_blocks = inherited["C"], inherited["reg_blocks"]
-                Xbuf, totbuf = inherited["X"], inherited["tot"]          # [C + 1, ...]: last slot reserved
-            else:
-                C = _classes_for(geo_.nb, m_ext, S_, kp // 4) if (use_classes and S_ == S) else 1
-                if C == 1:                                               # plain contiguous chunks (small rounds)
-                    n_ch = choose_chunks(local_blocks(off, Rl, geo_), m_ext, S_, kp // 4)
-                    Xbuf, totbuf = ops.empty(n_ch, m_ext, S_), ops.empty(n_ch, S_)
-                    p_split = _late_split(off, Rl, geo_.n_full, S_, n_ch, LATE_CHUNKS) if (defer_last and Rl > 0) else None
-                    if p_split is None:
-                        timed_blocksum(0, Rl, geo_, S_, n_ch, (Xbuf, totbuf))
-                        return Xbuf, totbuf, n_ch, 1, 0, None
-                    # the last chunk(s) are launched behind the range finder's GPU work; same chunk boundaries, same sums
-                    timed_blocksum(0, p_split, geo_, S_, n_ch - LATE_CHUNKS, (Xbuf[:n_ch - LATE_CHUNKS], totbuf[:n_ch - LATE_CHUNKS]))
-                    return (Xbuf, totbuf, n_ch, 1, 0,
-                            lambda: timed_blocksum(p_split, Rl, geo_, S_, LATE_CHUNKS, (Xbuf[n_ch - LATE_CHUNKS:], totbuf[n_ch - LATE_CHUNKS:])))
-                reg_blocks = (geo_.nb // C) * C
-                Xbuf, totbuf = ops.empty(C + 1, m_ext, S_), ops.empty(C + 1, S_)
+            C = _classes_for(geo_.nb, m_ext, S_, kp // 4) if (use_classes and S_ == S) else 1
+            if C == 1:
+                n_ch = choose_chunks(local_blocks(off, Rl, geo_), m_ext, S_, kp // 4)
+                Xbuf, totbuf = ops.empty(n_ch, m_ext, S_), ops.empty(n_ch, S_)
+                p_split = _late_split(off, Rl, geo_.n_full, S_, n_ch, LATE_CHUNKS) if (defer_last and Rl > 0) else None
+                if p_split is None:
+                    timed_blocksum(0, Rl, geo_, S_, n_ch, (Xbuf, totbuf))
+                    return Xbuf, totbuf, n_ch, 1, 0, None
+                # the last chunk(s) are launched behind the range finder's GPU work; same chunk boundaries, same sums
+                timed_blocksum(0, p_split, geo_, S_, n_ch - LATE_CHUNKS, (Xbuf[:n_ch - LATE_CHUNKS], totbuf[:n_ch - LATE_CHUNKS]))
+                return (Xbuf, totbuf, n_ch, 1, 0,
+                        lambda: timed_blocksum(p_split, Rl, geo_, S_, LATE_CHUNKS, (Xbuf[n_ch - LATE_CHUNKS:], totbuf[n_ch - LATE_CHUNKS:])))
+            reg_blocks = (geo_.nb // C) * C
+            Xbuf, totbuf = ops.empty(C + 1, m_ext, S_), ops.empty(C + 1, S_)
             reg_hi = min(max(reg_blocks * S_ - off, 0), Rl)              # local end of the regular region
             irregular = lambda: timed_blocksum(reg_hi, Rl, geo_, S_, 1, (Xbuf[C:C + 1], totbuf[C:C + 1]))   # noqa: E731
-            if inherited is not None:
-                irregular()
-                return Xbuf, totbuf, C + 1, C, reg_blocks, None
-            if defer_last and C >= 2:
+            if defer_last:
                 timed_blocksum(0, reg_hi, geo_, S_, C - 1, (Xbuf[:C - 1], totbuf[:C - 1]), class_mod=C, class0=0)
 
                 def late_fn():
@@ -652,7 +653,7 @@ class RecombinationEngine:
 
         if R > S and not opaque:
             geo = RoundGeometry.of(R, S)
-            pre = evaluate_block_sums(geo, S, None, defer_last=True)
+            pre = evaluate_block_sums(geo, S, defer_last=True)
             late = pre[5]
 
         # ---- Nystrom basis (one Gaussian draw on rank 0, as in the reference) ----------------------------
@@ -725,31 +726,49 @@ class RecombinationEngine:
             S_r = R if final else S
             geo = RoundGeometry.of(R, S_r)
             t0 = time.perf_counter()
-            C_cur, reg_blocks = 1, 0
+            C_cur, reg_blocks, msg, Mc = 1, 0, None, None
             if opaque:
                 with _Timer(ops, trace, "blocksum"):
                     Xpart, totpart = self._opaque_block_sums(kernel, pts_nys, cand, mu, Rl, off, geo.n_full, S_r, m)
                 n_chunks = 1
+            elif cls is not None and not final and S_r == S:
+                # inside an epoch: the class messages were regrouped from the previous round's; only the candidates they
+                # do not cover are evaluated (a few blocks + the ragged tail)
+                Mc, C_cur, reg_blocks = cls["M"], cls["C"], cls["reg_blocks"]
+                with _Timer(ops, trace, "blocksum"):
+                    Xirr, totirr = irregular_block_sums(geo, S_r, reg_blocks)
+                with _Timer(ops, trace, "project"):
+                    ops.project_chunks(U_ext, q_ext, m_ext, Xirr, totirr, 1, S_r, kscale, out=Mc[C_cur:C_cur + 1])
+                    msg = ops.sum_parts(Mc)
             else:
                 with _Timer(ops, trace, "blocksum"):
                     if pre is not None:
                         Xpart, totpart, n_chunks, C_cur, reg_blocks = pre[:5]
                         pre = None
                     else:
-                        Xpart, totpart, n_chunks, C_cur, reg_blocks, _ = evaluate_block_sums(
-                            geo, S_r, cls if (not final and S_r == S) else None)
-                cls = None
-            if sober and not final and geo.n_tail > 0:
-                # SOBER/_rchq.py:127-135: the remainder's kernel columns also go to sets 0..N_rest-1 (no weight added)
-                t0l = max(geo.n_full - off, 0)                   # first local tail position
-                if t0l < Rl:
-                    Xt, _ = ops.blocksum(spec, nys_ext, m_ext, cand[t0l:], mu[t0l:], None if wx is None else wx[t0l:],
-                                         Rl - t0l, off + t0l - geo.n_full, S_r, S_r, 1)
-                    Xpart = torch.cat([Xpart, Xt], 0)
-                    totpart = torch.cat([totpart, ops.zeros(1, S_r)], 0)
-                    n_chunks += 1
-            with _Timer(ops, trace, "project"):
-                msg = ops.project(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S_r, kscale)
+                        Xpart, totpart, n_chunks, C_cur, reg_blocks, _ = evaluate_block_sums(geo, S_r)
+                if C_cur >= 2:
+                    # start of an epoch: one message per residue class; the [m, S] partials are not needed again
+                    with _Timer(ops, trace, "project"):
+                        Mc = ops.project_chunks(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S_r, kscale)
+                        msg = ops.sum_parts(Mc)
+                    del Xpart, totpart
+            cls = None
+            if msg is None and not opaque:                       # plain rounds: chunk partials -> one projection
+                if sober and not final and geo.n_tail > 0:
+                    # SOBER/_rchq.py:127-135: the remainder's kernel columns also go to sets 0..N_rest-1 (no weight added)
+                    t0l = max(geo.n_full - off, 0)               # first local tail position
+                    if t0l < Rl:
+                        Xt, _ = ops.blocksum(spec, nys_ext, m_ext, cand[t0l:], mu[t0l:], None if wx is None else wx[t0l:],
+                                             Rl - t0l, off + t0l - geo.n_full, S_r, S_r, 1)
+                        Xpart = torch.cat([Xpart, Xt], 0)
+                        totpart = torch.cat([totpart, ops.zeros(1, S_r)], 0)
+                        n_chunks += 1
+                with _Timer(ops, trace, "project"):
+                    msg = ops.project(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S_r, kscale)
+            elif msg is None:
+                with _Timer(ops, trace, "project"):
+                    msg = ops.project(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S_r, kscale)
             if warp == "wsabim":
                 # + U @ (0.5 sum mu cov^2): the one term of wsabim_kernel that is not linear in the block sums
                 with _Timer(ops, trace, "wsabim_sq"):
@@ -842,13 +861,12 @@ class RecombinationEngine:
                 idx, w = gids[kept_t], w_star[:n_keep].clone()   # :69-73
                 break
             t0 = time.perf_counter()
-            if C_cur >= 2 and 2 * n_keep == S_r and status == 0:
-                # exactly half of the sets survived: the next round's class partials are a gather + rescale of this round's
+            if Mc is not None and C_cur >= 2 and 2 * n_keep == S_r and status == 0:
+                # exactly half of the sets survived: the next round's class messages are a gather + rescale of this round's
                 kept_dev = kept if (comm.world == 1 or replicate) else res[2:2 + M].to(torch.int32)
-                Xn, totn = ops.empty(C_cur // 2 + 1, m_ext, S_r), ops.empty(C_cur // 2 + 1, S_r)
-                ops.regroup_classes(Xpart[:C_cur], totpart[:C_cur], kept_dev, w_star, tot,
-                                    out=(Xn[:C_cur // 2], totn[:C_cur // 2]))
-                cls = dict(X=Xn, tot=totn, C=C_cur // 2, reg_blocks=reg_blocks // 2)
+                Mn = ops.empty(C_cur // 2 + 1, Mc.shape[1], S_r)
+                ops.regroup_classes(Mc[:C_cur], kept_dev, w_star, tot, out=Mn[:C_cur // 2])
+                cls = dict(M=Mn, C=C_cur // 2, reg_blocks=reg_blocks // 2)
             new_off, new_Rl = next_shard(off, Rl, geo, kept_list)
             cand, mu, gid, wx = ops.reweight_compact(cand, mu, gid, wx, Rl, off, geo.n_full, S_r, kp, keep_rank, w_star,
                                                      tot, n_keep, new_off, new_Rl)

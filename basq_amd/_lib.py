@@ -41,6 +41,8 @@ SIGNATURES = {
                                     _vp]),
     "basq_regroup_classes_f64": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "basq_project_f64": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _f64, _i32, _vp, _vp, _vp]),
+    "basq_project_chunks_f64": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _f64, _i32, _vp, _vp, _vp]),
+    "basq_sum_parts_f64": (C.c_int, [_vp, _i32, _i64, _vp, _vp]),
     "basq_finalize_f64": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _f64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "basq_nullspace_f64": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "basq_reduction_ws_doubles": (C.c_int64, [_i32, _i32]),

@@ -127,19 +127,38 @@ class HipOps:
                                          self._stream()), "basq_blocksum_f64")
         return Xpart, totpart
 
-    def regroup_classes(self, T, totT, kept, w_star, tot, out=None):
-        """Class partials of the next round from this round's (``basq_regroup_classes_f64``): ``T [C, m, S]``,
-        ``totT [C, S]`` -> ``([C/2, m, S], [C/2, S])`` (``out``: caller-provided contiguous slices).  ``kept`` int32
-        (first S/2 entries), ``w_star``, ``tot`` on the device."""
-        Cn, m, S = T.shape
-        assert T.is_contiguous() and totT.is_contiguous()
-        To, toto = out if out is not None else (self.empty(Cn // 2, m, S), self.empty(Cn // 2, S))
-        assert To.is_contiguous() and toto.is_contiguous() and tuple(To.shape) == (Cn // 2, m, S)
-        check(self.lib.basq_regroup_classes_f64(_ptr(T), m, S, Cn, _ptr(kept), _ptr(w_star), _ptr(tot), _ptr(To),
+    def regroup_classes(self, T, kept, w_star, tot, out=None):
+        """Class partials (or class messages) of the next round from this round's (``basq_regroup_classes_f64``):
+        ``T [C, rows, S]`` -> ``[C/2, rows, S]`` (``out``: a caller-provided contiguous slice).  ``kept`` int32 (first
+        S/2 entries), ``w_star``, ``tot`` on the device."""
+        Cn, rows, S = T.shape
+        assert T.is_contiguous()
+        To = out if out is not None else self.empty(Cn // 2, rows, S)
+        assert To.is_contiguous() and tuple(To.shape) == (Cn // 2, rows, S)
+        check(self.lib.basq_regroup_classes_f64(_ptr(T), rows, S, Cn, _ptr(kept), _ptr(w_star), _ptr(tot), _ptr(To),
                                                 self._stream()), "basq_regroup_classes_f64")
-        check(self.lib.basq_regroup_classes_f64(_ptr(totT), 1, S, Cn, _ptr(kept), _ptr(w_star), _ptr(tot), _ptr(toto),
-                                                self._stream()), "basq_regroup_classes_f64")
-        return To, toto
+        return To
+
+    def project_chunks(self, U, q, m, Xpart, totpart, n_chunks, S, outputscale, out=None, ksplit=None):
+        """Per-chunk messages ``[n_chunks, q + 1, S]``: row 0 = ``totpart[c]``, rows 1.. = ``outputscale * U @ Xpart[c]``."""
+        self._chk(U)
+        if ksplit is None:
+            ksplit = max(1, min(PROJECT_KSPLIT_MAX, m // 128))
+        work = self.empty(n_chunks * ksplit * q * S)
+        if out is None:
+            out = self.empty(n_chunks, q + 1, S)
+        assert out.is_contiguous() and tuple(out.shape) == (n_chunks, q + 1, S)
+        check(self.lib.basq_project_chunks_f64(_ptr(U), q, m, _ptr(Xpart), _ptr(totpart), n_chunks, S, float(outputscale),
+                                               ksplit, _ptr(work), _ptr(out), self._stream()), "basq_project_chunks_f64")
+        return out
+
+    def sum_parts(self, parts):
+        """``parts [n, ...] -> parts.sum(0)`` in index order."""
+        assert parts.is_contiguous()
+        out = self.empty(*parts.shape[1:])
+        check(self.lib.basq_sum_parts_f64(_ptr(parts), parts.shape[0], out.numel(), _ptr(out), self._stream()),
+              "basq_sum_parts_f64")
+        return out
 
     def project(self, U, q, m, Xpart, totpart, n_chunks, S, outputscale, ksplit=None):
         self._chk(U)

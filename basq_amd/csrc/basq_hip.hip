@@ -2899,6 +2899,61 @@ int basq_project_f64(const double* U, int32_t q, int32_t m, const double* Xpart,
     return BASQ_OK;
 }
 
+// out[c][0][s] = totpart[c][s];  out[c][1+r][s] = sum_z work[c * nz + z][r][s]   (fixed order)
+__global__ void project_chunks_reduce_kernel(const double* __restrict__ work, int nz, int q, int S,
+                                             const double* __restrict__ totpart, int n_chunks, double* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per = (long long)(q + 1) * S;
+    if (idx >= per * n_chunks) return;
+    const int c = (int)(idx / per);
+    const int e = (int)(idx - (long long)c * per);
+    const int r = e / S, s2 = e - r * S;
+    double v = 0.0;
+    if (r == 0) {
+        v = totpart[(long long)c * S + s2];
+    } else {
+        for (int z = 0; z < nz; ++z) v += work[(((long long)c * nz + z) * q + (r - 1)) * S + s2];
+    }
+    out[idx] = v;
+}
+
+__global__ void sum_parts_kernel(const double* __restrict__ parts, int n_parts, long long n, double* __restrict__ out) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    double v = parts[e];
+    for (int p = 1; p < n_parts; ++p) v += parts[(long long)p * n + e];
+    out[e] = v;
+}
+
+int basq_project_chunks_f64(const double* U, int32_t q, int32_t m, const double* Xpart, const double* totpart,
+                            int32_t n_chunks, int32_t S, double outputscale, int32_t ksplit, double* work, double* out,
+                            void* stream) {
+    if (!U || !Xpart || !totpart || !work || !out || q < 1 || m < 1 || S < 1 || n_chunks < 1 || ksplit < 1)
+        return BASQ_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    int kslice = (m + ksplit - 1) / ksplit;
+    kslice = ((kslice + 15) / 16) * 16;
+    const int nz = (m + kslice - 1) / kslice;          // <= ksplit slabs per chunk
+    if ((long long)n_chunks * nz > 65535) return BASQ_EINVAL;
+    dim3 grid((unsigned)((q + 15) / 16), (unsigned)((S + 63) / 64), (unsigned)(n_chunks * nz));
+    hipLaunchKernelGGL((gemm_kernel<1>), grid, dim3(256), 0, st, U, (long long)m, Xpart, (long long)S, 0LL, 1, work,
+                       (long long)S, (long long)q * S, q, S, m, kslice, outputscale, nz, (long long)m * S);
+    BASQ_CHECK_LAUNCH();
+    const long long tot = (long long)(q + 1) * S * n_chunks;
+    hipLaunchKernelGGL(project_chunks_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, work, nz, q, S,
+                       totpart, n_chunks, out);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_sum_parts_f64(const double* parts, int32_t n_parts, int64_t n, double* out, void* stream) {
+    if (!parts || !out || n_parts < 1 || n < 1) return BASQ_EINVAL;
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, parts, n_parts,
+                       (long long)n, out);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
 int basq_finalize_f64(const double* parts, int32_t n_parts, int32_t msg_rows, int32_t q, int32_t S,
                       const double* diagU, int64_t ld_diag, int32_t n_diag, double diag_noise, int32_t diag_wrow,
                       int32_t diag_tail_row, int32_t n_tail_diag, double* XcarT, double* tot_out, void* stream) {

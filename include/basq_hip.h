@@ -109,6 +109,18 @@ int basq_blocksum_f64(const basq_kernel_spec* spec, const double* nys, int32_t m
                       int32_t n_chunks, int32_t class_mod, int32_t class0, double* Xpart, double* totpart, void* stream);
 
 /*
+ * The same contraction per chunk -- out[c] = [ totpart[c] ; outputscale * U @ Xpart[c] ], c < n_chunks, each (q+1) x S --
+ * for residue-class chunks: the classes' MESSAGES (100 x 200 doubles each) are all the later rounds of an epoch need
+ * (basq_regroup_classes_f64 applies to them row by row), so the [m, S] class partials can be dropped right after this
+ * call.  work: n_chunks * nz * q * S doubles, nz = ceil(m / (16 ceil(ceil(m / ksplit) / 16))) <= ksplit.
+ * basq_sum_parts_f64: out[e] = sum_p parts[p][e] in index order (the round's message = the sum of its class messages).
+ */
+int basq_project_chunks_f64(const double* U, int32_t q, int32_t m, const double* Xpart, const double* totpart,
+                            int32_t n_chunks, int32_t S, double outputscale, int32_t ksplit, double* work, double* out,
+                            void* stream);
+int basq_sum_parts_f64(const double* parts, int32_t n_parts, int64_t n, double* out, void* stream);
+
+/*
  * Block sums of the next round WITHOUT evaluating the kernel again.  When a round keeps exactly n_keep = S/2 sets
  * (BASQ/_rchq.py:107-130), the survivor at (block b, kept set of rank k) moves to position b*S/2 + k: block b/2, set
  * (b % 2) * S/2 + k, and its weight is rescaled by w_star[k] / tot[kept[k]] (:113-114).  So with the sums of this round
@@ -116,9 +128,10 @@ int basq_blocksum_f64(const basq_kernel_spec* spec, const double* nys, int32_t m
  *     Tin[c][j][s] = sum over blocks b == c (mod C) of k(nys_j, x_{b,s}) mu_{b,s},
  * the next round's are a gather and a rescale:
  *     Tout[c'][j][par * S/2 + k] = (Tin[2c' + par][j][kept[k]] * w_star[k]) / tot[kept[k]],      c' < C/2, par in {0, 1}
- * -- half as many classes, so C classes pay for log2(C) rounds.  rows = rows of each [rows, S] class matrix (the caller
- * regroups the set weights, rows = 1, with a second call).  Valid for the blocks the classes cover; the caller evaluates
- * the few remaining candidates (blocks beyond a multiple of C, the ragged tail) directly.  C even, S even.
+ * -- half as many classes, so C classes pay for log2(C) rounds.  rows = rows of each [rows, S] class matrix: the map is
+ * linear, so it applies equally to the class MESSAGES [ tot ; U @ T ] of basq_project_chunks_f64 (rows = q + 1), which
+ * is how the engine uses it.  Valid for the blocks the classes cover; the caller evaluates the few remaining candidates
+ * (blocks beyond a multiple of C, the ragged tail) directly.  C even, S even.
  */
 int basq_regroup_classes_f64(const double* Tin, int32_t rows, int32_t S, int32_t C, const int32_t* kept,
                              const double* w_star, const double* tot, double* Tout, void* stream);

@@ -39,7 +39,7 @@ def sampled_batch_seconds(pts_rec, pts_nys, num_pts, kernel, stride: int = 8, dt
     try:
         # warm-up at this dtype / team size (first-use costs of MKL's thread team and LAPACK workspaces: ~1 s otherwise
         # lands in the Gram + svd_lowrank timer of the first cell)
-        nw = min(len(pts_rec), 4000)
+        nw = min(len(pts_rec), 1000)
         _run(pts_rec[:nw].to(dtype), pts_nys[:max(1, min(len(pts_nys), nw // 20))].to(dtype), num_pts, kernel, 1, None, None)
         res = _run(pts_rec.to(dtype), pts_nys.to(dtype), num_pts, kernel, max(1, int(stride)), loop_budget_s, give_up_above_s)
         res["threads"] = torch.get_num_threads()

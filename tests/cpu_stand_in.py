@@ -126,25 +126,32 @@ class CpuStandInOps:
         self._count("matvec")
         return bias + spec.outputscale * (self._kfun(spec, packA[:na] @ packB[:nb].T) @ v)
 
-    def regroup_classes(self, T, totT, kept, w_star, tot, out=None):
+    def regroup_classes(self, T, kept, w_star, tot, out=None):
         self._count("regroup")
-        Cn, m, S = T.shape
+        Cn, rows, S = T.shape
         H = S // 2
         kk = kept[:H].to(torch.int64)
-        scale_w, scale_t = w_star[:H], tot[kk]
-
-        def one(X):                                            # X [C, rows, S] -> [C/2, rows, S]
-            out = torch.empty(Cn // 2, X.shape[1], S, dtype=torch.float64)
-            for par in (0, 1):
-                out[:, :, par * H:(par + 1) * H] = (X[par::2][:, :, kk] * scale_w) / scale_t
-            return out
-
-        To, toto = one(T), one(totT.unsqueeze(1)).squeeze(1)
+        To = torch.empty(Cn // 2, rows, S, dtype=torch.float64)
+        for par in (0, 1):
+            To[:, :, par * H:(par + 1) * H] = (T[par::2][:, :, kk] * w_star[:H]) / tot[kk]
         if out is not None:
-            out[0].copy_(To)
-            out[1].copy_(toto)
+            out.copy_(To)
             return out
-        return To, toto
+        return To
+
+    def project_chunks(self, U, q, m, Xpart, totpart, n_chunks, S, outputscale, out=None, ksplit=None):
+        self._count("project_chunks")
+        M = torch.cat([totpart[:n_chunks].unsqueeze(1), outputscale * torch.matmul(U, Xpart[:n_chunks])], 1)
+        if out is not None:
+            out.copy_(M)
+            return out
+        return M
+
+    def sum_parts(self, parts):
+        out = parts[0].clone()
+        for p in range(1, parts.shape[0]):
+            out = out + parts[p]
+        return out
 
     def blocksum(self, spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, out=None, class_mod=0, class0=0):
         self._count("blocksum")

@@ -518,17 +518,36 @@ def test_blocksum_residue_classes_vs_standin(hip_ops, family, d, m, S, Rl, off, 
         assert (Xg.cpu().sum(0) - X1[0]).abs().max().item() <= 1e-12 * scale
 
 
-@pytest.mark.parametrize("C,m,S", [(8, 70, 200), (2, 33, 22), (16, 5, 400)])
-def test_regroup_classes_vs_standin(hip_ops, C, m, S):
+@pytest.mark.parametrize("C,rows,S", [(8, 70, 200), (2, 33, 22), (16, 100, 400)])
+def test_regroup_classes_vs_standin(hip_ops, C, rows, S):
     cpu = CpuStandInOps()
-    T, totT = _rand(C * m, S, 11).reshape(C, m, S).contiguous(), _rand(C, S, 12).abs() + 0.1
+    T = _rand(C * rows, S, 11).reshape(C, rows, S).contiguous()
     g = torch.Generator().manual_seed(3)
     kept = torch.sort(torch.randperm(S, generator=g)[: S // 2]).values.to(torch.int32)
     kept_full = torch.zeros(S, dtype=torch.int32)
     kept_full[: S // 2] = kept
     w_star = torch.rand(S, generator=g, dtype=torch.float64) + 0.01
     tot = torch.rand(S, generator=g, dtype=torch.float64) + 0.5
-    Tc, tc = cpu.regroup_classes(T, totT, kept_full, w_star, tot)
+    Tc = cpu.regroup_classes(T, kept_full, w_star, tot)
     dev = hip_ops.to_device
-    Tg, tg = hip_ops.regroup_classes(dev(T), dev(totT), dev(kept_full), dev(w_star), dev(tot))
-    assert torch.equal(Tg.cpu(), Tc) and torch.equal(tg.cpu(), tc)           # mul then div, same order: bit-exact
+    Tg = hip_ops.regroup_classes(dev(T), dev(kept_full), dev(w_star), dev(tot))
+    assert torch.equal(Tg.cpu(), Tc)                                          # mul then div, same order: bit-exact
+
+
+@pytest.mark.parametrize("q,m,S,n_chunks", [(99, 1000, 200, 17), (9, 50, 20, 3), (199, 333, 400, 5), (100, 10_000, 200, 2)])
+def test_project_chunks_and_sum_parts_vs_standin(hip_ops, q, m, S, n_chunks):
+    """Per-chunk messages [tot ; U @ X_c] (the class messages of an epoch) and their ordered sum = the plain projection."""
+    cpu = CpuStandInOps()
+    U = _rand(q, m, 21)
+    X = _rand(n_chunks * m, S, 22).reshape(n_chunks, m, S).contiguous()
+    t = _rand(n_chunks, S, 23).abs() + 0.1
+    Mc = cpu.project_chunks(U, q, m, X, t, n_chunks, S, 1.7)
+    dev = hip_ops.to_device
+    Mg = hip_ops.project_chunks(dev(U), q, m, dev(X), dev(t), n_chunks, S, 1.7)
+    scale = Mc.abs().max().item()
+    assert (Mg.cpu() - Mc).abs().max().item() <= 1e-12 * scale
+    assert torch.equal(Mg.cpu()[:, 0, :], t)
+    total = hip_ops.sum_parts(Mg).cpu()
+    plain = hip_ops.project(dev(U), q, m, dev(X), dev(t), n_chunks, S, 1.7).cpu()
+    assert (total - plain).abs().max().item() <= 1e-12 * scale
+    assert (total - cpu.sum_parts(Mc)).abs().max().item() <= 1e-12 * scale
