@@ -240,6 +240,7 @@ LATE_CHUNKS = 1                  # chunks of the round-1 block sums deferred beh
 # survivor of (block b, kept rank k) to (block b // 2, set (b % 2) * n + k), so the next round's sums -- again per class,
 # modulo C / 2 -- are a gather + rescale of this round's (``basq_regroup_classes_f64``): no candidate is touched.  Only
 # the blocks beyond a multiple of C and the ragged tail (< (C + 1) * S points, halving every round) are evaluated directly.
+BASIS_SIDE_STREAM = False        # one rank: range finder on a second stream beside the round-1 block sums (A/B on MI355X: 25.6 vs 24.6 ms -- off)
 CLASS_SUMS = True
 MAX_CLASSES = 16                 # classes at the start of an epoch (power of two): 16 -> the kernel runs in rounds 1, 6, 11
 
@@ -657,31 +658,21 @@ class RecombinationEngine:
             late = pre[5]
 
         # ---- Nystrom basis (one Gaussian draw on rank 0, as in the reference) ----------------------------
-        if SHARDED_BASIS and comm.world > 1 and not sober and not opaque:
-            # every rank builds its row block of the Gram matrix and takes part in the range finder (no broadcast of U)
-            shards = initial_shards(m, comm.world)
-            r0, mr = shards[comm.rank]
-            with _Timer(ops, trace, "basis.gram"):
-                A_rows = kernel.dense(ops, pts_nys[r0:r0 + mr].contiguous(), pts_nys, center, diag_offset=r0) \
-                    if mr else ops.zeros(0, m)
-            U = nystrom_basis(ops, _ShardedProducts(ops, comm, A_rows, shards, m), num_pts - 1, trace, overlap=late)
-            del A_rows
-        else:
-            if comm.rank == 0:
-                with _Timer(ops, trace, "basis.gram"):
-                    A = kernel.dense(ops, pts_nys, pts_nys, center)
-                    if sober:
-                        A = _make_cov_psd(A)
-                U = nystrom_basis(ops, A, num_pts - 1, trace, overlap=late)
-                del A
-                assert U.shape[0] == q
-            else:
-                U = ops.empty(q, m)
-                _skip_test_matrix_draw(ops, m, num_pts - 1)     # keep this rank's global generator in step with rank 0
-                if late is not None:
-                    late()                                      # runs while rank 0 finishes the basis
-            if comm.world > 1:
-                comm.broadcast(U)
+        # One rank: the range finder goes to a second stream.  Its ~2 ms of latency-bound steps (panel Cholesky,
+        # triangular solves, Box-Muller, the host's k x k SVD) then hide under the round-1 block sums instead of
+        # following them; the throughput-bound GEMMs simply share the chip.
+        import contextlib
+
+        two_streams = (BASIS_SIDE_STREAM and comm.world == 1 and hasattr(ops, "side_stream")
+                       and (trace is None or not (trace.host_sync or trace.time_kernels)))   # timed kernels run alone
+        if two_streams and late is not None:
+            late()                                              # nothing is deferred: everything overlaps anyway
+            late = None
+        basis_ctx = ops.side_stream() if two_streams else contextlib.nullcontext()
+        with basis_ctx as main_stream:
+            U = self._basis(ops, comm, kernel, pts_nys, center, m, q, num_pts, sober, opaque, late, trace)
+            if two_streams:
+                U.record_stream(main_stream)
         if trace is not None:
             if trace.host_sync:
                 ops.synchronize()
@@ -885,6 +876,33 @@ class RecombinationEngine:
         return idx, w
 
     # ------------------------------------------------------------------------------------------------
+    def _basis(self, ops, comm, kernel, pts_nys, center, m, q, num_pts, sober, opaque, late, trace):
+        """Nystrom Gram + range finder -> ``U [q, m]`` (identical on every rank)."""
+        if SHARDED_BASIS and comm.world > 1 and not sober and not opaque:
+            # every rank builds its row block of the Gram matrix and takes part in the range finder (no broadcast of U)
+            shards = initial_shards(m, comm.world)
+            r0, mr = shards[comm.rank]
+            with _Timer(ops, trace, "basis.gram"):
+                A_rows = kernel.dense(ops, pts_nys[r0:r0 + mr].contiguous(), pts_nys, center, diag_offset=r0) \
+                    if mr else ops.zeros(0, m)
+            return nystrom_basis(ops, _ShardedProducts(ops, comm, A_rows, shards, m), num_pts - 1, trace, overlap=late)
+        if comm.rank == 0:
+            with _Timer(ops, trace, "basis.gram"):
+                A = kernel.dense(ops, pts_nys, pts_nys, center)
+                if sober:
+                    A = _make_cov_psd(A)
+            U = nystrom_basis(ops, A, num_pts - 1, trace, overlap=late)
+            del A
+            assert U.shape[0] == q
+        else:
+            U = ops.empty(q, m)
+            _skip_test_matrix_draw(ops, m, num_pts - 1)         # keep this rank's global generator in step with rank 0
+            if late is not None:
+                late()                                          # runs while rank 0 finishes the basis
+        if comm.world > 1:
+            comm.broadcast(U)
+        return U
+
     def _opaque_block_sums(self, kernel, pts_nys, cand, mu, Rl, off, n_full, S, m):
         """Block sums of one round for an opaque callable: ``X_for_nys`` and ``tot_weights`` of ``_rchq.py:79-99`` as
         ``(Xpart [1, m, S], totpart [1, S])``, same layout as ``basq_blocksum_f64`` with one chunk.

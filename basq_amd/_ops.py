@@ -148,7 +148,7 @@ class HipOps:
         if out is None:
             out = self.empty(n_chunks, q + 1, S)
         assert out.is_contiguous() and tuple(out.shape) == (n_chunks, q + 1, S)
-        check(self.lib.basq_project_chunks_f64(_ptr(U), q, m, _ptr(Xpart), _ptr(totpart), n_chunks, S, float(outputscale),
+        check(self.lib.basq_project_chunks_f64(_ptr(self._transposed(U)), q, m, _ptr(Xpart), _ptr(totpart), n_chunks, S, float(outputscale),
                                                ksplit, _ptr(work), _ptr(out), self._stream()), "basq_project_chunks_f64")
         return out
 
@@ -160,13 +160,21 @@ class HipOps:
               "basq_sum_parts_f64")
         return out
 
+    def _transposed(self, U):
+        """``U.t().contiguous()``, cached per tensor: the contraction kernels read the basis transposed (``[m, q]``)."""
+        key = (U.data_ptr(), U._version, tuple(U.shape))
+        hit = self.__dict__.get("_ut_cache")
+        if hit is None or hit[0] != key:
+            hit = self.__dict__["_ut_cache"] = (key, U.t().contiguous(), U)      # keeps U alive: the pointer stays unique
+        return hit[1]
+
     def project(self, U, q, m, Xpart, totpart, n_chunks, S, outputscale, ksplit=None):
         self._chk(U)
         if ksplit is None:
             ksplit = max(1, min(PROJECT_KSPLIT_MAX, m // 128))
         work = self.empty((m * S if n_chunks > 1 else 0) + ksplit * q * S)
         out = self.empty(q + 1, S)
-        check(self.lib.basq_project_f64(_ptr(U), q, m, _ptr(Xpart), _ptr(totpart), n_chunks, S, float(outputscale),
+        check(self.lib.basq_project_f64(_ptr(self._transposed(U)), q, m, _ptr(Xpart), _ptr(totpart), n_chunks, S, float(outputscale),
                                         ksplit, _ptr(work), _ptr(out), self._stream()), "basq_project_f64")
         return out
 
@@ -352,6 +360,26 @@ class HipOps:
         buf = self._pinned(t.shape, t.dtype, tag)
         buf.copy_(t)
         return buf.to(self.device, non_blocking=True)
+
+    def side_stream(self):
+        """Context manager: work enqueued inside runs on a second HIP stream that starts behind everything already
+        enqueued on the current one; on exit the current stream waits for it.  Independent phases (the range finder
+        beside the round-1 block sums) then share the GPU instead of queueing behind each other."""
+        import contextlib
+
+        side = self.__dict__.get("_side_stream")
+        if side is None:
+            side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+
+        @contextlib.contextmanager
+        def ctx():
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                yield cur
+            cur.wait_stream(side)
+
+        return ctx()
 
     def synchronize(self):
         torch.cuda.current_stream(self.device).synchronize()

@@ -109,13 +109,13 @@ int basq_blocksum_f64(const basq_kernel_spec* spec, const double* nys, int32_t m
                       int32_t n_chunks, int32_t class_mod, int32_t class0, double* Xpart, double* totpart, void* stream);
 
 /*
- * The same contraction per chunk -- out[c] = [ totpart[c] ; outputscale * U @ Xpart[c] ], c < n_chunks, each (q+1) x S --
+ * The same contraction per chunk (Ut [m, q] as above) -- out[c] = [ totpart[c] ; outputscale * U @ Xpart[c] ], each (q+1) x S --
  * for residue-class chunks: the classes' MESSAGES (100 x 200 doubles each) are all the later rounds of an epoch need
  * (basq_regroup_classes_f64 applies to them row by row), so the [m, S] class partials can be dropped right after this
  * call.  work: n_chunks * nz * q * S doubles, nz = ceil(m / (16 ceil(ceil(m / ksplit) / 16))) <= ksplit.
  * basq_sum_parts_f64: out[e] = sum_p parts[p][e] in index order (the round's message = the sum of its class messages).
  */
-int basq_project_chunks_f64(const double* U, int32_t q, int32_t m, const double* Xpart, const double* totpart,
+int basq_project_chunks_f64(const double* Ut, int32_t q, int32_t m, const double* Xpart, const double* totpart,
                             int32_t n_chunks, int32_t S, double outputscale, int32_t ksplit, double* work, double* out,
                             void* stream);
 int basq_sum_parts_f64(const double* parts, int32_t n_parts, int64_t n, double* out, void* stream);
@@ -143,8 +143,10 @@ int basq_regroup_classes_f64(const double* Tin, int32_t rows, int32_t S, int32_t
  * (one streaming pass), then ONE GEMM split `ksplit` ways along K whose slabs are re-added in index order.
  * `work` holds (n_chunks > 1 ? m*S : 0) + ksplit*q*S doubles, 16-byte aligned; m*S must be even if n_chunks > 1.  `out` is [(q+1), S]: the per-rank message
  * of the multi-GPU all-gather; it is NOT yet divided by the set weights.
+ * The basis is passed TRANSPOSED: Ut [m, q] row-major (Ut[j][r] = U[r][j]) -- the MFMA row groups then read whole
+ * 128-byte lines of it (a 10x faster contraction than from the [q, m] layout; the caller transposes once per batch).
  */
-int basq_project_f64(const double* U, int32_t q, int32_t m, const double* Xpart, const double* totpart,
+int basq_project_f64(const double* Ut, int32_t q, int32_t m, const double* Xpart, const double* totpart,
                      int32_t n_chunks, int32_t S, double outputscale, int32_t ksplit, double* work, double* out,
                      void* stream);
 

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--family", default="rbf")
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--chunks", type=int, default=0)
+    ap.add_argument("--classes", type=int, default=16, help="residue classes of the block index (what round 1 of an "
+                    "epoch launches; 0 = contiguous chunks)")
     args = ap.parse_args()
     ops = HipOps("cuda:0")
     S = 2 * args.n
@@ -39,13 +41,18 @@ def main():
     out = {}
     impls = ("mfma",)
     for impl in impls:
-        nch = args.chunks or choose_chunks(local_blocks(0, args.R, geo), args.m, S, ops.kp(args.d) // 4)
-        X, t = ops.blocksum(spec, A, args.m, B, mu, None, args.R, 0, geo.n_full, S, nch)   # warm-up
+        cm = args.classes
+        if cm:
+            nch, Rr = cm, (geo.nb // cm) * cm * S          # the regular region: a multiple of cm full blocks
+        else:
+            nch, Rr = args.chunks or choose_chunks(local_blocks(0, args.R, geo), args.m, S, ops.kp(args.d) // 4), args.R
+        pairs = float(Rr) * args.m
+        X, t = ops.blocksum(spec, A, args.m, B, mu, None, Rr, 0, geo.n_full, S, nch, class_mod=cm)   # warm-up
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(args.reps):
-            X, t = ops.blocksum(spec, A, args.m, B, mu, None, args.R, 0, geo.n_full, S, nch)
+            X, t = ops.blocksum(spec, A, args.m, B, mu, None, Rr, 0, geo.n_full, S, nch, class_mod=cm)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps

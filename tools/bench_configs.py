@@ -23,7 +23,8 @@ def main():
     ap.add_argument("--only", default="")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    names = [a.only] if a.only else ["cfg2_rbf_1e5", "cfg3_rbf_1e6", "cfg4_matern52_1e6_d32", "cfg5_wsabil_5e5"]
+    names = [a.only] if a.only else ["cfg2_rbf_1e5", "cfg3_rbf_1e6", "cfg4_matern52_1e6_d32", "cfg5_wsabil_5e5",
+                                     "cfg5m_wsabim_5e5"]
     for name in names:
         c = BY_NAME[name]
         pts, nys = build_pool(c)
