@@ -303,7 +303,8 @@ __global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A) {
     // XCD-aware work-group -> tile map.  Work-groups are dealt round-robin over the 8 XCDs (blockIdx.x % 8), each with
     // its own 4-MB L2.  All row groups of one (set tile, chunk) pair read the SAME candidate slice (~0.5 MB at the
     // headline size), so they are given to ONE XCD, consecutively: the slice is fetched into that L2 once instead of
-    // once per row group (PMC: 1.7 GB -> see profiles/r02_traffic.json).  Placement only affects speed, never results.
+    // once per row group (PMC: 1.7 GB -> 94 MB per round-1 launch, profiles/r02_traffic.json).  Placement only affects
+    // speed, never results.
     const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
     const int jg = seq % A.n_jgroups;
     const int gidx = (seq / A.n_jgroups) * 8 + xcd;                 // (set tile, chunk) pair of this work-group
@@ -1016,22 +1017,6 @@ __device__ __forceinline__ double agent_load_f64(const double* p) {
     return __longlong_as_double((long long)__hip_atomic_load((basq_gu64*)p, BASQ_RLX_AGENT));
 }
 
-// 8-byte {tag, half} granules (MI355X_MICROARCH.md, visibility, R2: "the data IS the flag"): a double travels as two
-// naturally aligned 8-byte agent-scope stores, each carrying the 32-bit epoch of the step it belongs to; the consumer
-// re-reads until both tags match.  No flag, no vmcnt drain, no release: ONE fabric latency per hand-off instead of
-// three (payload drain -> flag -> gather).  Slot i of a granule buffer = words 2i, 2i+1.
-__device__ __forceinline__ void granule_store_f64(double* buf, int i, unsigned epoch, double v) {
-    const unsigned long long b = (unsigned long long)__double_as_longlong(v), tag = (unsigned long long)epoch << 32;
-    __hip_atomic_store((basq_gu64*)buf + 2 * i, tag | (b & 0xffffffffull), BASQ_RLX_AGENT);
-    __hip_atomic_store((basq_gu64*)buf + 2 * i + 1, tag | (b >> 32), BASQ_RLX_AGENT);
-}
-__device__ __forceinline__ bool granule_load_f64(const double* buf, int i, unsigned epoch, double& v) {
-    const unsigned long long lo = __hip_atomic_load((basq_gu64*)buf + 2 * i, BASQ_RLX_AGENT);
-    const unsigned long long hi = __hip_atomic_load((basq_gu64*)buf + 2 * i + 1, BASQ_RLX_AGENT);
-    v = __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32)));
-    return (unsigned)(lo >> 32) == epoch && (unsigned)(hi >> 32) == epoch;
-}
-
 __device__ __forceinline__ int wave_min_i32(int v) {
     const int BIG = 0x7fffffff;
     v = min(v, __builtin_amdgcn_update_dpp(BIG, v, 0x111, 0xf, 0xf, false));
@@ -1158,47 +1143,31 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) car_eliminate_cluster_kernel(co
         const int lane_j = (j & 127) >> 1;
         const double rphij = (j == 0x7fffffff) ? 0.0 : readlane_f64(brphi, lane_j);
         const double phij = (j == 0x7fffffff) ? 0.0 : readlane_f64(bphi, lane_j);
-        double* slot = ring + (size_t)(kp % D) * SLOT * (GLOBAL ? 2 : 1);
+        double* slot = ring + (size_t)(kp % D) * SLOT;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            if (GLOBAL) granule_store_f64(slot, BASQ_PAIRCOL(k), (unsigned)(kp + 1), r[k]);
+            if (GLOBAL) agent_store_f64(slot + BASQ_PAIRCOL(k), r[k]);
             else slot[BASQ_PAIRCOL(k)] = r[k];
         }
         if (lane < 4) {
             const double v = (lane == 0) ? wmin : (lane == 1) ? rphij : (lane == 2) ? phij : __longlong_as_double((long long)j);
-            if (GLOBAL) granule_store_f64(slot, NC + lane, (unsigned)(kp + 1), v);
+            if (GLOBAL) agent_store_f64(slot + NC + lane, v);
             else slot[NC + lane] = v;
         }
-        if (!GLOBAL) counter_publish<false>(count, kp + 1, lane);   // clusters: the tagged granules ARE the signal
+        counter_publish<GLOBAL>(count, kp + 1, lane);
     };
     if (nrows > 0 && gw == 0) test_and_publish(a[0], 0);
     int status = 0;
     for (int k = 0; k < nrows; ++k) {
-        const double* slot = ring + (size_t)(k % D) * SLOT * (GLOBAL ? 2 : 1);
-        double phi[NV], hdr[4];
-        if (GLOBAL) {
-            // sweep the pivot's granules until every tag carries this step's epoch (bounded: a timeout ends the kernel
-            // with status 2; every wave polls for itself, so no wave is left waiting for another)
-            unsigned spins = 0;
-            bool ok;
-            for (;;) {
-                ok = true;
+        const int seen = counter_wait_gt<GLOBAL>(count, k);
+        if (seen >= BASQ_ABORT_COUNT) { status = 2; break; }
+        const double* slot = ring + (size_t)(k % D) * SLOT;
+        double phi[NV];
 #pragma unroll
-                for (int kk = 0; kk < NV; ++kk) ok &= granule_load_f64(slot, BASQ_PAIRCOL(kk), (unsigned)(k + 1), phi[kk]);
+        for (int kk = 0; kk < NV; ++kk) phi[kk] = GLOBAL ? agent_load_f64(slot + BASQ_PAIRCOL(kk)) : slot[BASQ_PAIRCOL(kk)];
+        double hdr[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) ok &= granule_load_f64(slot, NC + u, (unsigned)(k + 1), hdr[u]);
-                if (__all(ok) || ++spins > BASQ_SPIN_LIMIT) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (!__all(ok)) { status = 2; break; }
-        } else {
-            const int seen = counter_wait_gt<false>(count, k);
-            if (seen >= BASQ_ABORT_COUNT) { status = 2; break; }
-#pragma unroll
-            for (int kk = 0; kk < NV; ++kk) phi[kk] = slot[BASQ_PAIRCOL(kk)];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) hdr[u] = slot[NC + u];
-        }
+        for (int u = 0; u < 4; ++u) hdr[u] = GLOBAL ? agent_load_f64(slot + NC + u) : slot[NC + u];
         const double aj = hdr[0], rphij = hdr[1], phij = hdr[2];
         const int j = __builtin_amdgcn_readfirstlane((int)__double_as_longlong(hdr[3]));
         if (j == 0x7fffffff) { status = 1; break; }               // uniform: no positive entry (the reference raises)
@@ -1786,11 +1755,11 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const dou
     const int gw = cu * WPG + wv;
     __shared__ __attribute__((aligned(16))) double wpart_l[2 * WPG * MSG];   // [parity][local wave]: partial row | ssp
     __shared__ __attribute__((aligned(16))) double r1_l[2 * MSG];          // [parity]: row t+1 after G_t | its column-t entry
-    __shared__ __attribute__((aligned(16))) double gsum_l[GLOBAL ? NCU * MSG : 2];   // clusters: the gathered work-group sums
-    __shared__ int abort_l[NCU + 1];
+    __shared__ int abort_l;
     // global (clusters): ws = [flags: NCU words in the first 128 B][2][NCU][MSG] work-group sums [2][MSG] row t+1
-    double* gsum = GLOBAL ? (ws + 16) : nullptr;                       // [2][NCU][2 MSG] granule words
-    double* gr1 = GLOBAL ? (gsum + 2 * NCU * 2 * MSG) : nullptr;       // [2][2 MSG]
+    unsigned* flags = (unsigned*)ws;
+    double* gsum = GLOBAL ? (ws + 16) : nullptr;
+    double* gr1 = GLOBAL ? (gsum + 2 * NCU * MSG) : nullptr;
 
     double a[NG * 4][NV], cprev[NG * 4];
 #pragma unroll
@@ -1811,7 +1780,7 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const dou
     for (int t = -1; t + 1 < m; ++t) {
         const int par = (t + 1) & 1;
         double* my_msg = wpart_l + (size_t)(par * WPG + wv) * MSG;
-        double* r1buf = GLOBAL ? (gr1 + (size_t)par * 2 * MSG) : (r1_l + (size_t)par * MSG);   // granule slots are 2 words
+        double* r1buf = GLOBAL ? (gr1 + (size_t)par * MSG) : (r1_l + (size_t)par * MSG);
         double pw[NV];
 #pragma unroll
         for (int k = 0; k < NV; ++k) pw[k] = 0.0;
@@ -1849,11 +1818,11 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const dou
                         if (r == t + 1) {
 #pragma unroll
                             for (int k = 0; k < NV; ++k) {
-                                if (GLOBAL) granule_store_f64(r1buf, BASQ_PAIRCOL(k), (unsigned)(t + 2), a[jr][k]);
+                                if (GLOBAL) agent_store_f64(r1buf + BASQ_PAIRCOL(k), a[jr][k]);
                                 else r1buf[BASQ_PAIRCOL(k)] = a[jr][k];
                             }
                             if (lane == 0) {
-                                if (GLOBAL) granule_store_f64(r1buf, NC, (unsigned)(t + 2), cr);
+                                if (GLOBAL) agent_store_f64(r1buf + NC, cr);
                                 else r1buf[NC] = cr;
                             }
                         } else {
@@ -1867,16 +1836,16 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const dou
         } else if (gw == 0) {   // prologue: row 0 as it stands is "row t+1"
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
-                if (GLOBAL) granule_store_f64(r1buf, BASQ_PAIRCOL(k), (unsigned)(t + 2), a[0][k]);
+                if (GLOBAL) agent_store_f64(r1buf + BASQ_PAIRCOL(k), a[0][k]);
                 else r1buf[BASQ_PAIRCOL(k)] = a[0][k];
             }
-            if (GLOBAL && lane == 0) granule_store_f64(r1buf, NC, (unsigned)(t + 2), 0.0);
         }
 #pragma unroll
         for (int h = 0; h < NV / 2; ++h)
             *reinterpret_cast<d2_t*>(my_msg + 2 * lane + 128 * h) = (d2_t){pw[2 * h], pw[2 * h + 1]};
         if (lane == 0) my_msg[NC] = ssp;
         BASQ_NS_STAMP(t + 1, 1);
+        if (GLOBAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the owner's row stores have left the CU
         __syncthreads();
         BASQ_NS_STAMP(t + 1, 2);
         // ---- chain (every wave) ----
@@ -1903,56 +1872,60 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const dou
             // for every work-group's flag, gathers the sums in cluster order and the published row t+1, and hands the
             // result to its seven sibling waves through LDS -- 20 KB of fabric traffic per CU and step instead of 160 KB.
             const unsigned epoch = (unsigned)(t + 2);
-            double* mine = gsum + (size_t)(par * NCU + cu) * 2 * MSG;
+            double* mine = gsum + (size_t)(par * NCU + cu) * MSG;
+            double* tot_l = wpart_l + (size_t)(par * WPG) * MSG;    // this parity's first partial slot: free after the sum above
             if (wv == 0) {
 #pragma unroll
-                for (int k = 0; k < NV; ++k) granule_store_f64(mine, BASQ_PAIRCOL(k), epoch, accs[k]);
-                if (lane == 0) granule_store_f64(mine, NC, epoch, ss2);
-            }
-            // the gathers are spread over the waves (wave c2 sweeps work-group c2's sum, wave NCU the published row): all
-            // fabric round trips run side by side and no wave needs more than NV extra registers.  A sweep re-reads
-            // its granules until every tag carries this step's epoch; bounded, the verdict goes through LDS.
-            if (wv <= NCU) {
-                const double* src = (wv < NCU) ? (gsum + (size_t)(par * NCU + wv) * 2 * MSG) : r1buf;
-                double* dst = (wv < NCU) ? (gsum_l + (size_t)wv * MSG) : (r1_l + (size_t)par * MSG);
-                double got[NV], gx = 0.0;
+                for (int k = 0; k < NV; ++k) agent_store_f64(mine + BASQ_PAIRCOL(k), accs[k]);
+                if (lane == 0) agent_store_f64(mine + NC, ss2);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store((basq_gu32*)(flags + cu), epoch, BASQ_RLX_AGENT);
                 unsigned spins = 0;
-                bool ok;
+                bool bad = false;
                 for (;;) {
-                    ok = true;
-#pragma unroll
-                    for (int k = 0; k < NV; ++k) ok &= granule_load_f64(src, BASQ_PAIRCOL(k), epoch, got[k]);
-                    ok &= granule_load_f64(src, NC, epoch, gx);
-                    if (__all(ok) || ++spins > BASQ_SPIN_LIMIT) break;   // the limit is never reached in a healthy run
+                    const unsigned f = (lane < NCU) ? __hip_atomic_load((basq_gu32*)(flags + lane), BASQ_RLX_AGENT) : epoch;
+                    if (__all(f >= epoch)) { bad = __any(f >= (unsigned)BASQ_ABORT_COUNT); break; }
+                    if (++spins > BASQ_SPIN_LIMIT) {                // never in a healthy run: abort the whole cluster
+                        if (lane == 0) __hip_atomic_store((basq_gu32*)(flags + cu), (unsigned)BASQ_ABORT_COUNT, BASQ_RLX_AGENT);
+                        bad = true;
+                        break;
+                    }
                     __builtin_amdgcn_s_sleep(1);
                 }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: the gathers stay below the poll
+                double tot[NV], sst = 0.0;
 #pragma unroll
-                for (int h = 0; h < NV / 2; ++h)
-                    *reinterpret_cast<d2_t*>(dst + 2 * lane + 128 * h) = (d2_t){got[2 * h], got[2 * h + 1]};
-                if (lane == 0) {
-                    dst[NC] = gx;
-                    abort_l[wv] = __all(ok) ? 0 : 1;
+                for (int k = 0; k < NV; ++k) tot[k] = 0.0;
+                if (!bad) {
+#pragma unroll
+                    for (int c2 = 0; c2 < NCU; ++c2) {              // cluster order: every work-group forms the same sum
+                        const double* src = gsum + (size_t)(par * NCU + c2) * MSG;
+#pragma unroll
+                        for (int k = 0; k < NV; ++k) tot[k] += agent_load_f64(src + BASQ_PAIRCOL(k));
+                        sst += agent_load_f64(src + NC);
+                    }
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) {
+                        tot_l[BASQ_PAIRCOL(k)] = tot[k];
+                        r1_l[(size_t)par * MSG + BASQ_PAIRCOL(k)] = agent_load_f64(r1buf + BASQ_PAIRCOL(k));
+                    }
+                    if (lane == 0) {
+                        tot_l[NC] = sst;
+                        r1_l[(size_t)par * MSG + NC] = agent_load_f64(r1buf + NC);
+                    }
                 }
+                if (lane == 0) abort_l = bad ? 1 : 0;
             }
-            __syncthreads();                                        // gathered data + verdicts: work-group uniform
-            aborted = false;
-#pragma unroll
-            for (int w = 0; w <= NCU; ++w) aborted |= abort_l[w] != 0;
+            __syncthreads();                                        // wave 0's verdict and gathered data: work-group uniform
+            aborted = abort_l != 0;
             if (aborted) break;                                     // no wave is left behind at a barrier
-            ss2 = 0.0;
 #pragma unroll
-            for (int k = 0; k < NV; ++k) accs[k] = 0.0;
-#pragma unroll
-            for (int c2 = 0; c2 < NCU; ++c2) {                      // cluster order: every work-group forms the same sum
-                const double* src = gsum_l + (size_t)c2 * MSG;
-#pragma unroll
-                for (int h = 0; h < NV / 2; ++h) {
-                    const d2_t v = *reinterpret_cast<const d2_t*>(src + 2 * lane + 128 * h);
-                    accs[2 * h] += v.x;
-                    accs[2 * h + 1] += v.y;
-                }
-                ss2 += src[NC];
+            for (int h = 0; h < NV / 2; ++h) {
+                const d2_t v = *reinterpret_cast<const d2_t*>(tot_l + 2 * lane + 128 * h);
+                accs[2 * h] = v.x;
+                accs[2 * h + 1] = v.y;
             }
+            ss2 = tot_l[NC];
         }
         {
             const double* r1src = r1_l + (size_t)par * MSG;          // clusters: wave 0's copy of the published row
@@ -3008,7 +2981,7 @@ int basq_finalize_f64(const double* parts, int32_t n_parts, int32_t msg_rows, in
 }
 
 // workspace (doubles) of the cluster kernels for an [s, M] reduction: 16 counter/flag words + the message ring
-static inline size_t cluster_ws_doubles(int nv, int ncu) { return 16 + (size_t)(2 * BASQ_WPG * ncu) * 2 * (nv * 64 + 8); }
+static inline size_t cluster_ws_doubles(int nv, int ncu) { return 16 + (size_t)(2 * BASQ_WPG * ncu) * (nv * 64 + 8); }
 
 #ifndef BASQ_CAR_CLUSTER
 #define BASQ_CAR_CLUSTER 1      // 1: cluster kernels where the null vectors do not fit one CU's LDS; 2: also where they do
@@ -3042,8 +3015,7 @@ int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32
         return BASQ_OK;
     }
     if (nrows >= 1 && !fits_lds && M <= 512 && nrows <= 4 * BASQ_WPG * 8 && ws) {   // 4-CU cluster (n = 200: M = 400)
-        // every tag of the granule ring must be stale before the launch (a tag left by an earlier launch could pass)
-        if (hipMemsetAsync(ws, 0, cluster_ws_doubles(8, 4) * sizeof(double), st) != hipSuccess) return BASQ_ELAUNCH;
+        if (hipMemsetAsync(ws, 0, 16 * sizeof(double), st) != hipSuccess) return BASQ_ELAUNCH;
         hipLaunchKernelGGL((car_eliminate_cluster_kernel<8, 8, 4>), dim3(4 * 8), dim3(T), 0, st, PhiT, mu, M, s,
                            keep_rank, kept, w_star, info, ws, 8);
         BASQ_CHECK_LAUNCH();
@@ -3087,8 +3059,7 @@ int basq_nullspace_f64(const double* X, int32_t s, int32_t M, double* V, double*
         else hipLaunchKernelGGL((bidiag_cluster_kernel<4, 14, 1>), dim3(1), dim3(T), 0, st, X, s, M, V, tau, (double*)nullptr, 1);
         rc = (hipGetLastError() == hipSuccess) ? BASQ_OK : BASQ_ELAUNCH;
     } else if (BASQ_NS_CLUSTER && !(M <= 256 && s <= 112) && M <= 512 && s <= 4 * BASQ_WPG * 8 && ws) {   // 4-CU cluster
-        if (hipMemsetAsync(ws, 0, (16 + (size_t)(2 * 4 + 2) * 2 * (8 * 64 + 8)) * sizeof(double), st) != hipSuccess)
-            return BASQ_ELAUNCH;                                 // flag words + every granule tag of its message area
+        if (hipMemsetAsync(ws, 0, 16 * sizeof(double), st) != hipSuccess) return BASQ_ELAUNCH;
         hipLaunchKernelGGL((bidiag_cluster_kernel<8, 8, 4>), dim3(4 * 8), dim3(T), 0, st, X, s, M, V, tau, ws, 8);
         rc = (hipGetLastError() == hipSuccess) ? BASQ_OK : BASQ_ELAUNCH;
     } else if (M <= 256 && s <= 112) {                          // whole matrix in registers (16 waves)

@@ -34,7 +34,8 @@ PEAK_FP64_VECTOR_TFLOPS = 78.6      # MI355X nominal: 256 CU x 128 flop/clk x 2.
 # What the part sustains in a register-only micro-benchmark (tools/microbench.hip, profiles/r02_microbench_fp64_rates.txt,
 # 4 waves/SIMD, in-kernel clock 2.32-2.39 GHz): v_fma_f64 only 72.9 TF/s (4.2 cycles per wave instruction),
 # v_mfma_f64_16x16x4 only 47.2 TF/s (one issue per 106 cycles), the two interleaved 63.1 TF/s (they do not overlap).
-# The block-sum kernel's default form is all-VALU, so 72.9 is its practical ceiling; ``frac`` stays against the nominal figure.
+# The block-sum kernel issues BOTH (MFMA distances + VALU exponentials: 83 + 60 of its 143 cycles per 64 pairs), so the mixed
+# figure is its practical ceiling; ``frac`` stays against the nominal figure.
 MEASURED_FP64_TFLOPS = {"fma_only": 72.9, "mfma_only": 47.2, "mixed_fma_mfma": 63.1}
 PEAK_HBM_GBS = 8000.0
 POOL_SEEDS = (0, 1, 2, 3, 4)        # seeds 0-4, median
@@ -150,7 +151,7 @@ def main():
     # HBM bytes of the largest block-sum launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE in separate runs, KiB units; 8-B-per-lane loads, so the gfx950 16-B half-count does not apply)
     traffic, traffic_src, pipe_busy = None, None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    pmc = os.path.join(ROOT, "profiles", "r02_traffic.json")
     if os.path.exists(pmc) and N == WORKLOAD["N"] and d == WORKLOAD["d"] and world == 1:
         with open(pmc) as f:
             rec = json.load(f)
