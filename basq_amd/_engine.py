@@ -476,6 +476,18 @@ class RecombinationEngine:
     # ------------------------------------------------------------------------------------------------
     def run(self, pts_local, gid0: int, n_total: int, pts_nys, num_pts: int, kernel, trace: EngineTrace | None = None,
             variant: str = "basq", init_weights=None, objective=None):
+        """One recombination batch (see ``_run``); the launch stream is looked up once for the whole batch."""
+        pin = getattr(self.ops, "pin_stream", None)
+        if pin is None:
+            return self._run(pts_local, gid0, n_total, pts_nys, num_pts, kernel, trace, variant, init_weights, objective)
+        pin()
+        try:
+            return self._run(pts_local, gid0, n_total, pts_nys, num_pts, kernel, trace, variant, init_weights, objective)
+        finally:
+            self.ops.unpin_stream()
+
+    def _run(self, pts_local, gid0: int, n_total: int, pts_nys, num_pts: int, kernel, trace: EngineTrace | None = None,
+             variant: str = "basq", init_weights=None, objective=None):
         """Recombine.  ``pts_local`` = this rank's contiguous slice ``[gid0, gid0 + len)`` of the pool.
 
         ``variant="basq"`` follows ``BASQ/_rchq.py`` (uniform start weights, ``init_weights`` ignored);
@@ -553,7 +565,6 @@ class RecombinationEngine:
 
         # ---- candidate state ---------------------------------------------------------------------------
         cand = (pts_local if Rl > 0 else ops.zeros(1, d)) if opaque else ops.pack(spec, pts_local, center, ROLE_B)
-        cand_raw = pts_local if warp == "wsabim" else None      # WSABI-M needs dense kernel blocks of the survivors
         mu, gid = ops.init_state(Rl, gid0, n_total)
         wx = None
         if warp != "none":
@@ -579,8 +590,6 @@ class RecombinationEngine:
                 obj_live = obj_live[nz].contiguous()
             if wx is not None:
                 wx = wx[nz].contiguous()
-            if cand_raw is not None:
-                cand_raw = cand_raw[nz].contiguous()
             Rl = int(nz.numel())
             counts = torch.tensor([float(Rl)], dtype=torch.float64, device=mu.device)
             if comm.world > 1:
@@ -690,6 +699,10 @@ class RecombinationEngine:
             W = ops.to_device(post.W, torch.float64)
             Bmat = base.dense(ops, pts_nys, Xo, center) @ W      # [m, n_obs] (small rocBLAS GEMM)
             U_cols.append(-(Um @ Bmat))
+            if warp == "wsabim":
+                # B^T, zero-padded to whole MFMA fragments: the A operand of the fused squared-covariance block sums
+                bmatT = ops.zeros(((n_obs + 3) // 4) * 4, ((m + 63) // 64) * 64)
+                bmatT[:n_obs, :m] = Bmat.t()
         U_ext = torch.cat(U_cols, 1) if len(U_cols) > 1 else Um
         if wrow:
             sel = ops.zeros(1, m_ext)
@@ -718,6 +731,9 @@ class RecombinationEngine:
             geo = RoundGeometry.of(R, S_r)
             t0 = time.perf_counter()
             C_cur, reg_blocks, msg, Mc = 1, 0, None, None
+            # One rank, no extra message row: the class messages go to the finalize kernel as they are -- it adds its
+            # parts in index order, which is exactly the sum a separate launch would have formed first.
+            sum_classes_here = comm.world > 1 or (diag_noise != 0.0 and geo.n_tail > 0)
             if opaque:
                 with _Timer(ops, trace, "blocksum"):
                     Xpart, totpart = self._opaque_block_sums(kernel, pts_nys, cand, mu, Rl, off, geo.n_full, S_r, m)
@@ -730,7 +746,7 @@ class RecombinationEngine:
                     Xirr, totirr = irregular_block_sums(geo, S_r, reg_blocks)
                 with _Timer(ops, trace, "project"):
                     ops.project_chunks(U_ext, q_ext, m_ext, Xirr, totirr, 1, S_r, kscale, out=Mc[C_cur:C_cur + 1])
-                    msg = ops.sum_parts(Mc)
+                    msg = ops.sum_parts(Mc) if sum_classes_here else Mc
             else:
                 with _Timer(ops, trace, "blocksum"):
                     if pre is not None:
@@ -742,7 +758,7 @@ class RecombinationEngine:
                     # start of an epoch: one message per residue class; the [m, S] partials are not needed again
                     with _Timer(ops, trace, "project"):
                         Mc = ops.project_chunks(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S_r, kscale)
-                        msg = ops.sum_parts(Mc)
+                        msg = ops.sum_parts(Mc) if sum_classes_here else Mc
                     del Xpart, totpart
             cls = None
             if msg is None and not opaque:                       # plain rounds: chunk partials -> one projection
@@ -763,8 +779,7 @@ class RecombinationEngine:
             if warp == "wsabim":
                 # + U @ (0.5 sum mu cov^2): the one term of wsabim_kernel that is not linear in the block sums
                 with _Timer(ops, trace, "wsabim_sq"):
-                    E = self._wsabim_square_term(base, spec, pts_nys, Xo, Bmat, center, cand_raw, mu, Rl, off,
-                                                 geo.n_full, S_r, m, diag_noise)
+                    E = self._wsabim_square_term(spec, nys_ext, m, n_obs, bmatT, cand, mu, Rl, off, geo, S_r, diag_noise, kp)
                     msg[1:q + 1] += ops.matmul(U, E)
             tail_row, n_tail_diag = 0, 0
             if diag_noise != 0.0 and not final and geo.n_tail > 0:
@@ -787,11 +802,11 @@ class RecombinationEngine:
                 # every other message row); the reduction then keeps q + 2 points and the thinning removes one more
                 idx, w = self._reduce_with_objective(msg, obj_live, obj_full, gid, mu, Rl, R, q, trace)
                 break
-            parts = comm.all_gather(msg) if comm.world > 1 else msg.unsqueeze(0)
+            parts = comm.all_gather(msg) if comm.world > 1 else (msg if msg.dim() == 3 else msg.unsqueeze(0))
             M = S_r
             replicate = REPLICATED_REDUCTION and comm.world > 1
             if comm.rank == 0 or replicate:
-                XcarT, tot = ops.finalize(parts, comm.world, parts.shape[1], q, S_r, diagU, m, min(m, S_r), diag_noise, wrow,
+                XcarT, tot = ops.finalize(parts, parts.shape[0], parts.shape[1], q, S_r, diagU, m, min(m, S_r), diag_noise, wrow,
                                           tail_row, n_tail_diag)
                 if GPU_NULLSPACE:
                     with _Timer(ops, trace, "nullspace"):
@@ -807,6 +822,13 @@ class RecombinationEngine:
                 mu_car = tot.clone()
                 with _Timer(ops, trace, "eliminate"):
                     keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, mu_car, M, s)
+            Mn = None
+            if Mc is not None and C_cur >= 2 and not final and (comm.world == 1 or replicate):
+                # Enqueued BEFORE the host waits for this round's outcome: if exactly half of the sets survive (checked
+                # below), the next round's class messages are a gather + rescale of this round's; otherwise the result
+                # is dropped (the kernel tolerates a short survivor list).
+                Mn = ops.empty(C_cur // 2 + 1, Mc.shape[1], S_r)
+                ops.regroup_classes(Mc[:C_cur], kept, w_star, tot, out=Mn[:C_cur // 2])
             if comm.world > 1 and not replicate:
                 # one broadcast of the (tiny) reduction result: info | kept | w_star | keep_rank | tot
                 res = ops.empty(2 + 4 * M)
@@ -854,15 +876,13 @@ class RecombinationEngine:
             t0 = time.perf_counter()
             if Mc is not None and C_cur >= 2 and 2 * n_keep == S_r and status == 0:
                 # exactly half of the sets survived: the next round's class messages are a gather + rescale of this round's
-                kept_dev = kept if (comm.world == 1 or replicate) else res[2:2 + M].to(torch.int32)
-                Mn = ops.empty(C_cur // 2 + 1, Mc.shape[1], S_r)
-                ops.regroup_classes(Mc[:C_cur], kept_dev, w_star, tot, out=Mn[:C_cur // 2])
+                if Mn is None:
+                    Mn = ops.empty(C_cur // 2 + 1, Mc.shape[1], S_r)
+                    ops.regroup_classes(Mc[:C_cur], res[2:2 + M].to(torch.int32), w_star, tot, out=Mn[:C_cur // 2])
                 cls = dict(M=Mn, C=C_cur // 2, reg_blocks=reg_blocks // 2)
             new_off, new_Rl = next_shard(off, Rl, geo, kept_list)
             cand, mu, gid, wx = ops.reweight_compact(cand, mu, gid, wx, Rl, off, geo.n_full, S_r, kp, keep_rank, w_star,
                                                      tot, n_keep, new_off, new_Rl)
-            if cand_raw is not None:
-                cand_raw = pts_local[(gid[:new_Rl] - gid0)]
             R = survivors_before(R, geo, kept_list)
             off, Rl = new_off, new_Rl
             if trace is not None:
@@ -985,35 +1005,25 @@ class RecombinationEngine:
         gids = gid[:Rl]
         return gids[kept_pos.to(gids.device)], ops.to_device(w_host)
 
-    def _wsabim_square_term(self, base, spec, pts_nys, Xo, Bmat, center, cand_raw, mu, Rl, off, n_full, S, m,
-                            diag_noise=0.0, chunk_bytes=256 << 20):
+    def _wsabim_square_term(self, spec, nys_ext, m, n_obs, bmatT, cand, mu, Rl, off, geo, S, diag_noise, kp):
         """E[j, s] = 0.5 * sum_{p in set s} mu_p * cov(pt_j, x_p)^2  with cov = k - K(pt,X) W K(X, x)  (_wsabi.py:240).
 
         ``cov`` is ``predictive_covariance``, which carries the likelihood noise on entry [k][k] of every block the
         reference builds: candidate p of a full block meets Nystrom row ``p mod S``, tail point k meets row k.
 
-        Dense in chunks of candidates: two HIP Gram blocks, one rocBLAS GEMM for the posterior correction and the
-        HIP squared block sum; the chunk partials are accumulated in position order (fixed summation order).
+        Fused: one Gram launch for ``K(X, x_p)`` of the live candidates ([n_obs, Rl], the only per-candidate array),
+        then ``basq_blocksum_sq_f64`` evaluates k, subtracts the correction (a second MFMA chain over the observations),
+        squares and accumulates in registers -- no [m, candidates] covariance block exists.
         """
         ops = self.ops
-        E = ops.zeros(m, S)
         if Rl == 0:
-            return E
-        nc_max = max(S, min(Rl, chunk_bytes // (8 * m)))
-        pa = ops.pack(spec, pts_nys, center, ROLE_A)
-        po = ops.pack(spec, Xo, center, ROLE_A)
-        for p0 in range(0, Rl, nc_max):
-            nc = min(nc_max, Rl - p0)
-            pb = ops.pack(spec, cand_raw[p0:p0 + nc].contiguous(), center, ROLE_B)
-            cov = ops.gram(spec, pa, m, pb, nc)
-            cov -= Bmat @ ops.gram(spec, po, Xo.shape[0], pb, nc)
-            if diag_noise != 0.0:
-                pg = off + p0 + torch.arange(nc, device=cov.device)
-                kappa = torch.where(pg < n_full, pg % S, pg - n_full)
-                hit = kappa < m
-                cov[kappa[hit], torch.arange(nc, device=cov.device)[hit]] += diag_noise
-            ops.dense_blocksum(cov, mu[p0:p0 + nc], off + p0, n_full, S, 0.5, E, square=True)
-        return E
+            return ops.zeros(m, S)
+        n4 = bmatT.shape[0]
+        kobs = ops.zeros(n4, Rl) if n4 != n_obs else ops.empty(n4, Rl)
+        ops.gram_into(spec, nys_ext[m:m + n_obs], n_obs, cand, Rl, kobs)      # rows m.. of nys_ext = packed observations
+        n_ch = choose_chunks(local_blocks(off, Rl, geo), m, S, kp // 4)
+        Epart = ops.blocksum_sq(spec, nys_ext, m, cand, mu, Rl, off, geo.n_full, S, n_ch, bmatT, kobs, n_obs, diag_noise)
+        return Epart[0] if n_ch == 1 else Epart.sum(0)
 
     # ------------------------------------------------------------------------------------------------
     def _gather_survivors(self, gid, mu, Rl, R, off, cap):

@@ -41,7 +41,16 @@ class HipOps:
 
     # -- helpers -----------------------------------------------------------------------------
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        s = self.__dict__.get("_pinned_stream")
+        return s if s is not None else C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def pin_stream(self):
+        """Look the current stream up ONCE for a whole batch (the engine launches ~250 kernels per batch and the lookup
+        costs more than the launch); ``unpin_stream`` restores the per-call lookup."""
+        self._pinned_stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def unpin_stream(self):
+        self._pinned_stream = None
 
     def _chk(self, t, dtype=torch.float64):
         if t.device != self.device and not (t.device.type == "cuda" and t.device.index == self.device.index):
@@ -254,6 +263,30 @@ class HipOps:
                                                float(scale), 1 if square else 0, _ptr(E), self._stream()),
               "basq_dense_blocksum_f64")
 
+    def blocksum_sq(self, spec, nys, m, cand, mu, Rl, off, n_full, S, n_chunks, bmatT, kobs, n_obs, noise):
+        """WSABI-M's squared-covariance block sums, fused (``basq_blocksum_sq_f64``) -> ``Epart [n_chunks, m, S]``.
+
+        ``bmatT [n_obs4, >= m padded to 64]``, ``kobs [n_obs4, >= Rl]`` (zero rows beyond ``n_obs``)."""
+        self._chk(bmatT)
+        self._chk(kobs)
+        Epart = self.empty(n_chunks, m, S)
+        if Rl == 0:
+            return Epart.zero_()
+        sc = self.spec_c(spec)
+        check(self.lib.basq_blocksum_sq_f64(C.byref(sc), _ptr(nys), m, _ptr(cand), _ptr(mu), Rl, off, n_full, S, n_chunks,
+                                            _ptr(bmatT), bmatT.stride(0), _ptr(kobs), kobs.stride(0), int(n_obs),
+                                            float(noise), _ptr(Epart), self._stream()), "basq_blocksum_sq_f64")
+        return Epart
+
+    def gram_into(self, spec, packA, na, packB, nb, out):
+        """``out[:na, :nb] = outputscale * k(A, B)`` for a caller-provided row-major buffer (row stride ``out.stride(0)``)."""
+        self._chk(out)
+        assert out.stride(1) == 1 and out.shape[0] >= na and out.shape[1] >= nb
+        sc = self.spec_c(spec)
+        check(self.lib.basq_gram_f64(C.byref(sc), _ptr(packA), na, _ptr(packB), nb, _ptr(out), out.stride(0), self._stream()),
+              "basq_gram_f64")
+        return out
+
     def box_muller(self, u, u_tail=None):
         """Normals from torch's uniforms (see basq_box_muller_f64); u on the device, n >= 16."""
         self._chk(u)
@@ -375,8 +408,15 @@ class HipOps:
         @contextlib.contextmanager
         def ctx():
             side.wait_stream(cur)
+            pinned = self.__dict__.get("_pinned_stream")
             with torch.cuda.stream(side):
-                yield cur
+                if pinned is not None:
+                    self._pinned_stream = C.c_void_p(side.cuda_stream)
+                try:
+                    yield cur
+                finally:
+                    if pinned is not None:
+                        self._pinned_stream = pinned
             cur.wait_stream(side)
 
         return ctx()

@@ -10,6 +10,7 @@
 //     C/D:       D[reg r] = D[row = g + 4 r][col = c]
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/basq_hip.h"
 #include "exp_coeffs.inc"
@@ -492,6 +493,214 @@ static int dispatch_blocksum(int kk, int fam, const BlocksumArgs& A, hipStream_t
     return BASQ_EUNSUPPORTED;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Block sums of SQUARED posterior covariances: the one term of the WSABI-M kernel (BASQ/_wsabi.py:227-249) that is
+// not linear in the kernel,
+//     E[j][s] = sum_{p in set s} (mu_p / 2) * cov(nys_j, y_p)^2,      cov = s2 k(nys_j, y_p) - sum_o B[j][o] ko[o][p]
+// (B = k(nys, Xobs) W, ko[o][p] = s2 k(Xobs_o, y_p); + the likelihood noise on entry [kappa][kappa] of every kernel
+// block, BASQ/_gp.py:275-276).  Same tile ownership, chunks and XCD map as blocksum_kernel; the correction is a second
+// MFMA chain over the n_obs observations whose operands stream from L2 (B^T rows: 16 consecutive Nystrom rows of one
+// observation = one 128-byte line; ko rows: 16 consecutive candidates of one observation).  Two blocks share every
+// B^T fragment (JT + 2 loads per 2 JT MFMAs), the next fragments are in flight while the current ones multiply.
+// Nothing of size [m, candidates] is ever written: 2 m n_obs flops per pair are what remains (MFMA-bound).
+// ------------------------------------------------------------------------------------------------
+struct SqArgs {
+    const double* bmatT;   // [4 ko][ldb]  B^T, rows >= n_obs and columns >= m zero
+    const double* kobs;    // [4 ko][ldk]  ko, LOCAL candidate positions, rows >= n_obs zero
+    long long ldb, ldk;
+    int ko;                // ceil(n_obs / 4)
+    double outputscale, noise;
+};
+
+template <int KK, int FAM, int JT>
+__device__ __forceinline__ void sq_pair_accumulate(const double (&a)[JT][KK], const CandFrag<KK>& f0, const CandFrag<KK>& f1,
+                                                   long long row0, long long row1, int kap0, int kap1, int jrow,
+                                                   const double* __restrict__ ap, int g, const SqArgs& Q,
+                                                   double (&acc)[JT][4], const ExpK& ek, const double* tab) {
+    d4 E0[JT], E1[JT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        E0[jt] = d4{0.0, 0.0, 0.0, 0.0};
+        E1[jt] = d4{0.0, 0.0, 0.0, 0.0};
+    }
+    const double* bp0 = Q.kobs + (long long)g * Q.ldk + row0;
+    const double* bp1 = Q.kobs + (long long)g * Q.ldk + row1;
+    const long long sa = 4 * Q.ldb, sb = 4 * Q.ldk;
+    double av[JT], b0 = bp0[0], b1 = bp1[0];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) av[jt] = ap[jt * 16];
+    for (int ko = 0; ko < Q.ko; ++ko) {
+        const long long kn = (ko + 1 < Q.ko) ? (ko + 1) : ko;          // last trip re-reads its own fragments
+        double avn[JT];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) avn[jt] = ap[kn * sa + jt * 16];
+        const double b0n = bp0[kn * sb], b1n = bp1[kn * sb];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            E0[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[jt], b0, E0[jt], 0, 0, 0);
+            E1[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[jt], b1, E1[jt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) av[jt] = avn[jt];
+        b0 = b0n;
+        b1 = b1n;
+    }
+    const bool noisy = Q.noise != 0.0;
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        d4 D0 = {0.0, 0.0, 0.0, 0.0}, D1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            D0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt][kk], f0.b[kk], D0, 0, 0, 0);
+            D1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt][kk], f1.b[kk], D1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = jrow + jt * 16 + 4 * r;
+            double v0 = __builtin_fma(Q.outputscale, kernel_from_arg_k<FAM>(D0[r], ek, tab), -E0[jt][r]);
+            double v1 = __builtin_fma(Q.outputscale, kernel_from_arg_k<FAM>(D1[r], ek, tab), -E1[jt][r]);
+            if (noisy) {
+                if (j == kap0) v0 += Q.noise;
+                if (j == kap1) v1 += Q.noise;
+            }
+            acc[jt][r] = __builtin_fma(f0.w * v0, v0, acc[jt][r]);
+            acc[jt][r] = __builtin_fma(f1.w * v1, v1, acc[jt][r]);
+        }
+    }
+}
+
+template <int KK, int FAM, int JT>
+__global__ void __launch_bounds__(256) blocksum_sq_kernel(const BlocksumArgs A, const SqArgs Q) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    constexpr int KP = KK * 4;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;            // XCD-aware map: see blocksum_kernel
+    const int jg = seq % A.n_jgroups;
+    const int gidx = (seq / A.n_jgroups) * 8 + xcd;
+    const int st = gidx % A.n_stiles;
+    const int chunk = gidx / A.n_stiles;
+    const int j0 = (jg * 4 + wave) * (16 * JT);
+    __shared__ double exp_tab[BASQ_TAB_N];
+    exp_table_init(exp_tab);
+    if (chunk >= A.n_chunks) return;
+    if (j0 >= A.m) return;
+    const int s0 = st * 16;
+    ExpK ek;
+    expk_init(ek);
+    double a[JT][KK];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) a[jt][kk] = A.nys[(long long)(j0 + jt * 16 + c) * KP + kk * 4 + g];
+    double acc[JT][4];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[jt][r] = 0.0;
+    const double* ap = Q.bmatT + (long long)g * Q.ldb + j0 + c;
+    const int jrow = j0 + g;
+    const bool col_ok = (s0 + c) < A.S;
+    const long long lim = (A.off + A.Rl < A.n_full) ? (A.off + A.Rl) : A.n_full;
+    long long bA = A.blk_lo + (long long)chunk * A.blk_per_chunk;
+    long long bB = bA + A.blk_per_chunk;
+    if (bB > A.blk_hi) bB = A.blk_hi;
+    // candidate of this lane's column in block i (weight mu / 2, zero when the position is not held here)
+    auto frag = [&](CandFrag<KK>& f, long long pl, bool ok) -> long long {
+        load_cand<KK>(f, A, pl, ok, g);
+        f.w = 0.5 * f.wm;
+        return ok ? pl : 0;
+    };
+    for (long long i = bA; i < bB; i += 2) {
+        const long long pg0 = i * A.S + s0 + c, pg1 = pg0 + A.S;
+        CandFrag<KK> f0, f1;
+        const long long r0 = frag(f0, pg0 - A.off, col_ok && pg0 >= A.off && pg0 < lim);
+        const long long r1 = frag(f1, pg1 - A.off, col_ok && (i + 1 < bB) && pg1 >= A.off && pg1 < lim);
+        // the noise sits on Nystrom row kappa = position inside the block = set index of the column
+        sq_pair_accumulate<KK, FAM, JT>(a, f0, f1, r0, r1, s0 + c, s0 + c, jrow, ap, g, Q, acc, ek, exp_tab);
+    }
+    // ragged tail: all of it belongs to set S-1; tail point k meets the noise on Nystrom row k
+    const long long t0 = (A.n_full > A.off) ? (A.n_full - A.off) : 0;
+    if (chunk == A.n_chunks - 1 && st == A.n_stiles - 1 && t0 < A.Rl) {
+        double tacc[JT][4];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tacc[jt][r] = 0.0;
+        for (long long p = t0; p < A.Rl; p += 32) {
+            const long long p0 = p + c, p1 = p + 16 + c;
+            CandFrag<KK> f0, f1;
+            const long long r0 = frag(f0, p0, p0 < A.Rl);
+            const long long r1 = frag(f1, p1, p1 < A.Rl);
+            const long long k0 = A.off + p0 - A.n_full, k1 = A.off + p1 - A.n_full;
+            sq_pair_accumulate<KK, FAM, JT>(a, f0, f1, r0, r1, (k0 < 0x7fffffffLL) ? (int)k0 : -1,
+                                            (k1 < 0x7fffffffLL) ? (int)k1 : -1, jrow, ap, g, Q, tacc, ek, exp_tab);
+        }
+        const int c_last = (A.S - 1) - s0;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = sum16(tacc[jt][r]);
+                if (c == c_last) acc[jt][r] += v;
+            }
+    }
+    if (col_ok) {
+        double* out = A.Xpart + (long long)chunk * A.m * A.S;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + jt * 16 + g + 4 * r;
+                if (j < A.m) out[(long long)j * A.S + s0 + c] = acc[jt][r];
+            }
+    }
+}
+
+template <int KK, int FAM, int JT>
+static int launch_blocksum_sq_jt(const BlocksumArgs& A, const SqArgs& Q, hipStream_t st) {
+    BlocksumArgs B = A;
+    B.n_jgroups = (A.m + 64 * JT - 1) / (64 * JT);
+    const long long npairs = (long long)A.n_stiles * A.n_chunks;
+    const long long nblk = ((npairs + 7) / 8) * 8 * B.n_jgroups;
+    if (nblk <= 0 || nblk > 0x7fffffffLL) return BASQ_EINVAL;
+    hipLaunchKernelGGL((blocksum_sq_kernel<KK, FAM, JT>), dim3((unsigned)nblk), dim3(256), 0, st, B, Q);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+template <int KK, int FAM>
+static int launch_blocksum_sq(const BlocksumArgs& A, const SqArgs& Q, hipStream_t st) {
+    static const int jt_env = [] { const char* e = getenv("BASQ_SQ_JT"); return e ? atoi(e) : 0; }();   // A/B knob
+    if (BASQ_JT_FOR(KK) == 4 && jt_env != 2) return launch_blocksum_sq_jt<KK, FAM, 4>(A, Q, st);
+    return launch_blocksum_sq_jt<KK, FAM, 2>(A, Q, st);
+}
+
+template <int KK>
+static int dispatch_blocksum_sq_fam(int fam, const BlocksumArgs& A, const SqArgs& Q, hipStream_t st) {
+    switch (fam) {
+        case BASQ_FAMILY_RBF: return launch_blocksum_sq<KK, BASQ_FAMILY_RBF>(A, Q, st);
+        case BASQ_FAMILY_MATERN52: return launch_blocksum_sq<KK, BASQ_FAMILY_MATERN52>(A, Q, st);
+        case BASQ_FAMILY_MATERN32: return launch_blocksum_sq<KK, BASQ_FAMILY_MATERN32>(A, Q, st);
+    }
+    return BASQ_EUNSUPPORTED;
+}
+
+static int dispatch_blocksum_sq(int kk, int fam, const BlocksumArgs& A, const SqArgs& Q, hipStream_t st) {
+    switch (kk) {
+        case 1: return dispatch_blocksum_sq_fam<1>(fam, A, Q, st);
+        case 2: return dispatch_blocksum_sq_fam<2>(fam, A, Q, st);
+        case 3: return dispatch_blocksum_sq_fam<3>(fam, A, Q, st);
+        case 4: return dispatch_blocksum_sq_fam<4>(fam, A, Q, st);
+        case 5: return dispatch_blocksum_sq_fam<5>(fam, A, Q, st);
+        case 6: return dispatch_blocksum_sq_fam<6>(fam, A, Q, st);
+        case 7: return dispatch_blocksum_sq_fam<7>(fam, A, Q, st);
+        case 8: return dispatch_blocksum_sq_fam<8>(fam, A, Q, st);
+        case 9: return dispatch_blocksum_sq_fam<9>(fam, A, Q, st);
+        case 10: return dispatch_blocksum_sq_fam<10>(fam, A, Q, st);
+    }
+    return BASQ_EUNSUPPORTED;
+}
+
 #ifndef BASQ_CAR_THREADS
 #define BASQ_CAR_THREADS 1024
 #endif
@@ -930,23 +1139,29 @@ __global__ void __launch_bounds__(1024) car_eliminate_lds_kernel(const double* _
             mu_r = dead ? 0.0 : (mu_r - step);         // eliminated columns: the reference has Phi = 0, mu = 0
         }
         BASQ_NS_STAMP(k, 3);
+        // Rows k+1.. are dealt to the row groups.  With two or more groups, group 0 -- the column owners, who also carry
+        // the serial part of a step (winner scan, weights, ratio test) -- takes ONLY row k+1, the one the next test needs;
+        // the others share rows k+2.. .  Before, the owners also took a full share of the update and every step cost
+        // (serial part + update share) instead of max(serial part, update): 170 -> ~120 us at 100 x 200.
+        const bool owners_apart = rows_per_pass >= 2;
+        const int rstep = owners_apart ? rows_per_pass - 1 : rows_per_pass;
         int cc = k + 1 + my_r;
         double fresh = 0.0;
-        if (upd && !dead && cc < nrows) {              // first row of this thread: row k+1 for the column owners
+        if (upd && !dead && cc < nrows && (my_r == 0 || !owners_apart)) {   // row k+1 for the column owners
             double* p = Phi + (size_t)cc * M;
             const double o = div_by_recip(p[j] * phi_i, phij, rphij);     // == prod / phij, bit for bit
             fresh = p[my_i] - o;
             p[my_i] = fresh;
         }
-        cc += rows_per_pass;
+        cc = owners_apart ? ((my_r == 0) ? nrows : (k + 1 + my_r)) : (cc + rows_per_pass);
         if (k + 1 < nrows && wv < nwv_act) ratio_test(fresh, pb ^ 1);    // step k+1's test, off the critical path
         if (upd && !dead) {
             // four independent rows per trip, all LDS reads before the writes (otherwise every row is its own round trip)
-            for (; cc + 3 * rows_per_pass < nrows; cc += 4 * rows_per_pass) {   // :165-171
+            for (; cc + 3 * rstep < nrows; cc += 4 * rstep) {   // :165-171
                 double* p0 = Phi + (size_t)cc * M;
-                double* p1 = p0 + (size_t)rows_per_pass * M;
-                double* p2 = p1 + (size_t)rows_per_pass * M;
-                double* p3 = p2 + (size_t)rows_per_pass * M;
+                double* p1 = p0 + (size_t)rstep * M;
+                double* p2 = p1 + (size_t)rstep * M;
+                double* p3 = p2 + (size_t)rstep * M;
                 const double a0 = p0[j], a1 = p1[j], a2 = p2[j], a3 = p3[j];
                 const double b0 = p0[my_i], b1 = p1[my_i], b2 = p2[my_i], b3 = p3[my_i];
                 const double o0 = div_by_recip(a0 * phi_i, phij, rphij);
@@ -958,7 +1173,7 @@ __global__ void __launch_bounds__(1024) car_eliminate_lds_kernel(const double* _
                 p2[my_i] = b2 - o2;
                 p3[my_i] = b3 - o3;
             }
-            for (; cc < nrows; cc += rows_per_pass) {
+            for (; cc < nrows; cc += rstep) {
                 double* p = Phi + (size_t)cc * M;
                 const double o = div_by_recip(p[j] * phi_i, phij, rphij);
                 p[my_i] = p[my_i] - o;
@@ -2836,6 +3051,37 @@ int basq_blocksum_f64(const basq_kernel_spec* spec, const double* nys, int32_t m
                          stream);
 }
 
+int basq_blocksum_sq_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
+                         const double* mu, int64_t Rl, int64_t off, int64_t n_full, int32_t S, int32_t n_chunks,
+                         const double* bmatT, int64_t ldb, const double* kobs, int64_t ldk, int32_t n_obs, double noise,
+                         double* Epart, void* stream) {
+    if (!spec_ok(spec) || !nys || !cand || !mu || !bmatT || !kobs || !Epart) return BASQ_EINVAL;
+    if (m < 1 || Rl < 1 || off < 0 || n_full < 0 || S < 1 || n_chunks < 1 || n_obs < 1) return BASQ_EINVAL;
+    if (n_full % S != 0) return BASQ_EINVAL;
+    const int jt = BASQ_JT_FOR(basq_kp(spec->d) / 4);
+    if (ldb < (((int64_t)m + 16 * jt - 1) / (16 * jt)) * (16 * jt) || ldk < Rl) return BASQ_EINVAL;   // fragment reads stay inside
+    BlocksumArgs A;
+    A.nys = nys; A.cand = cand; A.mu = mu; A.wx = nullptr; A.Xpart = Epart; A.totpart = nullptr;
+    A.Rl = Rl; A.off = off; A.n_full = n_full; A.m = m; A.S = S; A.n_chunks = n_chunks;
+    A.class_mod = 0; A.class0 = 0;
+    A.n_stiles = (S + 15) / 16;
+    const long long lim = (off + Rl < n_full) ? (off + Rl) : n_full;
+    if (lim > off) {
+        A.blk_lo = off / S;
+        A.blk_hi = (lim + S - 1) / S;
+    } else {
+        A.blk_lo = 0;
+        A.blk_hi = 0;
+    }
+    const long long nblk = A.blk_hi - A.blk_lo;
+    A.blk_per_chunk = (nblk + n_chunks - 1) / n_chunks;
+    if (A.blk_per_chunk < 1) A.blk_per_chunk = 1;
+    SqArgs Q;
+    Q.bmatT = bmatT; Q.kobs = kobs; Q.ldb = ldb; Q.ldk = ldk; Q.ko = (n_obs + 3) / 4;
+    Q.outputscale = spec->outputscale; Q.noise = noise;
+    return dispatch_blocksum_sq(basq_kp(spec->d) / 4, spec->family, A, Q, (hipStream_t)stream);
+}
+
 // Next round's class partials from this round's, without touching a candidate (see include/basq_hip.h):
 //   Tout[c'][j][par * H + k] = (Tin[2 c' + par][j][kept[k]] * w_star[k]) / tot[kept[k]],   H = n_keep = S / 2
 __global__ void regroup_classes_kernel(const double* __restrict__ Tin, int rows, int S, int C, const int* __restrict__ kept,
@@ -2850,6 +3096,10 @@ __global__ void regroup_classes_kernel(const double* __restrict__ Tin, int rows,
     const int j = (int)(rest % rows), cp = (int)(rest / rows);
     const int H = S / 2, par = sp / H, k = sp - par * H;
     const int s = kept[k];
+    if ((unsigned)s >= (unsigned)S) {          // launched before the host checked n_keep: entries past it are stale
+        Tout[e] = 0.0;
+        return;
+    }
     const double v = Tin[((long long)(2 * cp + par) * rows + j) * S + s];
     Tout[e] = (v * w_star[k]) / tot[s];                                        // the order of BASQ/_rchq.py:113-114
 }

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BASQ_ABI_VERSION 3
+#define BASQ_ABI_VERSION 4
 
 /* error codes */
 #define BASQ_OK            0
@@ -241,6 +241,23 @@ int basq_init_state_f64(double* mu, int64_t* gid, int64_t Rl, int64_t gid0, int6
  */
 int basq_dense_blocksum_f64(const double* C, int32_t m, int64_t nc, int64_t ldc, const double* mu, int64_t pg0,
                             int64_t n_full, int32_t S, double scale, int32_t square, double* E, void* stream);
+
+/*
+ * WSABI-M's non-linear term, fused (BASQ/_wsabi.py:227-249: CLy = mu_x cov mu_y + 0.5 cov^2, cov = the GP's predictive
+ * covariance BASQ/_gp.py:233-277): block sums of the SQUARED covariances straight from the packed points,
+ *     Epart[c][j][s] = sum over the candidates p of chunk c with set(p) = s of  (mu[p] / 2) * cov(nys_j, y_p)^2,
+ *     cov(nys_j, y_p) = outputscale * k(nys_j, y_p) - sum_o bmatT[o][j] * kobs[o][p]  (+ noise where the pair is entry
+ *     [kappa][kappa] of its kernel block: kappa = p % S below n_full, p - n_full in the ragged tail, _gp.py:275-276).
+ * bmatT [n_obs4, ldb] = (k(nys, Xobs) W)^T, kobs [n_obs4, ldk] = outputscale * k(Xobs, y_p) at LOCAL candidate positions
+ * (basq_gram_f64 of the packed observations against `cand`); n_obs4 = n_obs rounded up to 4, the extra rows zero;
+ * ldb >= m rounded up to 64, the extra columns zero; ldk >= Rl.  nys / cand / mu / Rl / off / n_full / S / n_chunks as
+ * for basq_blocksum_f64 (contiguous chunks).  No [m, candidates] matrix is formed; replaces the dense
+ * covariance chunks + library GEMM + basq_dense_blocksum_f64(square = 1) of the unfused path.
+ */
+int basq_blocksum_sq_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
+                         const double* mu, int64_t Rl, int64_t off, int64_t n_full, int32_t S, int32_t n_chunks,
+                         const double* bmatT, int64_t ldb, const double* kobs, int64_t ldk, int32_t n_obs, double noise,
+                         double* Epart, void* stream);
 
 /*
  * Gaussian test matrix of torch.svd_lowrank (BASQ/_rchq.py:29 -> torch._lowrank: R = torch.randn(m, q)): the

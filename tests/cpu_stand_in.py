@@ -294,6 +294,29 @@ class CpuStandInOps:
         sets = torch.where(pg < n_full, pg % S, torch.full_like(pg, S - 1))
         E.index_add_(1, sets, scale * ((Cmat * Cmat) if square else Cmat) * mu_chunk[:nc].unsqueeze(0))
 
+    def gram_into(self, spec, packA, na, packB, nb, out):
+        out[:na, :nb] = self.gram(spec, packA, na, packB, nb)
+        return out
+
+    def blocksum_sq(self, spec, nys, m, cand, mu, Rl, off, n_full, S, n_chunks, bmatT, kobs, n_obs, noise):
+        """E[j, s] = sum_p (mu_p / 2) cov(j, p)^2, cov = s2 k - B ko (+ noise on entry [kappa][kappa] of each block)."""
+        self._count("blocksum_sq")
+        Epart = torch.zeros(n_chunks, m, S, dtype=torch.float64)
+        if Rl == 0:
+            return Epart
+        step = max(S, (1 << 22) // max(m, 1))
+        for p0 in range(0, Rl, step):
+            nc = min(step, Rl - p0)
+            cov = self.gram(spec, nys, m, cand[p0:p0 + nc], nc) - bmatT[:n_obs, :m].T @ kobs[:n_obs, p0:p0 + nc]
+            pg = off + p0 + torch.arange(nc)
+            if noise != 0.0:
+                kappa = torch.where(pg < n_full, pg % S, pg - n_full)
+                hit = kappa < m
+                cov[kappa[hit], torch.arange(nc)[hit]] += noise
+            sets = torch.where(pg < n_full, pg % S, torch.full_like(pg, S - 1))
+            Epart[0].index_add_(1, sets, 0.5 * (cov * cov) * mu[p0:p0 + nc].unsqueeze(0))
+        return Epart
+
     def box_muller(self, u, u_tail=None):
         def bm(v):
             blk = v.view(-1, 16)

@@ -329,6 +329,39 @@ def test_dense_blocksum_vs_standin(hip_ops, m, nc, pg0, n_full, S, square):
     assert (Eg.cpu() - Ec).abs().max().item() <= 1e-12 * Ec.abs().max().item()
 
 
+@pytest.mark.parametrize("family,d,m,n_obs,Rl,off,n_full,S,n_chunks,noise", [
+    ("rbf", 10, 300, 202, 5000, 0, 4800, 200, 3, 0.0),          # WSABI-M shape: n_obs not a multiple of 4, ragged tail
+    ("rbf", 4, 70, 50, 2321, 0, 2300, 50, 2, 1e-2),             # noise on [kappa][kappa] of blocks and tail
+    ("matern52", 8, 130, 61, 1500, 700, 2800, 100, 1, 1e-3),    # a middle shard (no tail, starts mid-block)
+    ("rbf", 6, 64, 8, 999, 1200, 2000, 40, 4, 1e-3),            # the last shard: blocks + the whole tail
+    ("matern32", 24, 90, 33, 777, 0, 770, 70, 2, 0.0),          # KK = 7 (two row tiles per wave)
+    ("rbf", 5, 40, 12, 37, 0, 0, 37, 1, 1e-2),                  # the final round: every point its own set, all tail
+])
+def test_blocksum_sq_vs_standin(hip_ops, family, d, m, n_obs, Rl, off, n_full, S, n_chunks, noise):
+    """Fused WSABI-M term (basq_blocksum_sq_f64) vs the stand-in's dense covariance blocks."""
+    cpu = CpuStandInOps()
+    spec = _spec(family, d)
+    nys, obs, cand = _rand(m, d, 51), _rand(n_obs, d, 52), _rand(Rl, d, 53)
+    center = nys.mean(0)
+    g = torch.Generator().manual_seed(7)
+    mu = torch.rand(Rl, generator=g, dtype=torch.float64) + 0.05
+    Bm = 0.1 * _rand(m, n_obs, 54)
+    n4, mp = (n_obs + 3) // 4 * 4, (m + 63) // 64 * 64
+
+    def run(ops):
+        pa = ops.pack(spec, ops.to_device(torch.cat([nys, obs], 0)), ops.to_device(center), 0, pad_rows_to=64)
+        pb = ops.pack(spec, ops.to_device(cand), ops.to_device(center), 1)
+        bT = ops.zeros(n4, mp)
+        bT[:n_obs, :m] = ops.to_device(Bm).t()
+        kobs = ops.zeros(n4, Rl)
+        ops.gram_into(spec, pa[m:m + n_obs], n_obs, pb, Rl, kobs)
+        return ops.blocksum_sq(spec, pa, m, pb, ops.to_device(mu), Rl, off, n_full, S, n_chunks, bT, kobs, n_obs, noise)
+
+    Ec = run(cpu).sum(0)
+    Eg = run(hip_ops).sum(0).cpu()
+    assert (Eg - Ec).abs().max().item() <= 2e-12 * Ec.abs().max().item()
+
+
 def test_quadrature_step_vs_oracle(hip_ops):
     """EZy = w . mean_predict(X), VarZy = w^T K(X, X) w with the structured kernels' own mean
     (BASQ/_quadrature.py:53-64), against the oracle's CPU kernels."""
