@@ -441,18 +441,28 @@ def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None, overlap=
         return (-1 * U.t()).contiguous()                       # :30
 
 
+PSD_EIG_MAX_M = 4096             # _make_cov_psd: largest Gram whose spectrum is checked (SOBER/_utils.py:122-124)
+
+
 def _make_cov_psd(A, max_iter: int = 10):
     """``SafeTensorOperator.make_cov_psd`` (``SOBER/_utils.py:128-154``) for the Nystrom Gram, on the device.
 
     The reference tests exact symmetry + Cholesky + ``eig >= 0``; a kernel Gram computed in floating point
     is never bitwise symmetric, so its repair branch ``cov <- sqrt(cov * cov.T)`` always runs: that is done here
-    unconditionally.  The follow-up PSD test uses Cholesky only (an O(m^3) ``eig`` of a 1e4 x 1e4 matrix is
-    not affordable); when it fails, the reference's diagonal-jitter loop is reproduced.
+    unconditionally.  The follow-up PSD test is the reference's: Cholesky AND no negative eigenvalue -- the spectrum
+    from the symmetric solver (the matrix is exactly symmetric after the repair; the reference's general ``eig`` sees
+    the same eigenvalues up to round-off) for Grams of up to ``PSD_EIG_MAX_M`` points.  Beyond that (where the
+    reference's own ``eig`` of an [m, m] matrix takes tens of minutes) Cholesky alone decides -- the one stated fork.
+    When the test fails, the reference's diagonal-jitter loop is reproduced.
     """
     A = torch.sqrt(torch.nan_to_num(A) * torch.nan_to_num(A).T)
 
     def psd(M_):
-        return int(torch.linalg.cholesky_ex(M_).info.item()) == 0
+        if int(torch.linalg.cholesky_ex(M_).info.item()) != 0:
+            return False
+        if M_.shape[0] > PSD_EIG_MAX_M:
+            return True
+        return bool((torch.linalg.eigvalsh(M_) >= 0).all())
 
     if not psd(A):
         n = A.shape[0]

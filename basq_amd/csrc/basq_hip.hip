@@ -1139,29 +1139,26 @@ __global__ void __launch_bounds__(1024) car_eliminate_lds_kernel(const double* _
             mu_r = dead ? 0.0 : (mu_r - step);         // eliminated columns: the reference has Phi = 0, mu = 0
         }
         BASQ_NS_STAMP(k, 3);
-        // Rows k+1.. are dealt to the row groups.  With two or more groups, group 0 -- the column owners, who also carry
-        // the serial part of a step (winner scan, weights, ratio test) -- takes ONLY row k+1, the one the next test needs;
-        // the others share rows k+2.. .  Before, the owners also took a full share of the update and every step cost
-        // (serial part + update share) instead of max(serial part, update): 170 -> ~120 us at 100 x 200.
-        const bool owners_apart = rows_per_pass >= 2;
-        const int rstep = owners_apart ? rows_per_pass - 1 : rows_per_pass;
         int cc = k + 1 + my_r;
         double fresh = 0.0;
-        if (upd && !dead && cc < nrows && (my_r == 0 || !owners_apart)) {   // row k+1 for the column owners
+        if (upd && !dead && cc < nrows) {              // first row of this thread: row k+1 for the column owners
             double* p = Phi + (size_t)cc * M;
             const double o = div_by_recip(p[j] * phi_i, phij, rphij);     // == prod / phij, bit for bit
             fresh = p[my_i] - o;
             p[my_i] = fresh;
         }
-        cc = owners_apart ? ((my_r == 0) ? nrows : (k + 1 + my_r)) : (cc + rows_per_pass);
+        cc += rows_per_pass;
         if (k + 1 < nrows && wv < nwv_act) ratio_test(fresh, pb ^ 1);    // step k+1's test, off the critical path
         if (upd && !dead) {
-            // four independent rows per trip, all LDS reads before the writes (otherwise every row is its own round trip)
-            for (; cc + 3 * rstep < nrows; cc += 4 * rstep) {   // :165-171
+            // four independent rows per trip, all LDS reads before the writes (otherwise every row is its own round trip).
+            // (Taking the column owners off this loop -- they also carry the serial part of a step -- made the kernel
+            // SLOWER, 188 vs 169 us at 100 x 200: the update is bound by LDS bandwidth, 24 B per entry and step, not by
+            // the serial part, and every thread's share counts.)
+            for (; cc + 3 * rows_per_pass < nrows; cc += 4 * rows_per_pass) {   // :165-171
                 double* p0 = Phi + (size_t)cc * M;
-                double* p1 = p0 + (size_t)rstep * M;
-                double* p2 = p1 + (size_t)rstep * M;
-                double* p3 = p2 + (size_t)rstep * M;
+                double* p1 = p0 + (size_t)rows_per_pass * M;
+                double* p2 = p1 + (size_t)rows_per_pass * M;
+                double* p3 = p2 + (size_t)rows_per_pass * M;
                 const double a0 = p0[j], a1 = p1[j], a2 = p2[j], a3 = p3[j];
                 const double b0 = p0[my_i], b1 = p1[my_i], b2 = p2[my_i], b3 = p3[my_i];
                 const double o0 = div_by_recip(a0 * phi_i, phij, rphij);
@@ -1173,7 +1170,7 @@ __global__ void __launch_bounds__(1024) car_eliminate_lds_kernel(const double* _
                 p2[my_i] = b2 - o2;
                 p3[my_i] = b3 - o3;
             }
-            for (; cc < nrows; cc += rstep) {
+            for (; cc < nrows; cc += rows_per_pass) {
                 double* p = Phi + (size_t)cc * M;
                 const double o = div_by_recip(p[j] * phi_i, phij, rphij);
                 p[my_i] = p[my_i] - o;

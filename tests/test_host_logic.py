@@ -288,3 +288,31 @@ def test_tiny_and_degenerate_pools(N, d, n, m):
         assert len(wo) == len(we) and (len(wo) == 0 or ((we - wo).abs() / wo).max().item() <= 1e-9)
     finally:
         torch.set_default_dtype(prev)
+
+
+@pytest.mark.parametrize("kind", ["gram", "gram_asymmetric", "duplicates", "indefinite"])
+def test_make_cov_psd_follows_the_reference(kind):
+    """SOBER's Gram repair (SOBER/_utils.py:113-154, restated in oracle/rchq_oracle.py): Cholesky AND a non-negative
+    spectrum decide, the jitter loop runs until both hold."""
+    from basq_amd._engine import _make_cov_psd
+    from oracle.rchq_oracle import make_cov_psd_sober
+
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(60, 3, generator=g, dtype=torch.float64)
+    if kind == "duplicates":
+        X[10:30] = X[0:20].clone()                                    # numerically singular: Cholesky fails, jitter is added
+    A = torch.exp(-0.5 * torch.cdist(X, X) ** 2)
+    if kind == "gram_asymmetric":
+        A = A * (1.0 + 1e-16 * torch.arange(60, dtype=torch.float64).unsqueeze(0))
+    if kind == "indefinite":
+        A = A - 0.5 * torch.eye(60, dtype=torch.float64)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)                    # the reference allocates its jitter in the default dtype
+    try:
+        want = make_cov_psd_sober(A.clone())
+    finally:
+        torch.set_default_dtype(prev)
+    got = _make_cov_psd(A.clone())
+    assert torch.allclose(got, want, rtol=0, atol=1e-15)
+    if kind in ("duplicates", "indefinite"):
+        assert (got.diagonal() > A.diagonal() + 5e-6).all()   # the repair really ran

@@ -1,0 +1,19 @@
+#!/bin/bash
+# round-2 GPU check #12: launch-path trims (finalize from class messages, early regroup, pinned stream), elimination row split
+set -u
+out=gpurun_out/r02l; mkdir -p $out
+timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "car_eliminate or regroup or cluster" > $out/kernels.log 2>&1
+echo "kernel tests rc=$?" >> $out/kernels.log; tail -3 $out/kernels.log
+for shape in "100 200" "50 100" "200 400"; do echo "== $shape" >> $out/reduction.txt; timeout 300 python tools/bench_reduction.py $shape 2>&1 | grep -v amdgpu.ids >> $out/reduction.txt; done
+cat $out/reduction.txt
+timeout 900 python bench.py --breakdown > $out/bench1.json 2> $out/bench1.err; cut -c1-330 $out/bench1.json
+timeout 900 python bench.py --no-cpu-baseline > $out/bench2.json 2> $out/bench2.err; cut -c1-200 $out/bench2.json
+timeout 2400 python -m pytest tests -x -q -m gpu > $out/gpu_tests.log 2>&1
+echo "gpu tests rc=$?" >> $out/gpu_tests.log; tail -5 $out/gpu_tests.log | cut -c1-300
+timeout 1200 python tools/bench_configs.py > $out/configs.txt 2>&1; grep -v amdgpu.ids $out/configs.txt | cut -c1-330
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof_bench -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/$out/prof_bench.log 2>&1
+cd $GRAFT_REPO_ROOT
+python tools/trace_gaps.py $(ls $out/prof_bench/*kernel_trace.csv | head -1) > $out/trace_gaps_bench.txt 2>&1; cat $out/trace_gaps_bench.txt | cut -c1-200
+rm -f $out/prof_*/*trace.csv
+head -12 $out/prof_bench/bench_kernel_stats.csv | cut -c1-140
