@@ -153,13 +153,27 @@ def _splits_for(K: int, want: int) -> int:
     return 1
 
 
+# The range finder's products on basq_skinny_gemm_f64 (False: library GEMMs through torch, for A/B comparisons).
+OWN_RANGE_GEMM = True
+
+
 def _mm_splitk(ops, A, B, want: int = 8):
-    """``A @ B`` for a long contraction with a skinny output, as ONE batched library GEMM over K slices.
+    """``A @ B`` for a long contraction with a skinny output (<= 208 columns): the hand-written tall-skinny MFMA kernel
+    (``basq_skinny_gemm_f64``).  Wider outputs, other dtypes and the CPU stand-in take the library path below: ONE
+    batched library GEMM over K slices.
 
     rocBLAS tiles the output only (no split-K): ``[1e4,1e4] @ [1e4,99]`` is 79 work-groups on 256 CUs and
     ``[99,1e4] @ [1e4,99]`` a single one.  Viewing the K dimension as (splits, K/splits) -- strided views, no
     copies -- runs ``splits`` times more work-groups concurrently; the partial products are added in slice order.
     """
+    sk = getattr(ops, "skinny_gemm", None) if OWN_RANGE_GEMM else None
+    if sk is not None and A.dim() == 2 and B.dim() == 2 and B.shape[1] <= ops.SKINNY_MAX_N and B.stride(1) == 1 \
+            and A.dtype == torch.float64 and B.dtype == torch.float64:
+        # the hand-written tall-skinny MFMA kernel (basq_skinny_gemm_f64): A read once, split-K inside
+        if A.stride(1) == 1 and A.stride(0) >= A.shape[1]:
+            return sk(A, B, False)
+        if A.stride(0) == 1 and A.stride(1) >= A.shape[0]:
+            return sk(A.t(), B, True)                          # A is a transposed view: read the stored matrix
     M, K = A.shape
     N = B.shape[1]
     c = _splits_for(K, want)
@@ -191,7 +205,7 @@ def _cholqr(ops, X, flags, passes=2):
         else:
             W, info = ops.chol_inv(G)
             flags.append(info)
-            X = ops.matmul(X, W)
+            X = _mm_splitk(ops, X, W, 1)
     return X
 
 
@@ -394,10 +408,10 @@ def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None, overlap=
                 i2 = ops.chol_factor(G2)
             else:
                 W1, i1 = ops.chol_inv(G1)
-                Yq = ops.matmul(Y, W1)
+                Yq = _mm_splitk(ops, Y, W1, 1)
                 G2 = _mm_splitk(ops, Yq.t(), Yq, 32)
                 _, i2 = ops.chol_inv(G2)
-            L = ops.matmul(torch.tril(G1), torch.tril(G2))
+            L = _mm_splitk(ops, torch.tril(G1), torch.tril(G2), 1)
             bad = torch.stack([f.reshape(()) for f in flags + [i1, i2]]).max()
             both, ready = ops.to_host_async(torch.cat([L.reshape(-1), bad.to(torch.float64).reshape(1)]), "basisL")
         if overlap is not None:
@@ -412,7 +426,7 @@ def nystrom_basis(ops, A, q_req: int, trace: EngineTrace | None = None, overlap=
                     Ub = torch.linalg.svd(Lh)[0]
         if ok:
             with _Timer(ops, trace, "basis.gemm"):
-                U = ops.matmul(Q, ops.to_device(Ub))           # [m, k]
+                U = _mm_splitk(ops, Q, ops.to_device(Ub), 1)   # [m, k]
                 return (-1 * U.t()).contiguous()               # :30
         if trace is not None:
             trace.timers["basis.fallback"] = trace.timers.get("basis.fallback", 0) + 1

@@ -352,6 +352,27 @@ class HipOps:
     def matmul(self, A, B):
         return torch.matmul(A, B)
 
+    SKINNY_MAX_N = 208               # widest output of basq_skinny_gemm_f64 (13 column tiles)
+
+    def skinny_gemm(self, A, B, trans=False, ksplit=None):
+        """``A @ B`` (``trans``: ``A.T @ B``) for a skinny ``B [K, N <= 208]`` on the hand-written f64 MFMA kernel
+        (``basq_skinny_gemm_f64``): the range finder's products.  ``A``, ``B`` row-major (row strides free)."""
+        if A.dtype != torch.float64 or B.dtype != torch.float64 or A.stride(1) != 1 or B.stride(1) != 1:
+            raise ValueError("expected float64 matrices with unit column stride")
+        K, M = (A.shape[0], A.shape[1]) if trans else (A.shape[1], A.shape[0])
+        N = B.shape[1]
+        assert B.shape[0] == K and N <= self.SKINNY_MAX_N
+        if ksplit is None:
+            # enough K slices for ~2048 waves (a wave owns 32 rows, 16 for N > 112), at least 8 trips of 16 each
+            rows_per_wave = 16 if N > 112 else 32
+            row_waves = (M + rows_per_wave - 1) // rows_per_wave
+            ksplit = max(1, min((2048 + row_waves - 1) // row_waves, K // 128))
+        out = self.empty(M, N)
+        work = self.empty(ksplit * M * N) if ksplit > 1 else None
+        check(self.lib.basq_skinny_gemm_f64(_ptr(A), A.stride(0), 1 if trans else 0, M, K, _ptr(B), B.stride(0), N,
+                                            int(ksplit), _ptr(work), _ptr(out), self._stream()), "basq_skinny_gemm_f64")
+        return out
+
     # -- host <-> device staging through cached pinned buffers (per-round 160 KB / 80 KB / 0.4 KB copies) ---------
     def _pinned(self, shape, dtype, tag):
         cache = self.__dict__.setdefault("_pin_cache", {})

@@ -843,6 +843,96 @@ __global__ void __launch_bounds__(256) gemm_kernel(const double* __restrict__ A,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tall-skinny f64 MFMA GEMM for the range finder (torch.svd_lowrank, BASQ/_rchq.py:29: A Q, A^T Q, Q^T A, X^T X with
+// A the [m, m] Nystrom Gram matrix and only q + 1 <= 208 columns on the other side):
+//     Cpart[z][M, N] = sum over K slice z of  op(A)[M, K] @ B[K, N],   op(A) = A ([M, K] row-major) or A^T (A is [K, M]).
+// A wave owns 16 JT rows and ALL N columns (NT tiles of 16): its A fragments are read from HBM exactly once per launch,
+// B (a few MB) comes from L2; per 16-k trip 4 JT + 4 NT loads feed 4 JT NT MFMAs, so the kernel runs at the matrix
+// pipe's rate.  A row-major: lane (c, g) reads A[row c][k + 4 g .. + 3] -- one 128-byte line per row and trip -- and the
+// k index of MFMA step u is k + 4 g + u (any order of the contraction index is a valid order, B is read to match).
+// Split K over blockIdx.y; the slabs are added in slice order by sum_parts_kernel (fixed summation order).
+// ------------------------------------------------------------------------------------------------
+template <int NT, int JT, bool TRANS>
+__global__ void __launch_bounds__(256) skinny_gemm_kernel(const double* __restrict__ A, long long lda,
+                                                          const double* __restrict__ B, long long ldb,
+                                                          double* __restrict__ C, long long ldc, long long cstride, int M,
+                                                          int N, int K, int kslice) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int r0 = (blockIdx.x * 4 + wave) * (16 * JT);
+    if (r0 >= M) return;
+    const int k0 = blockIdx.y * kslice;
+    int k1 = k0 + kslice;
+    if (k1 > K) k1 = K;
+    long long aoff[JT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        int r = r0 + jt * 16 + c;
+        if (r >= M) r = M - 1;
+        aoff[jt] = TRANS ? (long long)r : (long long)r * lda;
+    }
+    int bcol[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bcol[nt] = (nt * 16 + c < N) ? (nt * 16 + c) : (N - 1);
+    d4 acc[JT][NT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[jt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int k = k0; k < k1; k += 16) {
+        double av[4][JT];
+        int kg[4];
+        bool kin[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            kg[u] = TRANS ? (k + 4 * u + g) : (k + 4 * g + u);
+            kin[u] = kg[u] < k1;
+            if (!kin[u]) kg[u] = k1 - 1;                       // keep the address valid, zero the operand
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                const double v = TRANS ? A[(long long)kg[u] * lda + aoff[jt]] : A[aoff[jt] + kg[u]];
+                av[u][jt] = kin[u] ? v : 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            double bv[NT];
+            const double* bp = B + (long long)kg[u] * ldb;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = bp[bcol[nt]];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+                    acc[jt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][jt], bv[nt], acc[jt][nt], 0, 0, 0);
+        }
+    }
+    double* Cz = C + (long long)blockIdx.y * cstride;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if (nt * 16 + c >= N) continue;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = r0 + jt * 16 + g + 4 * r;
+                if (row < M) Cz[(long long)row * ldc + nt * 16 + c] = acc[jt][nt][r];
+            }
+    }
+}
+
+template <int NT, int JT>
+static void launch_skinny(bool trans, dim3 grid, hipStream_t st, const double* A, long long lda, const double* B,
+                          long long ldb, double* C, long long ldc, long long cstride, int M, int N, int K, int kslice) {
+    if (trans)
+        hipLaunchKernelGGL((skinny_gemm_kernel<NT, JT, true>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, cstride, M, N,
+                           K, kslice);
+    else
+        hipLaunchKernelGGL((skinny_gemm_kernel<NT, JT, false>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, cstride, M, N,
+                           K, kslice);
+}
+
 // Xsum[e] = sum_c Xpart[c][e]  (chunk order): one streaming pass instead of one GEMM per chunk partial
 __global__ void chunk_sum_kernel(const double* __restrict__ Xpart, long long n, int n_chunks, double* __restrict__ Xsum) {
     const long long e = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
@@ -3455,6 +3545,39 @@ int basq_trsm_rows_f64(const double* X, int64_t ldx, int64_t rows, int32_t q, co
     hipLaunchKernelGGL(trsm_rows_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(512), lds, (hipStream_t)stream, X,
                        (long long)ldx, (long long)rows, q, L, Q, (long long)ldq);
     BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_skinny_gemm_f64(const double* A, int64_t lda, int32_t trans, int32_t M, int32_t K, const double* B, int64_t ldb,
+                         int32_t N, int32_t ksplit, double* work, double* C, void* stream) {
+    if (!A || !B || !C || M < 1 || N < 1 || K < 1 || ksplit < 1 || ldb < N) return BASQ_EINVAL;
+    if (lda < (trans ? M : K)) return BASQ_EINVAL;
+    if (N > 208) return BASQ_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    int kslice = (K + ksplit - 1) / ksplit;
+    kslice = ((kslice + 15) / 16) * 16;                          // whole 16-k trips per slice
+    const int nz = (K + kslice - 1) / kslice;
+    if (nz > 1 && !work) return BASQ_EINVAL;
+    double* out = (nz > 1) ? work : C;
+    const long long cstride = (long long)M * N;
+    const int nt = (N + 15) / 16;
+    // rows per wave: 32 while the accumulators (4 NT JT doubles) leave room for two waves per SIMD, 16 for wide outputs
+    if (nt <= 4) {
+        dim3 grid((unsigned)((M + 127) / 128), (unsigned)nz);
+        launch_skinny<4, 2>(trans != 0, grid, st, A, lda, B, ldb, out, N, cstride, M, N, K, kslice);
+    } else if (nt <= 7) {
+        dim3 grid((unsigned)((M + 127) / 128), (unsigned)nz);
+        launch_skinny<7, 2>(trans != 0, grid, st, A, lda, B, ldb, out, N, cstride, M, N, K, kslice);
+    } else {
+        dim3 grid((unsigned)((M + 63) / 64), (unsigned)nz);
+        launch_skinny<13, 1>(trans != 0, grid, st, A, lda, B, ldb, out, N, cstride, M, N, K, kslice);
+    }
+    BASQ_CHECK_LAUNCH();
+    if (nz > 1) {
+        const long long n = cstride;
+        hipLaunchKernelGGL(sum_parts_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, work, nz, n, C);
+        BASQ_CHECK_LAUNCH();
+    }
     return BASQ_OK;
 }
 

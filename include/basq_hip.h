@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BASQ_ABI_VERSION 4
+#define BASQ_ABI_VERSION 5
 
 /* error codes */
 #define BASQ_OK            0
@@ -290,6 +290,16 @@ int basq_chol_inv_f64(double* G, int32_t q, double* W, int32_t* info, double rel
 int basq_chol_factor_f64(double* G, int32_t q, int32_t* info, double rel_tol, void* stream);
 int basq_trsm_rows_f64(const double* X, int64_t ldx, int64_t rows, int32_t q, const double* L, double* Q, int64_t ldq,
                        void* stream);
+
+/*
+ * The big products of the randomised range finder (torch.svd_lowrank -> torch._lowrank.get_approximate_basis,
+ * BASQ/_rchq.py:29: A @ R, A^H @ Q, A @ Q, Q^H @ A, and the Gram products X^T X of the orthonormalisations) as a
+ * tall-skinny f64 MFMA GEMM:  C[M, N] = op(A) @ B[K, N],  op(A) = A[M, K] (trans = 0) or A^T with A stored [K, M]
+ * (trans != 0), all row-major, N <= 208.  K is split into `ksplit` slices of whole 16-k trips; their partial products go to
+ * work [>= ksplit * M * N] and are added in slice order (work may be NULL when one slice results).  C is dense (ld = N).
+ */
+int basq_skinny_gemm_f64(const double* A, int64_t lda, int32_t trans, int32_t M, int32_t K, const double* B, int64_t ldb,
+                         int32_t N, int32_t ksplit, double* work, double* C, void* stream);
 
 /* Dense f64 GEMM on the matrix cores: C[M,N] = alpha * A[M,K] @ B[K,N] (row-major, lda/ldb/ldc). */
 int basq_gemm_f64(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, int32_t M,

@@ -584,3 +584,26 @@ def test_project_chunks_and_sum_parts_vs_standin(hip_ops, q, m, S, n_chunks):
     plain = hip_ops.project(dev(U), q, m, dev(X), dev(t), n_chunks, S, 1.7).cpu()
     assert (total - plain).abs().max().item() <= 1e-12 * scale
     assert (total - cpu.sum_parts(Mc)).abs().max().item() <= 1e-12 * scale
+
+
+@pytest.mark.parametrize("M,K,N,trans,ksplit", [
+    (1000, 3000, 99, False, None),       # the range finder's shape class: A Q
+    (1000, 3000, 99, True, None),        # A^T Q from the stored A
+    (99, 5000, 99, True, 31),            # Gram product X^T X of the orthonormalisation, many K slices
+    (777, 1003, 199, False, 4),          # 13 column tiles, K not a multiple of 16, ragged rows
+    (650, 333, 33, True, 1),             # few columns, one slice
+    (130, 99, 99, False, 1),             # K shorter than the output (the final U = Q Ub)
+    (64, 17, 208, False, 1),             # widest supported output, one partial trip
+])
+def test_skinny_gemm_vs_torch(hip_ops, M, K, N, trans, ksplit):
+    """The tall-skinny f64 MFMA GEMM of the range finder against torch's matmul (row strides exercised)."""
+    A = _rand(K if trans else M, M if trans else K, 71)
+    B = _rand(K, N, 72)
+    want = (A.t() if trans else A) @ B
+    Aw = hip_ops.zeros(A.shape[0], A.shape[1] + 3)           # row-strided views of wider buffers
+    Aw[:, :A.shape[1]] = hip_ops.to_device(A)
+    Bw = hip_ops.zeros(K, N + 5)
+    Bw[:, :N] = hip_ops.to_device(B)
+    got = hip_ops.skinny_gemm(Aw[:, :A.shape[1]], Bw[:, :N], trans=trans, ksplit=ksplit).cpu()
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() <= 1e-13 * K ** 0.5 * max(1.0, want.abs().max().item())
