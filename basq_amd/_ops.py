@@ -1,8 +1,8 @@
 """Device operations of the recombination engine: thin, checked wrappers over the C ABI.
 
 Every method takes/returns torch tensors that live on one HIP device; torch is used only
-for memory, streams and (for now) the five tall-skinny GEMMs of the randomised SVD
-(rocBLAS through ``torch.matmul``).  All pairwise-kernel work, the Nystrom contraction,
+for memory, streams and a few small dense products outside the per-batch loop (posterior set-up).
+All pairwise-kernel work, the range finder's tall-skinny GEMMs, the Nystrom contraction,
 the elimination and the compaction run in ``libbasq_hip.so``.
 
 The engine (``_engine.py``) is written against this interface so that the CPU tests can
@@ -12,6 +12,7 @@ drive its host logic (sharding, offsets, collectives) with a stand-in defined un
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -23,6 +24,7 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+HOST_SPIN_WAIT = os.environ.get("BASQ_SPIN_WAIT", "1") != "0"   # to_host: poll an event instead of a blocking stream wait
 PROJECT_KSPLIT_MAX = 48          # K slices of the projection GEMM (A/B: tools/ab_engine.py --module _ops)
 
 
@@ -354,6 +356,15 @@ class HipOps:
 
     SKINNY_MAX_N = 208               # widest output of basq_skinny_gemm_f64 (13 column tiles)
 
+    @staticmethod
+    def _skinny_ksplit(M, K, N):
+        """K slices for ``basq_skinny_gemm_f64``: ~5000 waves per launch (2.5 per wave slot of the chip at two waves per
+        SIMD -- the measured optimum at both range-finder shapes, profiles/r02_d_skinny_gemm_sweep.txt: 16 slices at
+        q = 99, 8 at q = 199), slices of at least ten 16-k trips."""
+        rows_per_wave = 16 if N > 112 else 32
+        row_waves = (M + rows_per_wave - 1) // rows_per_wave
+        return max(1, min(round(5000 / row_waves), K // 160))
+
     def skinny_gemm(self, A, B, trans=False, ksplit=None):
         """``A @ B`` (``trans``: ``A.T @ B``) for a skinny ``B [K, N <= 208]`` on the hand-written f64 MFMA kernel
         (``basq_skinny_gemm_f64``): the range finder's products.  ``A``, ``B`` row-major (row strides free)."""
@@ -363,10 +374,7 @@ class HipOps:
         N = B.shape[1]
         assert B.shape[0] == K and N <= self.SKINNY_MAX_N
         if ksplit is None:
-            # enough K slices for ~2048 waves (a wave owns 32 rows, 16 for N > 112), at least 8 trips of 16 each
-            rows_per_wave = 16 if N > 112 else 32
-            row_waves = (M + rows_per_wave - 1) // rows_per_wave
-            ksplit = max(1, min((2048 + row_waves - 1) // row_waves, K // 128))
+            ksplit = self._skinny_ksplit(M, K, N)
         out = self.empty(M, N)
         work = self.empty(ksplit * M * N) if ksplit > 1 else None
         check(self.lib.basq_skinny_gemm_f64(_ptr(A), A.stride(0), 1 if trans else 0, M, K, _ptr(B), B.stride(0), N,
@@ -388,7 +396,18 @@ class HipOps:
         the same tag and shape: consume it before then."""
         buf = self._pinned(t.shape, t.dtype, tag)
         buf.copy_(t, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
+        stream = torch.cuda.current_stream(self.device)
+        if HOST_SPIN_WAIT:
+            # The per-round read-back sits on the critical path (the next round's launches need it): poll an event
+            # instead of a blocking stream wait, whose wake-up costs more than the 1.6-KB copy it waits for.
+            ev = self.__dict__.get("_spin_event")
+            if ev is None:
+                ev = self.__dict__["_spin_event"] = torch.cuda.Event()
+            ev.record(stream)
+            while not ev.query():
+                pass
+        else:
+            stream.synchronize()
         return buf
 
     def to_host_async(self, t, tag="d2h"):

@@ -880,33 +880,66 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(const double* __restri
     for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[jt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int k = k0; k < k1; k += 16) {
-        double av[4][JT];
-        int kg[4];
-        bool kin[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            kg[u] = TRANS ? (k + 4 * u + g) : (k + 4 * g + u);
-            kin[u] = kg[u] < k1;
-            if (!kin[u]) kg[u] = k1 - 1;                       // keep the address valid, zero the operand
+    // contraction index of MFMA step u of the trip that starts at k, for this lane's group g
+    auto kidx = [&](int k, int u) { return TRANS ? (k + 4 * u + g) : (k + 4 * g + u); };
+    // Software pipeline: the A fragments of the NEXT trip (HBM latency) and the B fragments of the NEXT step (L2 latency)
+    // are requested before the current step's MFMAs are issued.  Out-of-range k: the address is clamped to the slice's
+    // last row and the A operand zeroed (B stays finite, the product vanishes).
+    // row-major A: a lane's four k indices are 32 contiguous bytes -- two 16-byte loads when the rows are 16-byte aligned
+    const bool a_vec = !TRANS && ((lda & 1) == 0) && (((uintptr_t)A & 15) == 0);
+    auto load_a = [&](int k, double (&av)[4][JT]) {
+        if (!TRANS && a_vec && k + 16 <= k1) {                  // wave-uniform
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
-                const double v = TRANS ? A[(long long)kg[u] * lda + aoff[jt]] : A[aoff[jt] + kg[u]];
-                av[u][jt] = kin[u] ? v : 0.0;
+                const double2* p = reinterpret_cast<const double2*>(A + aoff[jt] + k + 4 * g);
+                const double2 lo = p[0], hi = p[1];
+                av[0][jt] = lo.x;
+                av[1][jt] = lo.y;
+                av[2][jt] = hi.x;
+                av[3][jt] = hi.y;
             }
+            return;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            double bv[NT];
-            const double* bp = B + (long long)kg[u] * ldb;
+            const int kk = kidx(k, u);
+            const int kc = (kk < k1) ? kk : (k1 - 1);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = bp[bcol[nt]];
+            for (int jt = 0; jt < JT; ++jt) {
+                const double v = TRANS ? A[(long long)kc * lda + aoff[jt]] : A[aoff[jt] + kc];
+                av[u][jt] = (kk < k1) ? v : 0.0;
+            }
+        }
+    };
+    auto load_b = [&](int k, int u, double (&bv)[NT]) {
+        const int kk = kidx(k, u);
+        const double* bp = B + (long long)((kk < k1) ? kk : (k1 - 1)) * ldb;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[nt] = bp[bcol[nt]];
+    };
+    double av[4][JT], bv[NT];
+    load_a(k0, av);
+    load_b(k0, 0, bv);
+    for (int k = k0; k < k1; k += 16) {
+        double avn[4][JT];
+        load_a(k + 16, avn);                                   // past the slice on the last trip: clamped, unused
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            double bvn[NT];
+            if (u < 3) load_b(k, u + 1, bvn);
+            else load_b(k + 16, 0, bvn);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
                     acc[jt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][jt], bv[nt], acc[jt][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = bvn[nt];
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) av[u][jt] = avn[u][jt];
     }
     double* Cz = C + (long long)blockIdx.y * cstride;
 #pragma unroll
