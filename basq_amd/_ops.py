@@ -12,7 +12,6 @@ drive its host logic (sharding, offsets, collectives) with a stand-in defined un
 from __future__ import annotations
 
 import ctypes as C
-import os
 
 import torch
 
@@ -24,7 +23,6 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-HOST_SPIN_WAIT = os.environ.get("BASQ_SPIN_WAIT", "1") != "0"   # to_host: poll an event instead of a blocking stream wait
 PROJECT_KSPLIT_MAX = 48          # K slices of the projection GEMM (A/B: tools/ab_engine.py --module _ops)
 
 
@@ -396,18 +394,8 @@ class HipOps:
         the same tag and shape: consume it before then."""
         buf = self._pinned(t.shape, t.dtype, tag)
         buf.copy_(t, non_blocking=True)
-        stream = torch.cuda.current_stream(self.device)
-        if HOST_SPIN_WAIT:
-            # The per-round read-back sits on the critical path (the next round's launches need it): poll an event
-            # instead of a blocking stream wait, whose wake-up costs more than the 1.6-KB copy it waits for.
-            ev = self.__dict__.get("_spin_event")
-            if ev is None:
-                ev = self.__dict__["_spin_event"] = torch.cuda.Event()
-            ev.record(stream)
-            while not ev.query():
-                pass
-        else:
-            stream.synchronize()
+        # (polling an event instead of this blocking wait was tried: no measurable difference, 41.5 vs 41.6 batches/s)
+        torch.cuda.current_stream(self.device).synchronize()
         return buf
 
     def to_host_async(self, t, tag="d2h"):
