@@ -256,6 +256,7 @@ LATE_CHUNKS = 1                  # chunks of the round-1 block sums deferred beh
 # the blocks beyond a multiple of C and the ragged tail (< (C + 1) * S points, halving every round) are evaluated directly.
 BASIS_SIDE_STREAM = False        # one rank: range finder on a second stream beside the round-1 block sums (A/B on MI355X: 25.6 vs 24.6 ms -- off)
 CLASS_SUMS = True
+ASYNC_ROUNDS = True              # one rank, plain block sums: rounds driven by a device-resident descriptor, no host wait per round
 MAX_CLASSES = 16                 # classes at the start of an epoch (power of two): 16 -> the kernel runs in rounds 1, 6, 11
 
 
@@ -511,7 +512,7 @@ class RecombinationEngine:
             self.ops.unpin_stream()
 
     def _run(self, pts_local, gid0: int, n_total: int, pts_nys, num_pts: int, kernel, trace: EngineTrace | None = None,
-             variant: str = "basq", init_weights=None, objective=None):
+             variant: str = "basq", init_weights=None, objective=None, _async_allowed: bool = True):
         """Recombine.  ``pts_local`` = this rank's contiguous slice ``[gid0, gid0 + len)`` of the pool.
 
         ``variant="basq"`` follows ``BASQ/_rchq.py`` (uniform start weights, ``init_weights`` ignored);
@@ -530,6 +531,7 @@ class RecombinationEngine:
         if variant not in ("basq", "sober"):
             raise ValueError(variant)
         sober = variant == "sober"
+        rng_state = torch.get_rng_state() if (ASYNC_ROUNDS and _async_allowed and trace is None) else None
         if n_total >= 2 ** 31:
             raise ValueError("pool sizes >= 2^31 are not supported")
         if n_total == 0:                                        # empty pool: nothing to select (the reference returns [])
@@ -738,6 +740,83 @@ class RecombinationEngine:
             if trace.host_sync:
                 ops.synchronize()
             trace.add_time("setup", time.perf_counter() - t0)
+
+        # ---- rounds without a host round trip (one rank, plain block sums) ----------------------------------
+        # The survivor count of a round depends on the data through two facts only (how many sets were kept, whether
+        # the last set -- owner of the ragged tail -- is one of them), so the next round's geometry is a closed form a
+        # one-thread kernel evaluates into a device-resident descriptor; every launch of the round reads its candidate
+        # range from there.  The host enqueues all rounds that are CERTAINLY not the final one (lower bound of the
+        # survivor count > S) without waiting, then reads the descriptor once and finishes round by round below.
+        if (ASYNC_ROUNDS and trace is None and comm.world == 1 and not opaque and not sober and obj_full is None
+                and warp != "wsabim" and diag_noise == 0.0 and hasattr(ops, "round_next") and R > S and _async_allowed):
+            n_keep_exp = s                                       # a regular round keeps s = S/2 sets
+            geo_t = ops.geo_init(64, R, S, (pre[4] * S) if (pre is not None and pre[3] >= 2) else 0)
+            r = 0
+            R_lo = R_up = R
+            plan_C = None                                        # classes planned for a fresh evaluation (set below)
+            while R_lo > S:
+                g_row = geo_t[r]
+                Mc, C_cur, parts = None, 1, None
+                if cls is not None:                              # inside an epoch: regrouped class messages + the rest
+                    Mc, C_cur = cls["M"], cls["C"]
+                    Xirr, totirr = ops.empty(1, m_ext, S), ops.empty(1, S)
+                    ops.blocksum_geo(spec, nys_ext, m_ext, cand, mu, wx, g_row, 2, S, 1, out=(Xirr, totirr))
+                    ops.project_chunks(U_ext, q_ext, m_ext, Xirr, totirr, 1, S, kscale, out=Mc[C_cur:C_cur + 1])
+                    parts = Mc
+                else:
+                    if pre is not None:                          # round 1: launched before the basis, host geometry
+                        Xpart, totpart, n_chunks, C_cur = pre[:4]
+                        pre = None
+                    else:
+                        C_cur = plan_C if plan_C is not None else 1
+                        if C_cur >= 2:
+                            n_chunks = C_cur + 1
+                            Xpart, totpart = ops.empty(n_chunks, m_ext, S), ops.empty(n_chunks, S)
+                            ops.blocksum_geo(spec, nys_ext, m_ext, cand, mu, wx, g_row, 1, S, C_cur,
+                                             out=(Xpart[:C_cur], totpart[:C_cur]), class_mod=C_cur)
+                            ops.blocksum_geo(spec, nys_ext, m_ext, cand, mu, wx, g_row, 2, S, 1,
+                                             out=(Xpart[C_cur:], totpart[C_cur:]))
+                        else:
+                            n_chunks = choose_chunks(R_lo // S, m_ext, S, kp // 4)
+                            Xpart, totpart = ops.blocksum_geo(spec, nys_ext, m_ext, cand, mu, wx, g_row, 3, S, n_chunks)
+                    if C_cur >= 2:
+                        Mc = ops.project_chunks(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S, kscale)
+                        parts = Mc
+                    else:
+                        parts = ops.project(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S, kscale).unsqueeze(0)
+                    del Xpart, totpart
+                XcarT, tot = ops.finalize(parts, parts.shape[0], parts.shape[1], q, S, None, m, min(m, S), 0.0, 0, 0, 0)
+                PhiT = ops.nullspace(XcarT, s, S)
+                keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, tot.clone(), S, s)
+                cls = None
+                if Mc is not None and C_cur >= 2:
+                    Mn = ops.empty(C_cur // 2 + 1, Mc.shape[1], S)
+                    ops.regroup_classes(Mc[:C_cur], kept, w_star, tot, out=Mn[:C_cur // 2])
+                    cls = dict(M=Mn, C=C_cur // 2, reg_blocks=None)
+                # bounds of the next survivor count; the class plan of the next fresh evaluation follows the lower one
+                R_lo_n = (R_lo // S) * n_keep_exp
+                R_up_n = (R_up // S) * n_keep_exp + (S - 1)
+                plan_C = None
+                if cls is None:
+                    plan_C = _classes_for(R_lo_n // S, m_ext, S, kp // 4) if use_classes else 1
+                ops.round_next(g_row, info, keep_rank, S, -1 if cls is not None else (plan_C if plan_C >= 2 else 0),
+                               True, geo_t[r + 1])
+                cand, mu, gid, wx = ops.reweight_compact_geo(cand, mu, gid, wx, g_row, info, R_up, S, kp, keep_rank,
+                                                             w_star, tot, R_up_n)
+                r += 1
+                R_lo, R_up = R_lo_n, R_up_n
+            row = ops.to_host(geo_t[r], "geo_row").tolist()      # the ONE wait of the asynchronous rounds
+            if row[3] != 0:
+                # an elimination failed or did not keep half of the sets: regrouped messages may be invalid -- repeat
+                # the batch with one read-back per round (same generator state, same results as that path alone)
+                torch.set_rng_state(rng_state)
+                return self._run(pts_local, gid0, n_total, pts_nys, num_pts, kernel, trace, variant, init_weights,
+                                 objective, _async_allowed=False)
+            R = Rl = int(row[0])
+            if cls is not None:
+                cls["reg_blocks"] = int(row[2]) // S
+            elif plan_C is not None and plan_C >= 2:
+                pass                                             # the next fresh evaluation re-plans from the exact R
 
         # ---- rounds -------------------------------------------------------------------------------------
         while True:

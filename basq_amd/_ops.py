@@ -244,6 +244,46 @@ class HipOps:
               "basq_reweight_compact_f64")
         return cand_o, mu_o, gid_o, wx_o
 
+    # -- device-resident round descriptors (basq_round_next_i64 and the *_geo entries) -----------------------------
+    def geo_init(self, n_rounds, R, S, reg_hi):
+        """Descriptor table ``[n_rounds, 8]`` (int64, device) with row 0 = the first round's geometry."""
+        nb = R // S
+        host = self._pinned((n_rounds, 8), torch.int64, "geo")
+        host.zero_()
+        host[0, 0], host[0, 1], host[0, 2], host[0, 4], host[0, 5] = R, nb * S, reg_hi, nb, R - nb * S
+        return host.to(self.device, non_blocking=True)
+
+    def round_next(self, geo_row, info, keep_rank, S, class_mode, expect_half, geo_next):
+        check(self.lib.basq_round_next_i64(_ptr(geo_row), _ptr(info), _ptr(keep_rank), S, int(class_mode),
+                                           1 if expect_half else 0, _ptr(geo_next), self._stream()), "basq_round_next_i64")
+
+    def blocksum_geo(self, spec, nys, m, cand, mu, wx, geo_row, mode, S, n_chunks, out=None, class_mod=0, class0=0):
+        """``blocksum`` with the candidate range read from a round descriptor (``mode`` 1: regular region, 2: the rest,
+        3: everything)."""
+        if out is None:
+            Xpart, totpart = self.empty(n_chunks, m, S), self.empty(n_chunks, S)
+        else:
+            Xpart, totpart = out
+            assert Xpart.is_contiguous() and totpart.is_contiguous()
+            assert tuple(Xpart.shape) == (n_chunks, m, S) and tuple(totpart.shape) == (n_chunks, S)
+        sc = self.spec_c(spec)
+        check(self.lib.basq_blocksum_geo_f64(C.byref(sc), _ptr(nys), m, _ptr(cand), _ptr(mu), _ptr(wx), _ptr(geo_row),
+                                             int(mode), S, n_chunks, int(class_mod), int(class0), _ptr(Xpart),
+                                             _ptr(totpart), self._stream()), "basq_blocksum_geo_f64")
+        return Xpart, totpart
+
+    def reweight_compact_geo(self, cand, mu, gid, wx, geo_row, info, R_max, S, kp, keep_rank, w_star, tot, out_rows):
+        """``reweight_compact`` on one rank with the counts read from the descriptor; outputs sized ``out_rows``."""
+        cand_o = self.empty(max(out_rows, 1), kp)
+        mu_o = self.empty(max(out_rows, 1))
+        gid_o = self.empty(max(out_rows, 1), dtype=torch.int64)
+        wx_o = self.empty(max(out_rows, 1)) if wx is not None else None
+        check(self.lib.basq_reweight_compact_geo_f64(_ptr(cand), _ptr(mu), _ptr(gid), _ptr(wx), _ptr(geo_row), _ptr(info),
+                                                     int(R_max), S, kp, _ptr(keep_rank), _ptr(w_star), _ptr(tot),
+                                                     _ptr(cand_o), _ptr(mu_o), _ptr(gid_o), _ptr(wx_o), self._stream()),
+              "basq_reweight_compact_geo_f64")
+        return cand_o, mu_o, gid_o, wx_o
+
     def init_state(self, Rl, gid0, n_total):
         mu = self.empty(max(Rl, 1))
         gid = self.empty(max(Rl, 1), dtype=torch.int64)

@@ -261,7 +261,40 @@ struct BlocksumArgs {
     long long blk_lo, blk_hi, blk_per_chunk;   // global block-index range touched by this rank
     int class_mod, class0;                     // > 0: chunk c = the blocks b with b % class_mod == class0 + c (residue classes)
     int m, S, n_chunks, n_stiles, n_jgroups;
+    // Device-resident round descriptor (basq_round_next_i64): when set, the candidate range comes from HBM instead of the
+    // launch arguments, so the host can enqueue a round before it knows how many candidates survived the previous one.
+    const long long* geo;                      // {R, n_full, reg_hi, violation, nb, n_tail, -, -}
+    int geo_mode;                              // 1: positions [0, reg_hi)   2: [reg_hi, R)   3: [0, R)
 };
+
+// Candidate range of a descriptor-driven launch (wave-uniform scalar loads and arithmetic; the formulas of blocksum_impl).
+template <int KP>
+__device__ __forceinline__ void blocksum_apply_geo(BlocksumArgs& A) {
+    const long long R = A.geo[0], n_full = A.geo[1], reg_hi = A.geo[2];
+    long long off = 0, Rl = R;
+    if (A.geo_mode == 1) {
+        Rl = reg_hi;
+    } else if (A.geo_mode == 2) {
+        off = reg_hi;
+        Rl = R - reg_hi;
+        A.cand += reg_hi * KP;
+        A.mu += reg_hi;
+        if (A.wx) A.wx += reg_hi;
+    }
+    A.off = off;
+    A.Rl = Rl;
+    A.n_full = n_full;
+    const long long lim = (off + Rl < n_full) ? (off + Rl) : n_full;
+    if (lim > off) {
+        A.blk_lo = off / A.S;
+        A.blk_hi = (lim + A.S - 1) / A.S;
+    } else {
+        A.blk_lo = 0;
+        A.blk_hi = 0;
+    }
+    A.blk_per_chunk = (A.blk_hi - A.blk_lo + A.n_chunks - 1) / A.n_chunks;
+    if (A.blk_per_chunk < 1) A.blk_per_chunk = 1;
+}
 
 template <int KK>
 struct CandFrag {
@@ -297,8 +330,10 @@ __device__ __forceinline__ void tile_accumulate(const double (&a)[JT][KK], const
 }
 
 template <int KK, int FAM, int JT>
-__global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A) {
+__global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A_in) {
     constexpr int KP = KK * 4;
+    BlocksumArgs A = A_in;
+    if (A.geo) blocksum_apply_geo<KP>(A);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     // XCD-aware work-group -> tile map.  Work-groups are dealt round-robin over the 8 XCDs (blockIdx.x % 8), each with
@@ -2480,6 +2515,73 @@ __global__ void reweight_compact_kernel(const double* __restrict__ cand, const d
     }
 }
 
+// Descriptor-driven form (single rank): the candidate count, the block geometry and the number of kept sets are read
+// from device memory (round descriptor + the elimination's info word), the grid is sized for an upper bound.
+__global__ void reweight_compact_geo_kernel(const double* __restrict__ cand, const double* __restrict__ mu,
+                                            const long long* __restrict__ gid, const double* __restrict__ wx,
+                                            const long long* __restrict__ geo, const int* __restrict__ info, int S, int kp,
+                                            const int* __restrict__ keep_rank, const double* __restrict__ w_star,
+                                            const double* __restrict__ tot, double* __restrict__ cand_out,
+                                            double* __restrict__ mu_out, long long* __restrict__ gid_out,
+                                            double* __restrict__ wx_out) {
+#pragma clang fp contract(off)
+    const long long Rl = geo[0], n_full = geo[1];
+    const int n_keep = info[0];
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Rl * kp) return;
+    const long long pg = t / kp;
+    const int k = (int)(t - pg * kp);
+    int set;
+    long long dst;
+    if (pg < n_full) {
+        const long long blk = pg / S;
+        set = (int)(pg - blk * S);
+        dst = blk * n_keep;
+    } else {
+        set = S - 1;
+        dst = (n_full / S) * n_keep + (pg - n_full);
+    }
+    const int kr = keep_rank[set];
+    if (kr < 0) return;
+    if (pg < n_full) dst += kr;
+    cand_out[dst * kp + k] = cand[t];
+    if (k == 0) {
+        const double scaled = mu[pg] * w_star[kr];                         // :113-114 / :121-122
+        mu_out[dst] = scaled / tot[set];
+        gid_out[dst] = gid[pg];
+        if (wx) wx_out[dst] = wx[pg];
+    }
+}
+
+// Next round's descriptor from this round's outcome (BASQ/_rchq.py:107-130 in closed form, basq_amd/_partition.py):
+//   R' = nb * n_keep + (n_tail if set S-1 survived);  class_mode > 0: a fresh evaluation with that many residue classes
+//   (regular region = the largest multiple of class_mode blocks), -1: the classes are inherited (regular region halves),
+//   0: no classes.  Sticky violation flag: the elimination failed (status) or did not keep exactly half of the sets
+//   while the host had already enqueued a regrouping that relies on it -- the host then repeats the batch round by round.
+__global__ void round_next_kernel(const long long* __restrict__ gp, const int* __restrict__ info,
+                                  const int* __restrict__ keep_rank, int S, int class_mode, int expect_half,
+                                  long long* __restrict__ gn) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const long long R = gp[0], n_full = gp[1];
+    const long long nb = n_full / S, n_tail = R - n_full;
+    const int n_keep = info[0], status = info[1];
+    long long viol = gp[3];
+    if (status != 0 || (expect_half && 2 * n_keep != S)) viol = 1;
+    const long long Rn = nb * n_keep + ((keep_rank[S - 1] >= 0) ? n_tail : 0);
+    const long long nbn = Rn / S;
+    long long reg_blocks = 0;
+    if (class_mode > 0) reg_blocks = (nbn / class_mode) * class_mode;
+    else if (class_mode < 0) reg_blocks = (gp[2] / S) / 2;
+    gn[0] = Rn;
+    gn[1] = nbn * S;
+    gn[2] = reg_blocks * S;
+    gn[3] = viol;
+    gn[4] = nbn;
+    gn[5] = Rn - nbn * S;
+    gn[6] = 0;
+    gn[7] = 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Small dense Cholesky + triangular inverse, one work-group, in place in global memory (L2-resident):
 // G (SPD, q x q) -> L in the lower triangle;  W = L^{-T} (upper triangular), so that for X with
@@ -3147,6 +3249,7 @@ static int blocksum_impl(const basq_kernel_spec* spec, const double* nys, int32_
     A.nys = nys; A.cand = cand; A.mu = mu; A.wx = wx; A.Xpart = Xpart; A.totpart = totpart;
     A.Rl = Rl; A.off = off; A.n_full = n_full; A.m = m; A.S = S; A.n_chunks = n_chunks;
     A.class_mod = class_mod; A.class0 = class0;
+    A.geo = nullptr; A.geo_mode = 0;
     A.n_stiles = (S + 15) / 16;
     // global blocks that intersect [off, min(off+Rl, n_full))
     const long long lim = (off + Rl < n_full) ? (off + Rl) : n_full;
@@ -3184,6 +3287,7 @@ int basq_blocksum_sq_f64(const basq_kernel_spec* spec, const double* nys, int32_
     A.nys = nys; A.cand = cand; A.mu = mu; A.wx = nullptr; A.Xpart = Epart; A.totpart = nullptr;
     A.Rl = Rl; A.off = off; A.n_full = n_full; A.m = m; A.S = S; A.n_chunks = n_chunks;
     A.class_mod = 0; A.class0 = 0;
+    A.geo = nullptr; A.geo_mode = 0;
     A.n_stiles = (S + 15) / 16;
     const long long lim = (off + Rl < n_full) ? (off + Rl) : n_full;
     if (lim > off) {
@@ -3479,6 +3583,48 @@ int basq_reweight_compact_f64(const double* cand, const double* mu, const int64_
                        cand, mu, (const long long*)gid, wx, (long long)Rl, (long long)off, (long long)n_full, S, kp,
                        keep_rank, w_star, tot, n_keep, (long long)new_off, cand_out, mu_out, (long long*)gid_out,
                        wx_out);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_blocksum_geo_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
+                          const double* mu, const double* wx, const int64_t* geo, int32_t geo_mode, int32_t S,
+                          int32_t n_chunks, int32_t class_mod, int32_t class0, double* Xpart, double* totpart,
+                          void* stream) {
+    if (!spec_ok(spec) || !nys || !cand || !mu || !Xpart || !totpart || !geo) return BASQ_EINVAL;
+    if (m < 1 || S < 1 || n_chunks < 1 || geo_mode < 1 || geo_mode > 3) return BASQ_EINVAL;
+    if (class_mod < 0 || class0 < 0 || (class_mod > 0 && class0 + n_chunks > class_mod)) return BASQ_EINVAL;
+    if (class_mod > 0 && geo_mode != 1) return BASQ_EINVAL;       // residue classes cover the regular region only
+    BlocksumArgs A;
+    A.nys = nys; A.cand = cand; A.mu = mu; A.wx = wx; A.Xpart = Xpart; A.totpart = totpart;
+    A.Rl = 0; A.off = 0; A.n_full = 0; A.blk_lo = 0; A.blk_hi = 0; A.blk_per_chunk = 1;   // set on the device
+    A.m = m; A.S = S; A.n_chunks = n_chunks;
+    A.class_mod = class_mod; A.class0 = class0;
+    A.geo = (const long long*)geo; A.geo_mode = geo_mode;
+    A.n_stiles = (S + 15) / 16;
+    return dispatch_blocksum(basq_kp(spec->d) / 4, spec->family, A, (hipStream_t)stream);
+}
+
+int basq_reweight_compact_geo_f64(const double* cand, const double* mu, const int64_t* gid, const double* wx,
+                                  const int64_t* geo, const int32_t* info, int64_t R_max, int32_t S, int32_t kp,
+                                  const int32_t* keep_rank, const double* w_star, const double* tot, double* cand_out,
+                                  double* mu_out, int64_t* gid_out, double* wx_out, void* stream) {
+    if (!cand || !mu || !gid || !geo || !info || !keep_rank || !w_star || !tot || !cand_out || !mu_out || !gid_out)
+        return BASQ_EINVAL;
+    if (R_max < 1 || S < 1 || kp < 1 || (wx && !wx_out)) return BASQ_EINVAL;
+    const long long nt = (long long)R_max * kp;
+    hipLaunchKernelGGL(reweight_compact_geo_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       cand, mu, (const long long*)gid, wx, (const long long*)geo, info, S, kp, keep_rank, w_star, tot,
+                       cand_out, mu_out, (long long*)gid_out, wx_out);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_round_next_i64(const int64_t* geo, const int32_t* info, const int32_t* keep_rank, int32_t S, int32_t class_mode,
+                        int32_t expect_half, int64_t* geo_next, void* stream) {
+    if (!geo || !info || !keep_rank || !geo_next || S < 1) return BASQ_EINVAL;
+    hipLaunchKernelGGL(round_next_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const long long*)geo, info, keep_rank,
+                       S, class_mode, expect_half, (long long*)geo_next);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }

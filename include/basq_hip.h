@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BASQ_ABI_VERSION 5
+#define BASQ_ABI_VERSION 6
 
 /* error codes */
 #define BASQ_OK            0
@@ -222,6 +222,35 @@ int basq_reweight_compact_f64(const double* cand, const double* mu, const int64_
                               const int32_t* keep_rank, const double* w_star, const double* tot, int32_t n_keep,
                               int64_t new_off, double* cand_out, double* mu_out, int64_t* gid_out, double* wx_out,
                               void* stream);
+
+/*
+ * Device-resident round descriptor: the divide-and-conquer loop (BASQ/_rchq.py:76-130) without a host round trip per
+ * round.  The number of survivors of a round depends on the data only through two facts -- how many sets the elimination
+ * kept and whether the last set (which owns the ragged tail, :91-99) is among them -- so the next round's geometry is a
+ * closed form of the previous one (basq_amd/_partition.py) that a one-thread kernel can evaluate:
+ *   geo[8] = { R, n_full = (R / S) * S, reg_hi, violation, nb, n_tail, 0, 0 }        (int64)
+ *   basq_round_next_i64: R' = nb * n_keep + (n_tail if keep_rank[S-1] >= 0), n_keep / status from the elimination's
+ *       info word.  class_mode > 0: the next round evaluates its block sums afresh with that many residue classes
+ *       (reg_hi' = S * the largest multiple of class_mode blocks), -1: it inherits regrouped classes (the regular
+ *       region halves), 0: no classes.  violation is sticky: status != 0, or expect_half != 0 and 2 n_keep != S (the host
+ *       had already enqueued a regrouping that needs exactly half of the sets): the host then repeats the batch with
+ *       one read-back per round.
+ *   basq_blocksum_geo_f64: basq_blocksum_f64 with the candidate range taken from the descriptor -- geo_mode 1: positions
+ *       [0, reg_hi) (class_mod > 0 allowed), 2: [reg_hi, R) (pointers are advanced on the device), 3: [0, R).
+ *   basq_reweight_compact_geo_f64: basq_reweight_compact_f64 for one rank (off = new_off = 0) with Rl, n_full from the
+ *       descriptor and n_keep from info[0]; the launch is sized for R_max >= R candidates.
+ * Launch grids never depend on R; buffers are sized from host-side upper bounds.
+ */
+int basq_round_next_i64(const int64_t* geo, const int32_t* info, const int32_t* keep_rank, int32_t S, int32_t class_mode,
+                        int32_t expect_half, int64_t* geo_next, void* stream);
+int basq_blocksum_geo_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
+                          const double* mu, const double* wx, const int64_t* geo, int32_t geo_mode, int32_t S,
+                          int32_t n_chunks, int32_t class_mod, int32_t class0, double* Xpart, double* totpart,
+                          void* stream);
+int basq_reweight_compact_geo_f64(const double* cand, const double* mu, const int64_t* gid, const double* wx,
+                                  const int64_t* geo, const int32_t* info, int64_t R_max, int32_t S, int32_t kp,
+                                  const int32_t* keep_rank, const double* w_star, const double* tot, double* cand_out,
+                                  double* mu_out, int64_t* gid_out, double* wx_out, void* stream);
 
 /* Initial state: mu[p] = 1/N_total (BASQ/_rchq.py:53), gid[p] = gid0 + p (:55). */
 int basq_init_state_f64(double* mu, int64_t* gid, int64_t Rl, int64_t gid0, int64_t n_total, void* stream);

@@ -282,6 +282,47 @@ class CpuStandInOps:
             wx_o[d] = wx[:Rl][sel]
         return cand_o, mu_o, gid_o, wx_o
 
+    # device-resident round descriptors: on the CPU the table is simply read
+    def geo_init(self, n_rounds, R, S, reg_hi):
+        g = torch.zeros(n_rounds, 8, dtype=torch.int64)
+        nb = R // S
+        g[0, 0], g[0, 1], g[0, 2], g[0, 4], g[0, 5] = R, nb * S, reg_hi, nb, R - nb * S
+        return g
+
+    def round_next(self, geo_row, info, keep_rank, S, class_mode, expect_half, geo_next):
+        self._count("round_next")
+        R, n_full = int(geo_row[0]), int(geo_row[1])
+        nb, n_tail = n_full // S, R - n_full
+        n_keep, status = int(info[0]), int(info[1])
+        viol = int(geo_row[3])
+        if status != 0 or (expect_half and 2 * n_keep != S):
+            viol = 1
+        Rn = nb * n_keep + (n_tail if int(keep_rank[S - 1]) >= 0 else 0)
+        nbn = Rn // S
+        reg_blocks = (nbn // class_mode) * class_mode if class_mode > 0 else ((int(geo_row[2]) // S) // 2 if class_mode < 0 else 0)
+        geo_next[:] = torch.tensor([Rn, nbn * S, reg_blocks * S, viol, nbn, Rn - nbn * S, 0, 0], dtype=torch.int64)
+
+    def blocksum_geo(self, spec, nys, m, cand, mu, wx, geo_row, mode, S, n_chunks, out=None, class_mod=0, class0=0):
+        R, n_full, reg_hi = int(geo_row[0]), int(geo_row[1]), int(geo_row[2])
+        lo, hi = (0, reg_hi) if mode == 1 else ((reg_hi, R) if mode == 2 else (0, R))
+        return self.blocksum(spec, nys, m, cand[lo:], mu[lo:], None if wx is None else wx[lo:], hi - lo, lo, n_full, S,
+                             n_chunks, out=out, class_mod=class_mod, class0=class0)
+
+    def reweight_compact_geo(self, cand, mu, gid, wx, geo_row, info, R_max, S, kp, keep_rank, w_star, tot, out_rows):
+        R, n_full = int(geo_row[0]), int(geo_row[1])
+        n_keep = int(info[0])
+        new_R = (n_full // S) * n_keep + ((R - n_full) if int(keep_rank[S - 1]) >= 0 else 0)
+        c, u, g, w = self.reweight_compact(cand, mu, gid, wx, R, 0, n_full, S, kp, keep_rank, w_star, tot, n_keep, 0, new_R)
+
+        def grow(t):
+            if t is None:
+                return None
+            o = torch.zeros((max(out_rows, 1),) + tuple(t.shape[1:]), dtype=t.dtype)
+            o[:new_R] = t[:new_R]
+            return o
+
+        return grow(c), grow(u), grow(g), grow(w)
+
     def init_state(self, Rl, gid0, n_total):
         mu = torch.full((max(Rl, 1),), 1.0 / n_total, dtype=torch.float64)
         gid = gid0 + torch.arange(max(Rl, 1), dtype=torch.int64)

@@ -174,7 +174,12 @@ def test_sharded_range_finder_equals_dense(name, world):
     ops = CpuStandInOps()
     kern = build_product_kernel(c)
     torch.manual_seed(7)
-    Ud = nystrom_basis(ops, kern.dense(ops, nys, nys, ops.col_mean(nys)), c["n"] - 1)
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)        # as in the workers: a BLAS team that resizes under load re-associates the products
+    try:
+        Ud = nystrom_basis(ops, kern.dense(ops, nys, nys, ops.col_mean(nys)), c["n"] - 1)
+    finally:
+        torch.set_num_threads(nthreads)
     for rank, U, blk_err in res:
         assert blk_err == 0.0                                   # same entries as the full Gram, diagonal terms included
         assert torch.equal(U, res[0][1])                        # replicated steps agree bit for bit across ranks

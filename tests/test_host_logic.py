@@ -316,3 +316,42 @@ def test_make_cov_psd_follows_the_reference(kind):
     assert torch.allclose(got, want, rtol=0, atol=1e-15)
     if kind in ("duplicates", "indefinite"):
         assert (got.diagonal() > A.diagonal() + 5e-6).all()   # the repair really ran
+
+
+@pytest.mark.parametrize("N,d,n,m,seed", [
+    (120_000, 4, 20, 300, 3),       # 3000 blocks: 16 classes, two epochs, ragged tails on the way down
+    (50_321, 3, 16, 200, 4),        # ragged from round 1
+    (9_000, 5, 30, 120, 5),         # few blocks: small class counts / plain rounds
+    (700, 3, 25, 60, 6),            # one asynchronous round at most
+    (90, 2, 20, 30, 7),             # nothing asynchronous (pool of at most two reductions)
+])
+def test_descriptor_driven_rounds_equal_round_by_round(N, d, n, m, seed):
+    """The rounds enqueued without a host wait (device-resident descriptor: basq_round_next_i64 + the *_geo entries) select
+    the same batch as the loop with one read-back per round -- same indices, weights to rounding."""
+    import basq_amd._engine as eng
+    from basq_amd.kernels import StationaryKernel
+    from basq_amd.pools import gmm_pool
+
+    pts = gmm_pool(N, d, seed)
+    nys = pts[:m]
+    kern = StationaryKernel("rbf", 1.5, 1.0)
+    res, counts = [], []
+    for flag in (True, False):
+        old = eng.ASYNC_ROUNDS
+        eng.ASYNC_ROUNDS = flag
+        try:
+            torch.manual_seed(11)
+            ops = CpuStandInOps()
+            res.append(eng.RecombinationEngine(ops).run(pts, 0, N, nys, n, kern))
+            counts.append(dict(ops.calls))
+            after = torch.rand(1).item()                       # the generator ends in the same state on both paths
+        finally:
+            eng.ASYNC_ROUNDS = old
+        res[-1] = res[-1] + (after,)
+    (ia, wa, ra), (ib, wb, rb) = res
+    assert torch.equal(ia, ib)
+    assert torch.allclose(wa, wb, rtol=1e-11, atol=0)
+    assert ra == rb
+    if N > 2 * 2 * n * 2:
+        assert counts[0].get("round_next", 0) >= 1             # the descriptor path really ran
+        assert counts[1].get("round_next", 0) == 0

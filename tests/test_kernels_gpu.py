@@ -607,3 +607,65 @@ def test_skinny_gemm_vs_torch(hip_ops, M, K, N, trans, ksplit):
     got = hip_ops.skinny_gemm(Aw[:, :A.shape[1]], Bw[:, :N], trans=trans, ksplit=ksplit).cpu()
     assert got.shape == want.shape
     assert (got - want).abs().max().item() <= 1e-13 * K ** 0.5 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("R,S,n_keep,reg_blocks,class_mod,drop_last", [
+    (10_000, 200, 100, 48, 16, False),     # regular region of 48 blocks in 16 classes + 2 blocks irregular, no tail
+    (10_123, 200, 100, 48, 16, True),      # ragged tail, last set dropped
+    (10_123, 200, 100, 0, 0, False),       # no classes: everything through mode 3
+    (4_321, 100, 37, 40, 8, False),        # an elimination that kept fewer than half of the sets
+])
+def test_descriptor_driven_kernels_vs_host_geometry(hip_ops, R, S, n_keep, reg_blocks, class_mod, drop_last):
+    """basq_blocksum_geo_f64 / basq_reweight_compact_geo_f64 / basq_round_next_i64: the same results as the
+    host-geometry entries given the same numbers, with launches and buffers sized for an upper bound."""
+    cpu = CpuStandInOps()
+    d, m = 5, 130
+    spec = _spec("rbf", d)
+    nys, cand = _rand(m, d, 81), _rand(R, d, 82)
+    g = torch.Generator().manual_seed(9)
+    mu = torch.rand(R, generator=g, dtype=torch.float64) + 0.05
+    center = hip_ops.to_device(nys.mean(0))
+    pa = hip_ops.pack(spec, hip_ops.to_device(nys), center, 0, pad_rows_to=64)
+    R_max = R + 777                                               # buffers and grids are sized for an upper bound
+    pb = hip_ops.zeros(R_max, hip_ops.kp(d))
+    pb[:R] = hip_ops.pack(spec, hip_ops.to_device(cand), center, 1)
+    mu_d = hip_ops.zeros(R_max)
+    mu_d[:R] = hip_ops.to_device(mu)
+    nb = R // S
+    n_full, reg_hi = nb * S, reg_blocks * S
+    geo = hip_ops.geo_init(4, R, S, reg_hi)
+    # block sums: regular region (classes), the rest, everything
+    if class_mod:
+        Xa, ta = hip_ops.blocksum_geo(spec, pa, m, pb, mu_d, None, geo[0], 1, S, class_mod, class_mod=class_mod)
+        Xb, tb = hip_ops.blocksum(spec, pa, m, pb, mu_d, None, reg_hi, 0, n_full, S, class_mod, class_mod=class_mod)
+        assert torch.equal(Xa, Xb) and torch.equal(ta, tb)
+        Xa, ta = hip_ops.blocksum_geo(spec, pa, m, pb, mu_d, None, geo[0], 2, S, 1)
+        Xb, tb = hip_ops.blocksum(spec, pa, m, pb[reg_hi:], mu_d[reg_hi:], None, R - reg_hi, reg_hi, n_full, S, 1)
+        assert torch.equal(Xa, Xb) and torch.equal(ta, tb)
+    Xa, ta = hip_ops.blocksum_geo(spec, pa, m, pb, mu_d, None, geo[0], 3, S, 3)
+    Xb, tb = hip_ops.blocksum(spec, pa, m, pb, mu_d, None, R, 0, n_full, S, 3)
+    assert torch.equal(Xa, Xb) and torch.equal(ta, tb)
+    # an elimination outcome: n_keep sets kept (the last one or not), arbitrary positive weights
+    kept_sets = sorted(torch.randperm(S - 1, generator=g)[:n_keep - (0 if drop_last else 1)].tolist() + ([] if drop_last else [S - 1]))
+    keep_rank = torch.full((S,), -1, dtype=torch.int32)
+    keep_rank[kept_sets] = torch.arange(len(kept_sets), dtype=torch.int32)
+    w_star = torch.rand(S, generator=g, dtype=torch.float64) + 0.1
+    tot = torch.rand(S, generator=g, dtype=torch.float64) + 0.1
+    info = torch.tensor([len(kept_sets), 0], dtype=torch.int32)
+    gid = torch.arange(R_max, dtype=torch.int64) * 3 + 1
+    kr_d, ws_d, tot_d, info_d, gid_d = (hip_ops.to_device(t) for t in (keep_rank, w_star, tot, info, gid))
+    new_R = nb * len(kept_sets) + (0 if drop_last else R - n_full)
+    out_rows = new_R + 55
+    ca, ma, ga, _ = hip_ops.reweight_compact_geo(pb, mu_d, gid_d, None, geo[0], info_d, R_max, S, hip_ops.kp(d), kr_d, ws_d,
+                                                 tot_d, out_rows)
+    cb, mb, gb, _ = hip_ops.reweight_compact(pb, mu_d, gid_d, None, R, 0, n_full, S, hip_ops.kp(d), kr_d, ws_d, tot_d,
+                                             len(kept_sets), 0, new_R)
+    assert torch.equal(ca[:new_R], cb[:new_R]) and torch.equal(ma[:new_R], mb[:new_R]) and torch.equal(ga[:new_R], gb[:new_R])
+    # next descriptor: fresh classes, inherited classes, none -- against the stand-in's closed form
+    for mode in (8, -1, 0):
+        hip_ops.round_next(geo[0], info_d, kr_d, S, mode, True, geo[1])
+        want = torch.zeros(8, dtype=torch.int64)
+        cpu.round_next(hip_ops.to_host(geo[0], "g0").clone(), info, keep_rank, S, mode, True, want)
+        got = hip_ops.to_host(geo[1], "g1").clone()
+        assert got.tolist() == want.tolist()
+        assert got[0].item() == new_R and got[3].item() == (1 if 2 * len(kept_sets) != S else 0)

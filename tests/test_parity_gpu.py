@@ -190,3 +190,24 @@ def test_tiny_and_degenerate_pools_gpu(N, d, n, m):
         assert len(wo) == len(we) and (len(wo) == 0 or ((we.cpu() - wo).abs() / wo).max().item() <= 1e-9)
     finally:
         torch.set_default_dtype(prev)
+
+
+@pytest.mark.parametrize("name", [n_ for n_ in FAST + FULL if BY_NAME[n_]["kernel"].get("posterior") is None
+                                  and BY_NAME[n_]["kernel"].get("warp", "none") == "none"])
+def test_golden_parity_descriptor_driven_rounds(name):
+    """The production path for plain kernels on one GPU -- rounds enqueued without a host wait, geometry in a
+    device-resident descriptor -- against the same goldens (no trace: a trace selects the round-by-round loop)."""
+    import basq_amd
+    import basq_amd._engine as eng
+
+    if not has_golden(name):
+        pytest.skip("fixture not generated")
+    assert eng.ASYNC_ROUNDS
+    c = BY_NAME[name]
+    fx = load_golden(name)
+    _, idx, w = _run(c, None)
+    gi = torch.tensor(fx["idx"], dtype=torch.int64)
+    gw = torch.tensor(fx["w"], dtype=torch.float64)
+    assert idx.tolist() == gi.tolist(), "selected indices differ from the reference"
+    rel = ((w - gw).abs() / gw).max().item() if len(gw) else 0.0
+    assert rel <= W_RTOL, f"weights off by {rel:.3e} relative"
