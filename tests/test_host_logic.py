@@ -355,3 +355,38 @@ def test_descriptor_driven_rounds_equal_round_by_round(N, d, n, m, seed):
     if N > 2 * 2 * n * 2:
         assert counts[0].get("round_next", 0) >= 1             # the descriptor path really ran
         assert counts[1].get("round_next", 0) == 0
+
+
+def test_descriptor_violation_repeats_the_batch_round_by_round():
+    """A violation flag in the descriptor (an elimination that failed or did not keep half of the sets while regrouped
+    messages were already enqueued) makes the engine repeat the batch with one read-back per round: same result, and the
+    CPU generator is consumed once, as by a single run."""
+    import basq_amd._engine as eng
+    from basq_amd.kernels import StationaryKernel
+    from basq_amd.pools import gmm_pool
+
+    N, d, n, m = 30_000, 3, 20, 200
+    pts = gmm_pool(N, d, 8)
+    nys = pts[:m]
+    kern = StationaryKernel("rbf", 1.5, 1.0)
+
+    class Flagging(CpuStandInOps):
+        def round_next(self, geo_row, info, keep_rank, S, class_mode, expect_half, geo_next):
+            super().round_next(geo_row, info, keep_rank, S, class_mode, expect_half, geo_next)
+            if self.calls["round_next"] == 3:
+                geo_next[3] = 1                                  # as the kernel would on status != 0 / 2 n_keep != S
+
+    torch.manual_seed(5)
+    ops = Flagging()
+    ia, wa = eng.RecombinationEngine(ops).run(pts, 0, N, nys, n, kern)
+    ra = torch.rand(1).item()
+    assert ops.calls["round_next"] >= 3                          # the flag was really raised mid-way
+    old = eng.ASYNC_ROUNDS
+    eng.ASYNC_ROUNDS = False
+    try:
+        torch.manual_seed(5)
+        ib, wb = eng.RecombinationEngine(CpuStandInOps()).run(pts, 0, N, nys, n, kern)
+        rb = torch.rand(1).item()
+    finally:
+        eng.ASYNC_ROUNDS = old
+    assert torch.equal(ia, ib) and torch.equal(wa, wb) and ra == rb
