@@ -748,7 +748,7 @@ class RecombinationEngine:
         # range from there.  The host enqueues all rounds that are CERTAINLY not the final one (lower bound of the
         # survivor count > S) without waiting, then reads the descriptor once and finishes round by round below.
         if (ASYNC_ROUNDS and trace is None and comm.world == 1 and not opaque and not sober and obj_full is None
-                and warp != "wsabim" and diag_noise == 0.0 and hasattr(ops, "round_next") and R > S and _async_allowed):
+                and warp != "wsabim" and hasattr(ops, "round_next") and R > S and _async_allowed):
             n_keep_exp = s                                       # a regular round keeps s = S/2 sets
             geo_t = ops.geo_init(64, R, S, (pre[4] * S) if (pre is not None and pre[3] >= 2) else 0)
             r = 0
@@ -785,7 +785,18 @@ class RecombinationEngine:
                     else:
                         parts = ops.project(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S, kscale).unsqueeze(0)
                     del Xpart, totpart
-                XcarT, tot = ops.finalize(parts, parts.shape[0], parts.shape[1], q, S, None, m, min(m, S), 0.0, 0, 0, 0)
+                if diag_noise != 0.0:
+                    # predictive_covariance's noise on the ragged tail block (entries [k][k], tail point k x Nystrom row
+                    # k): one more message row carries the tail weights; its length is known on the device only, so the
+                    # row is always there (all zeros without a tail: the extra terms vanish)
+                    rows = parts.shape[1]
+                    buf = ops.empty(1, rows + 1, S)
+                    ops.sum_parts(parts, out=buf[0, :rows])
+                    ops.tail_weights_geo(mu, wx, g_row, S, buf[0, rows])
+                    XcarT, tot = ops.finalize(buf, 1, rows + 1, q, S, diagU, m, min(m, S), diag_noise, wrow, rows,
+                                              min(m, S), geo_row=g_row)
+                else:
+                    XcarT, tot = ops.finalize(parts, parts.shape[0], parts.shape[1], q, S, None, m, min(m, S), 0.0, 0, 0, 0)
                 PhiT = ops.nullspace(XcarT, s, S)
                 keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, tot.clone(), S, s)
                 cls = None

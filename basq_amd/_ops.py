@@ -163,10 +163,12 @@ class HipOps:
                                                ksplit, _ptr(work), _ptr(out), self._stream()), "basq_project_chunks_f64")
         return out
 
-    def sum_parts(self, parts):
-        """``parts [n, ...] -> parts.sum(0)`` in index order."""
+    def sum_parts(self, parts, out=None):
+        """``parts [n, ...] -> parts.sum(0)`` in index order (``out``: a contiguous destination of that size)."""
         assert parts.is_contiguous()
-        out = self.empty(*parts.shape[1:])
+        if out is None:
+            out = self.empty(*parts.shape[1:])
+        assert out.is_contiguous() and out.numel() == parts[0].numel()
         check(self.lib.basq_sum_parts_f64(_ptr(parts), parts.shape[0], out.numel(), _ptr(out), self._stream()),
               "basq_sum_parts_f64")
         return out
@@ -190,15 +192,23 @@ class HipOps:
         return out
 
     def finalize(self, parts, n_parts, msg_rows, q, S, diagU=None, ld_diag=0, n_diag=0, diag_noise=0.0, diag_wrow=0,
-                 diag_tail_row=0, n_tail_diag=0):
+                 diag_tail_row=0, n_tail_diag=0, geo_row=None):
+        """``geo_row``: descriptor-driven round -- the tail length comes from the device, ``n_tail_diag`` is its cap."""
         self._chk(parts)
         XcarT = self.empty(q + 1, S)
         tot = self.empty(S)
-        check(self.lib.basq_finalize_f64(_ptr(parts), n_parts, msg_rows, q, S, _ptr(diagU), ld_diag, n_diag,
-                                         float(diag_noise), diag_wrow, diag_tail_row, n_tail_diag, _ptr(XcarT),
-                                         _ptr(tot), self._stream()),
-              "basq_finalize_f64")
+        check(self.lib.basq_finalize_geo_f64(_ptr(parts), n_parts, msg_rows, q, S, _ptr(diagU), ld_diag, n_diag,
+                                             float(diag_noise), diag_wrow, diag_tail_row, n_tail_diag, _ptr(geo_row),
+                                             _ptr(XcarT), _ptr(tot), self._stream()),
+              "basq_finalize_geo_f64")
         return XcarT, tot
+
+    def tail_weights_geo(self, mu, wx, geo_row, S, out):
+        """``out[k] = mu * wx`` of tail point k of a descriptor-driven round (zero beyond the tail); ``out`` = a row of S."""
+        assert out.is_contiguous() and out.numel() == S
+        check(self.lib.basq_tail_weights_geo_f64(_ptr(mu), _ptr(wx), _ptr(geo_row), S, _ptr(out), self._stream()),
+              "basq_tail_weights_geo_f64")
+        return out
 
     def nullspace(self, XcarT, s, M):
         """Rows s..M-1 of the full ``Vh`` of ``svd(XcarT [s, M])`` (``_rchq.py:140-143``) -> PhiT [M-s, M]."""

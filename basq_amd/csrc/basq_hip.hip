@@ -1037,9 +1037,13 @@ __global__ void project_reduce_kernel(const double* __restrict__ work, int kspli
 __global__ void finalize_kernel(const double* __restrict__ parts, int n_parts, int msg_rows, int q, int S,
                                 const double* __restrict__ diagU, long long ld_diag, int n_diag, double diag_noise,
                                 int diag_wrow, int diag_tail_row, int n_tail_diag, double* __restrict__ XcarT,
-                                double* __restrict__ tot_out) {
+                                double* __restrict__ tot_out, const long long* __restrict__ geo) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (q + 1) * S) return;
+    if (geo) {                                     // descriptor-driven round: n_tail_diag is a cap, the tail length is on the device
+        const long long nt = geo[5];
+        if (nt < n_tail_diag) n_tail_diag = (int)nt;
+    }
     const int r = idx / S, s = idx % S;
     const long long stride = (long long)msg_rows * S;
     double tot = 0.0;
@@ -3439,9 +3443,10 @@ int basq_sum_parts_f64(const double* parts, int32_t n_parts, int64_t n, double* 
     return BASQ_OK;
 }
 
-int basq_finalize_f64(const double* parts, int32_t n_parts, int32_t msg_rows, int32_t q, int32_t S,
-                      const double* diagU, int64_t ld_diag, int32_t n_diag, double diag_noise, int32_t diag_wrow,
-                      int32_t diag_tail_row, int32_t n_tail_diag, double* XcarT, double* tot_out, void* stream) {
+int basq_finalize_geo_f64(const double* parts, int32_t n_parts, int32_t msg_rows, int32_t q, int32_t S,
+                          const double* diagU, int64_t ld_diag, int32_t n_diag, double diag_noise, int32_t diag_wrow,
+                          int32_t diag_tail_row, int32_t n_tail_diag, const int64_t* geo, double* XcarT, double* tot_out,
+                          void* stream) {
     if (!parts || !XcarT || !tot_out || n_parts < 1 || q < 1 || S < 1 || msg_rows < q + 1) return BASQ_EINVAL;
     if (diag_wrow < 0 || diag_wrow >= msg_rows) return BASQ_EINVAL;
     if (diag_tail_row < 0 || diag_tail_row >= msg_rows || n_tail_diag < 0 || n_tail_diag > S) return BASQ_EINVAL;
@@ -3449,7 +3454,33 @@ int basq_finalize_f64(const double* parts, int32_t n_parts, int32_t msg_rows, in
     const int tot = (q + 1) * S;
     hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, parts,
                        n_parts, msg_rows, q, S, diagU, (long long)ld_diag, n_diag, diag_noise, diag_wrow, diag_tail_row,
-                       n_tail_diag, XcarT, tot_out);
+                       n_tail_diag, XcarT, tot_out, (const long long*)geo);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_finalize_f64(const double* parts, int32_t n_parts, int32_t msg_rows, int32_t q, int32_t S,
+                      const double* diagU, int64_t ld_diag, int32_t n_diag, double diag_noise, int32_t diag_wrow,
+                      int32_t diag_tail_row, int32_t n_tail_diag, double* XcarT, double* tot_out, void* stream) {
+    return basq_finalize_geo_f64(parts, n_parts, msg_rows, q, S, diagU, ld_diag, n_diag, diag_noise, diag_wrow,
+                                 diag_tail_row, n_tail_diag, nullptr, XcarT, tot_out, stream);
+}
+
+// tail weights of a descriptor-driven round: out[k] = mu * wx of tail point k (positions n_full + k), zero beyond the tail
+__global__ void tail_weights_geo_kernel(const double* __restrict__ mu, const double* __restrict__ wx,
+                                        const long long* __restrict__ geo, int S, double* __restrict__ out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= S) return;
+    const long long n_full = geo[1], n_tail = geo[5];
+    double v = 0.0;
+    if (k < n_tail) v = wx ? mu[n_full + k] * wx[n_full + k] : mu[n_full + k];
+    out[k] = v;
+}
+
+int basq_tail_weights_geo_f64(const double* mu, const double* wx, const int64_t* geo, int32_t S, double* out, void* stream) {
+    if (!mu || !geo || !out || S < 1) return BASQ_EINVAL;
+    hipLaunchKernelGGL(tail_weights_geo_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mu, wx,
+                       (const long long*)geo, S, out);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }

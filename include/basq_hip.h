@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BASQ_ABI_VERSION 6
+#define BASQ_ABI_VERSION 7
 
 /* error codes */
 #define BASQ_OK            0
@@ -241,6 +241,15 @@ int basq_reweight_compact_f64(const double* cand, const double* mu, const int64_
  *       descriptor and n_keep from info[0]; the launch is sized for R_max >= R candidates.
  * Launch grids never depend on R; buffers are sized from host-side upper bounds.
  */
+/* Descriptor-driven siblings of the noise-diagonal bookkeeping (BASQ/_gp.py:275-276 on the ragged tail block):
+ *   basq_finalize_geo_f64: basq_finalize_f64 with the tail length taken from geo[5]; n_tail_diag is then only a cap.
+ *   basq_tail_weights_geo_f64: out[k] = mu[n_full + k] * wx[n_full + k] (wx may be NULL) for k < n_tail, 0 for k < S beyond:
+ *       the message row that carries the tail weights. */
+int basq_finalize_geo_f64(const double* parts, int32_t n_parts, int32_t msg_rows, int32_t q, int32_t S,
+                          const double* diagU, int64_t ld_diag, int32_t n_diag, double diag_noise, int32_t diag_wrow,
+                          int32_t diag_tail_row, int32_t n_tail_diag, const int64_t* geo, double* XcarT, double* tot_out,
+                          void* stream);
+int basq_tail_weights_geo_f64(const double* mu, const double* wx, const int64_t* geo, int32_t S, double* out, void* stream);
 int basq_round_next_i64(const int64_t* geo, const int32_t* info, const int32_t* keep_rank, int32_t S, int32_t class_mode,
                         int32_t expect_half, int64_t* geo_next, void* stream);
 int basq_blocksum_geo_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,

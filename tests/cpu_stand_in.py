@@ -147,10 +147,20 @@ class CpuStandInOps:
             return out
         return M
 
-    def sum_parts(self, parts):
-        out = parts[0].clone()
+    def sum_parts(self, parts, out=None):
+        acc = parts[0].clone()
         for p in range(1, parts.shape[0]):
-            out = out + parts[p]
+            acc = acc + parts[p]
+        if out is None:
+            return acc
+        out.copy_(acc.reshape(out.shape))
+        return out
+
+    def tail_weights_geo(self, mu, wx, geo_row, S, out):
+        n_full, n_tail = int(geo_row[1]), int(geo_row[5])
+        out.zero_()
+        t = mu[n_full:n_full + n_tail]
+        out[:n_tail] = t if wx is None else t * wx[n_full:n_full + n_tail]
         return out
 
     def blocksum(self, spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, out=None, class_mod=0, class0=0):
@@ -207,8 +217,10 @@ class CpuStandInOps:
         return torch.cat([totpart.sum(0).unsqueeze(0), outputscale * (U @ X)], 0)
 
     def finalize(self, parts, n_parts, msg_rows, q, S, diagU=None, ld_diag=0, n_diag=0, diag_noise=0.0, diag_wrow=0,
-                 diag_tail_row=0, n_tail_diag=0):
+                 diag_tail_row=0, n_tail_diag=0, geo_row=None):
         self._count("finalize")
+        if geo_row is not None:
+            n_tail_diag = min(n_tail_diag, int(geo_row[5]))
         msg = parts[0].clone()
         for p in range(1, n_parts):
             msg = msg + parts[p]

@@ -390,3 +390,31 @@ def test_descriptor_violation_repeats_the_batch_round_by_round():
     finally:
         eng.ASYNC_ROUNDS = old
     assert torch.equal(ia, ib) and torch.equal(wa, wb) and ra == rb
+
+
+@pytest.mark.parametrize("name", ["cfg1_posterior_1e4", "posterior_noise_ragged", "wsabil_noise_ragged", "wsabil_2e4",
+                                  "matern52_posterior", "rbf_ragged"])
+def test_descriptor_driven_rounds_structured_kernels(name):
+    """Posterior / WSABI-L kernels (likelihood noise on the block diagonals, incl. the ragged tail block whose length
+    only the device knows) through the descriptor-driven rounds: the round-by-round loop's batch, and the golden's."""
+    import basq_amd._engine as eng
+
+    c = BY_NAME[name]
+    pts, nys = build_pool(c)
+    out = []
+    for flag in (True, False):
+        old = eng.ASYNC_ROUNDS
+        eng.ASYNC_ROUNDS = flag
+        try:
+            torch.manual_seed(c["torch_seed"])
+            ops = CpuStandInOps()
+            out.append(eng.RecombinationEngine(ops).run(pts, 0, c["N"], nys, c["n"], build_product_kernel(c)))
+            ran = ops.calls.get("round_next", 0)
+        finally:
+            eng.ASYNC_ROUNDS = old
+        assert (ran > 0) == (flag and c["N"] > 4 * c["n"])
+    (ia, wa), (ib, wb) = out
+    assert torch.equal(ia, ib)
+    assert torch.allclose(wa, wb, rtol=1e-11, atol=0)
+    if has_golden(name):
+        assert ia.tolist() == load_golden(name)["idx"]

@@ -192,11 +192,11 @@ def test_tiny_and_degenerate_pools_gpu(N, d, n, m):
         torch.set_default_dtype(prev)
 
 
-@pytest.mark.parametrize("name", [n_ for n_ in FAST + FULL if BY_NAME[n_]["kernel"].get("posterior") is None
-                                  and BY_NAME[n_]["kernel"].get("warp", "none") == "none"])
+@pytest.mark.parametrize("name", [n_ for n_ in FAST + FULL if BY_NAME[n_]["kernel"].get("warp", "none") != "wsabim"])
 def test_golden_parity_descriptor_driven_rounds(name):
-    """The production path for plain kernels on one GPU -- rounds enqueued without a host wait, geometry in a
-    device-resident descriptor -- against the same goldens (no trace: a trace selects the round-by-round loop)."""
+    """The production path on one GPU (stationary, posterior and WSABI-L kernels) -- rounds enqueued without a host wait,
+    geometry in a device-resident descriptor -- against the same goldens (no trace: a trace selects the round-by-round
+    loop)."""
     import basq_amd
     import basq_amd._engine as eng
 
