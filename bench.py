@@ -222,14 +222,16 @@ def main():
                 # contract vocabulary is hbm|mfma: this kernel is bound by the fp64 PIPE, which f64 MFMA and fp64 VALU share
                 # on gfx950 (roughly half of its busy cycles are MFMA, half the VALU exp epilogue) -- neither HBM nor a
                 # GEMM-shaped MFMA bound; "bound_detail" says so.
-                "bound": "mfma", "bound_detail": "fp64 pipe (the default form issues fp64 VALU FMAs only: f64 MFMA and fp64 "
-                                                   "VALU share one datapath and the MFMA issues once per ~106 cycles); not HBM",
-                "kernel": "blocksum_lds_kernel (fused pairwise-kernel block sums, BASQ/_rchq.py:79-99; LDS-broadcast VALU form)",
+                "bound": "mfma", "bound_detail": "fp64 pipe: f64 MFMA for the exponent arguments (0.78 per 64 pairs, one issue "
+                                                   "per ~106 cycles) + fp64 VALU for the table exponential (12.75 per 64 "
+                                                   "pairs x 4.2 cycles); the two do not overlap on gfx950; not HBM",
+                "kernel": "blocksum_kernel (fused pairwise-kernel block sums, BASQ/_rchq.py:79-99; MFMA distances + VALU exp)",
                 "achieved": achieved_tf, "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tf / PEAK_FP64_VECTOR_TFLOPS,
-                "peak_measured": MEASURED_FP64_TFLOPS["fma_only"],
-                "frac_of_measured_peak": achieved_tf / MEASURED_FP64_TFLOPS["fma_only"],
-                "peak_measured_source": "profiles/r02_microbench_fp64_rates.txt (fma-only 72.9, mfma-only 47.2, mixed 63.1 TF/s)",
+                "peak_measured": MEASURED_FP64_TFLOPS["mixed_fma_mfma"],
+                "frac_of_measured_peak": achieved_tf / MEASURED_FP64_TFLOPS["mixed_fma_mfma"],
+                "peak_measured_source": "profiles/r02_microbench_fp64_rates.txt (fma-only 72.9, mfma-only 47.2, both "
+                                        "interleaved 63.1 TF/s: the figure that applies to this kernel's instruction mix)",
                 "traffic": traffic,
                 "traffic_source": ("committed PMC pass, not measured in this run: " + traffic_src) if traffic_src else None,
                 "fp64_pipe_busy_pmc": pipe_busy,
@@ -238,9 +240,9 @@ def main():
                 "flops_per_pair": 3 * d + 3,
                 "hbm_algorithmic_GBs": bytes_alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
                 "hbm_peak_GBs": PEAK_HBM_GBS,
-                "note": "compute-bound on the fp64 VALU (SURVEY 8d): 33 flop per pair by SURVEY's count = d + 1 FMAs for the "
-                        "exponent argument, 8 for the table exp, 1 weighted accumulate per 64-lane instruction; measured "
-                        "per rank 0; traffic / pipe occupancy: committed PMC passes, see profiles/",
+                "note": "compute-bound on the fp64 pipe (SURVEY 8d): 33 flop per pair by SURVEY's count (3d + 3); the kernel "
+                        "spends 143 cycles per 64 pairs = its MFMA + VALU instruction mix; launch durations by HIP events on "
+                        "the launch stream over one traced batch, rank 0; traffic / pipe occupancy: committed PMC passes",
             },
             "cpu_baseline": cpu,
             "result_digest": {"n_selected": int(idx.numel()), "w_sum": float(w.sum().item())},
