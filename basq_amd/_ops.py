@@ -152,9 +152,8 @@ class HipOps:
         """Per-chunk messages ``[n_chunks, q + 1, S]``: row 0 = ``totpart[c]``, rows 1.. = ``outputscale * U @ Xpart[c]``."""
         self._chk(U)
         if ksplit is None:
-            # ~512 work-groups per launch: a single chunk (the irregular remainder inside an epoch) is cut into up to 128
-            # K slices -- at 48 its waves ran 13 trips of 28 MFMAs each, 31 us for 8 us of arithmetic
-            ksplit = max(1, min(max(PROJECT_KSPLIT_MAX, 128 // n_chunks), m // 64))
+            # (128 slices for the single-chunk launches were tried: GEMM 67 -> 63 us, but the slab reduction 16 -> 31 us)
+            ksplit = max(1, min(PROJECT_KSPLIT_MAX, m // 128))
         work = self.empty(n_chunks * ksplit * q * S)
         if out is None:
             out = self.empty(n_chunks, q + 1, S)

@@ -247,10 +247,20 @@ def main():
             "cpu_baseline": cpu,
             "result_digest": {"n_selected": int(idx.numel()), "w_sum": float(w.sum().item())},
         }
-        print(json.dumps(out))
+        line = json.dumps(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner to the C-level stdout buffer; push it out first so that the JSON line is the LAST
+        # line of rank 0's output
+        try:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
