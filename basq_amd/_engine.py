@@ -249,6 +249,8 @@ def _skip_test_matrix_draw(ops, m, q):
 REPLICATED_REDUCTION = True
 SHARDED_BASIS = True             # multi-rank: split the range finder's Gram products over the ranks (False: rank 0 only)
 LATE_CHUNKS = 1                  # chunks of the round-1 block sums deferred behind the range finder (0 = none)
+LATE_CLASSES = 2                 # the same in class mode: the deferred classes (2 of 16 = 1.1 ms of GPU work) run while the
+                                 # host does the range finder's q x q SVD; A/B on MI355X: 42.9 / 43.35 / 43.15 batches/s for 1 / 2 / 3
 # Residue-class block sums: evaluate the pairwise kernel once per EPOCH of log2(C) + 1 rounds.  The chunks of the block
 # sums are the residue classes of the block index modulo C; a round that keeps exactly half of the sets sends the
 # survivor of (block b, kept rank k) to (block b // 2, set (b % 2) * n + k), so the next round's sums -- again per class,
@@ -676,10 +678,11 @@ class RecombinationEngine:
             reg_hi = min(max(reg_blocks * S_ - off, 0), Rl)              # local end of the regular region
             irregular = lambda: timed_blocksum(reg_hi, Rl, geo_, S_, 1, (Xbuf[C:C + 1], totbuf[C:C + 1]))   # noqa: E731
             if defer_last:
-                timed_blocksum(0, reg_hi, geo_, S_, C - 1, (Xbuf[:C - 1], totbuf[:C - 1]), class_mod=C, class0=0)
+                L = max(1, min(LATE_CLASSES, C - 1))             # classes evaluated behind the range finder's GPU work
+                timed_blocksum(0, reg_hi, geo_, S_, C - L, (Xbuf[:C - L], totbuf[:C - L]), class_mod=C, class0=0)
 
                 def late_fn():
-                    timed_blocksum(0, reg_hi, geo_, S_, 1, (Xbuf[C - 1:C], totbuf[C - 1:C]), class_mod=C, class0=C - 1)
+                    timed_blocksum(0, reg_hi, geo_, S_, L, (Xbuf[C - L:C], totbuf[C - L:C]), class_mod=C, class0=C - L)
                     irregular()
 
                 return Xbuf, totbuf, C + 1, C, reg_blocks, late_fn
