@@ -669,3 +669,19 @@ def test_descriptor_driven_kernels_vs_host_geometry(hip_ops, R, S, n_keep, reg_b
         got = hip_ops.to_host(geo[1], "g1").clone()
         assert got.tolist() == want.tolist()
         assert got[0].item() == new_R and got[3].item() == (1 if 2 * len(kept_sets) != S else 0)
+
+
+@pytest.mark.parametrize("d", [1, 10, 26, 27, 38])
+@pytest.mark.parametrize("n", [1, 255, 257, 1000])
+def test_pack_points_vs_standin(hip_ops, d, n):
+    """Packed rows [(x - c) / l, 0.., h | 1, 1 | h] (LDS-staged kernel: 256 or 128 points per block, ragged last block)."""
+    cpu = CpuStandInOps()
+    spec = _spec("rbf", d)
+    X = _rand(n, d, 90 + d)
+    c = X.mean(0)
+    for role in (0, 1):
+        for center in (c, None):
+            want = cpu.pack(spec, X, center, role)
+            got = hip_ops.pack(spec, hip_ops.to_device(X), None if center is None else hip_ops.to_device(center), role).cpu()
+            assert got.shape == want.shape
+            assert (got - want).abs().max().item() <= 1e-14 * max(1.0, want.abs().max().item())
