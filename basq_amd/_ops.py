@@ -407,12 +407,12 @@ class HipOps:
 
     @staticmethod
     def _skinny_ksplit(M, K, N):
-        """K slices for ``basq_skinny_gemm_f64``: ~5000 waves per launch (2.5 per wave slot of the chip at two waves per
-        SIMD -- the measured optimum at both range-finder shapes, profiles/r02_d_skinny_gemm_sweep.txt: 16 slices at
-        q = 99, 8 at q = 199), slices of at least ten 16-k trips."""
+        """K slices for ``basq_skinny_gemm_f64``: ~1900 waves per launch -- just under the 2048 wave slots of the chip at
+        two waves per SIMD.  6 slices at q = 99 run as fast as 16 (435 / 464 us vs 435 / 462, the two optima of
+        profiles/r02_d_skinny_gemm_sweep.txt) and leave 6 instead of 16 slabs to add; slices of at least ten 16-k trips."""
         rows_per_wave = 16 if N > 112 else 32
         row_waves = (M + rows_per_wave - 1) // rows_per_wave
-        return max(1, min(round(5000 / row_waves), K // 160))
+        return max(1, min(round(1900 / row_waves), K // 160))
 
     def skinny_gemm(self, A, B, trans=False, ksplit=None):
         """``A @ B`` (``trans``: ``A.T @ B``) for a skinny ``B [K, N <= 208]`` on the hand-written f64 MFMA kernel
