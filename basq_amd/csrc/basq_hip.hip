@@ -2940,39 +2940,32 @@ __global__ void __launch_bounds__(1024) chol_factor_panel_kernel(double* __restr
     __syncthreads();
     const double floor_ = rel_tol * s_dmax;
     int bad = 0;
-    __shared__ int s_bad;
-    if (tid == 0) s_bad = 0;
-    // the waves that own a row below the block (tid < R <= q - 8) are the only ones that need the factored diagonal block
-    const int nwv_diag = (q + 63) >> 6;
     for (int j0 = 0; j0 < q; j0 += NB) {
         const int nb = (q - j0 < NB) ? (q - j0) : NB;
-        const int R = q - j0 - nb;
-        // ---- F1: diagonal block, redundantly in every thread of the row-owning waves (the other waves used to factor it
-        //      too, for nothing: twelve more waves issuing the same ~370 dependent instructions on the four SIMDs) ----
+        // ---- F1: diagonal block, redundantly in every thread ----
         double D[NB][NB], rd[NB];
-        if (wv < nwv_diag) {
 #pragma unroll
-            for (int r = 0; r < NB; ++r)
+        for (int r = 0; r < NB; ++r)
 #pragma unroll
-                for (int c = 0; c <= r; ++c) D[r][c] = (r < nb) ? BASQ_TRI(j0 + r, j0 + c) : ((r == c) ? 1.0 : 0.0);
+            for (int c = 0; c <= r; ++c) D[r][c] = (r < nb) ? BASQ_TRI(j0 + r, j0 + c) : ((r == c) ? 1.0 : 0.0);
 #pragma unroll
-            for (int c = 0; c < NB; ++c) {
-                const double d = D[c][c];
-                if (c < nb && !(d > floor_) && bad == 0) bad = j0 + c + 1;   // the same in every thread that runs F1
-                const double r = rsqrt_nr(bad ? 1.0 : d);
-                rd[c] = r;
-                D[c][c] = d * r;
+        for (int c = 0; c < NB; ++c) {
+            const double d = D[c][c];
+            if (c < nb && !(d > floor_) && bad == 0) bad = j0 + c + 1;       // uniform: every thread holds the same block
+            const double r = rsqrt_nr(bad ? 1.0 : d);
+            rd[c] = r;
+            D[c][c] = d * r;
 #pragma unroll
-                for (int i = c + 1; i < NB; ++i) D[i][c] *= r;
+            for (int i = c + 1; i < NB; ++i) D[i][c] *= r;
 #pragma unroll
-                for (int i = c + 1; i < NB; ++i)
+            for (int i = c + 1; i < NB; ++i)
 #pragma unroll
-                    for (int k = c + 1; k <= i; ++k) D[i][k] -= D[i][c] * D[k][c];
-            }
-            if (bad && tid == 0) s_bad = bad;
+                for (int k = c + 1; k <= i; ++k) D[i][k] -= D[i][c] * D[k][c];
         }
+        if (bad) break;                                                     // uniform
         // ---- F2: rows below the block ----
-        if (!bad && tid < R) {
+        const int R = q - j0 - nb;
+        if (tid < R) {
             const int i = j0 + nb + tid;
             double y[NB];
 #pragma unroll
@@ -2989,11 +2982,9 @@ __global__ void __launch_bounds__(1024) chol_factor_panel_kernel(double* __restr
                 if (c < nb) BASQ_TRI(i, j0 + c) = y[c];
         }
         __syncthreads();
-        bad = s_bad;                                                         // uniform from here on
-        if (bad) break;
         // the factored block goes back only now: before the barrier a slower wave may still be READING the unfactored
         // block in F1 (F3 below touches neither the block nor these rows' panel entries)
-        if (tid == 0) {
+        if (tid == 1023) {
 #pragma unroll
             for (int r = 0; r < NB; ++r)
 #pragma unroll
