@@ -6,12 +6,17 @@ Mirrors ``BASQ/_rchq.py``: ``rc_kernel_svd`` (:34-40) = Nystrom basis + ``Mod_Tc
 =======================================  ==========================================================
 step (reference lines)                   here
 =======================================  ==========================================================
-Gram ``kernel(pt, pt)`` (:29)            ``basq_gram_f64`` (+ small rocBLAS GEMMs for GP corrections)
+Gram ``kernel(pt, pt)`` (:29)            ``basq_gram_f64`` (+ two small library GEMMs per batch for GP corrections)
 ``torch.svd_lowrank`` (:29)              same algorithm (Halko 4.4/5.1, niter=2): uniforms of the Gaussian test
                                          matrix from the CPU global generator (parity) + Box-Muller on the GPU,
-                                         GEMMs on the GPU, CholeskyQR (``basq_chol_inv_f64``) instead of the
+                                         the products on ``basq_skinny_gemm_f64``, CholeskyQR
+                                         (``basq_chol_factor_f64`` + ``basq_trsm_rows_f64``) instead of the
                                          Householder QRs, one q x q SVD on host LAPACK
-hot loop + tail + tot (:79-99)           ``basq_blocksum_f64`` (fused, nothing materialised)
+hot loop + tail + tot (:79-99)           ``basq_blocksum_f64`` (fused, nothing materialised; per residue class of
+                                         the block index, so that the next rounds regroup instead of re-evaluating:
+                                         ``basq_regroup_classes_f64``)
+round geometry (:76-78, :107-130)        closed form, on the device: ``basq_round_next_i64`` + the ``*_geo`` entries
+                                         (one rank: no host wait per round)
 ``U_svd @ X_for_nys`` (:88)              ``basq_project_f64`` (f64 MFMA)
 divide, ones column (:101, :138)         ``basq_finalize_f64``
 full SVD -> null space (:140-143)        ``basq_nullspace_f64``: the right Householder reflectors of gesdd's
@@ -303,7 +308,7 @@ GPU_NULLSPACE = True
 
 
 class _DenseProducts:
-    """The Nystrom Gram matrix ``A`` resident on this GPU: the three products of the range finder as library GEMMs."""
+    """The Nystrom Gram matrix ``A`` resident on this GPU: the three products of the range finder (``_mm_splitk``)."""
 
     def __init__(self, ops, A):
         self.ops, self.A, self.At, self.m = ops, A, A.t(), A.shape[0]
@@ -726,7 +731,7 @@ class RecombinationEngine:
         U_cols = [Um]
         if post is not None:
             W = ops.to_device(post.W, torch.float64)
-            Bmat = base.dense(ops, pts_nys, Xo, center) @ W      # [m, n_obs] (small rocBLAS GEMM)
+            Bmat = base.dense(ops, pts_nys, Xo, center) @ W      # [m, n_obs] (small library GEMM, once per batch)
             U_cols.append(-(Um @ Bmat))
             if warp == "wsabim":
                 # B^T, zero-padded to whole MFMA fragments: the A operand of the fused squared-covariance block sums

@@ -399,7 +399,7 @@ class HipOps:
               "basq_gemm_f64")
         return Cm
 
-    # -- plumbing (library GEMMs of the randomised SVD; rocBLAS via torch) ---------------------
+    # -- plumbing (small dense products outside the hot loop go through torch) ---------------------
     def matmul(self, A, B):
         return torch.matmul(A, B)
 
