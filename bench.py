@@ -144,6 +144,9 @@ def main():
     k_ms = sum(a.elapsed_time(b) for a, b, _ in tr.kernel_events)
     k_pairs = sum(info["pairs"] for _, _, info in tr.kernel_events)
     k_launches = len(tr.kernel_events)
+    # what the REFERENCE's loop evaluates for the same batch (m * sum_r R_r + m^2): the residue-class block sums
+    # evaluate about half of it (rounds inside an epoch regroup the previous sums instead)
+    ref_pairs = float(m) * sum(r["R"] for r in tr.rounds) + float(m) * m
     flops = k_pairs * (3 * d + 3)
     bytes_alg = sum(info["R"] * (8 * d + 16) + 8 * info["m"] * d for _, _, info in tr.kernel_events)
     achieved_tf = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
@@ -237,6 +240,8 @@ def main():
                 "fp64_pipe_busy_pmc": pipe_busy,
                 "fp64_pipe_busy_source": "committed PMC pass (same file), not measured in this run" if pipe_busy else None,
                 "launches_per_batch": k_launches, "kernel_ms_per_batch": k_ms, "pairs_per_batch": k_pairs,
+                "reference_pairs_per_batch": ref_pairs,
+                "whole_batch_TFLOPs_by_reference_count": ref_pairs * (3 * d + 3) / (dt / args.steps) / 1e12,
                 "flops_per_pair": 3 * d + 3,
                 "hbm_algorithmic_GBs": bytes_alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
                 "hbm_peak_GBs": PEAK_HBM_GBS,
