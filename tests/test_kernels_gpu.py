@@ -609,6 +609,31 @@ def test_skinny_gemm_vs_torch(hip_ops, M, K, N, trans, ksplit):
     assert (got - want).abs().max().item() <= 1e-13 * K ** 0.5 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("M,K,N,pad,ksplit", [
+    (256, 4096, 99, 0, 4),       # the engine's layout: tight, 16-byte aligned rows -> the pipelined trips
+    (256, 4096, 99, 5, 3),       # NaN beyond column N of every B row: the 16 NT-wide row reads must not leak them
+    (100, 640, 37, 0, 2),        # three column tiles on the four-tile kernel: tiles past N are read from the next rows
+    (70, 96, 3, 0, 1),           # a row of B shorter than one tile: the wide reads span many rows, the last ones run masked
+    (512, 2048, 199, 1, 2),      # 13 column tiles
+    (96, 160, 112, 0, 1),        # N a whole number of tiles
+])
+@pytest.mark.parametrize("trans", [False, True])
+def test_skinny_gemm_pipelined_path(hip_ops, M, K, N, pad, ksplit, trans):
+    """Tight / aligned operands take the kernel's pipelined trips, whose B fragments are read 16 NT columns wide: whatever
+    lies beyond column N (the next rows, or NaN padding) must never reach a stored column, and nothing may be read past
+    the last row of B."""
+    A = _rand(K if trans else M, M if trans else K, 73)
+    B = _rand(K, N, 74)
+    want = (A.t() if trans else A) @ B
+    Ad = hip_ops.to_device(A)
+    Bw = hip_ops.zeros(K, N + pad)
+    Bw[:] = float("nan")
+    Bw[:, :N] = hip_ops.to_device(B)
+    got = hip_ops.skinny_gemm(Ad, Bw[:, :N], trans=trans, ksplit=ksplit).cpu()
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() <= 1e-13 * K ** 0.5 * max(1.0, want.abs().max().item())
+
+
 @pytest.mark.parametrize("R,S,n_keep,reg_blocks,class_mod,drop_last", [
     (10_000, 200, 100, 48, 16, False),     # regular region of 48 blocks in 16 classes + 2 blocks irregular, no tail
     (10_123, 200, 100, 48, 16, True),      # ragged tail, last set dropped
