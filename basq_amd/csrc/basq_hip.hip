@@ -330,64 +330,17 @@ __device__ __forceinline__ void load_cand(CandFrag<KK>& f, const BlocksumArgs& A
     f.w = ok ? m_ * x_ : 0.0;
 }
 
-// Exponent arguments of a 16*JT x 16 tile of (Nystrom row, candidate) pairs on v_mfma_f64_4x4x4_4b_f64: four independent
-// 4x4x4 products per instruction (lane map found by one-hot probing, tools/microbench_mfma4.hip: A lane = 16 k + 4 b + i,
-// B lane = 16 k + 4 b + j, D lane = 16 i + 4 b + j).  With c = 4 b + j the B operand and the result use exactly the lanes
-// of the 16x16x4 form (candidate column c, K index / row index lane >> 4); the A operand of sub-tile (jt, r) holds rows
-// 16 jt + 4 r + i replicated over the four blocks, and its result is row 16 jt + 4 r + (lane >> 4) -- the accumulator
-// layout of the 16x16x4 form.  Why: this instruction issues once per 16.5 cycles (75.7 TF/s chip-wide), the 16x16x4 form
-// once per 106 for four times the work (47.4 TF/s): profiles/r02_l_microbench_mfma_f64_4x4x4.txt.
-#ifndef BASQ_BS_MFMA4
-#define BASQ_BS_MFMA4 0
-#endif
-#ifndef BASQ_BS_ILV
-#define BASQ_BS_ILV 0
-#endif
-#if BASQ_BS_MFMA4
-#define BASQ_BS_AR 4
-#else
-#define BASQ_BS_AR 1
-#endif
 template <int KK, int FAM, int JT>
-__device__ __forceinline__ void tile_accumulate(const double (&a)[JT][BASQ_BS_AR][KK], const CandFrag<KK>& f, double (&acc)[JT][4],
+__device__ __forceinline__ void tile_accumulate(const double (&a)[JT][KK], const CandFrag<KK>& f, double (&acc)[JT][4],
                                                 const ExpK& ek, const double* tab) {
-#if BASQ_BS_MFMA4 && BASQ_BS_ILV
-    double D[JT][4];
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) D[jt][r] = 0.0;
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) D[jt][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[jt][r][kk], f.b[kk], D[jt][r], 0, 0, 0);
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[jt][r] = __builtin_fma(kernel_from_arg_k<FAM>(D[jt][r], ek, tab), f.w, acc[jt][r]);
-#elif BASQ_BS_MFMA4
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt) {
-        double D[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) D[r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[jt][r][kk], f.b[kk], D[r], 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[jt][r] = __builtin_fma(kernel_from_arg_k<FAM>(D[r], ek, tab), f.w, acc[jt][r]);
-    }
-#else
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) {
         d4 D = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) D = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt][0][kk], f.b[kk], D, 0, 0, 0);
+        for (int kk = 0; kk < KK; ++kk) D = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt][kk], f.b[kk], D, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[jt][r] = __builtin_fma(kernel_from_arg_k<FAM>(D[r], ek, tab), f.w, acc[jt][r]);
     }
-#endif
 }
 
 template <int KK, int FAM, int JT>
@@ -416,14 +369,11 @@ __global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A_in) 
     ExpK ek;
     expk_init(ek);
 
-    double a[JT][BASQ_BS_AR][KK];   // rows 16 jt + 4 r + (lane & 3), K index 4 kk + g: the same in all four blocks of the instruction
+    double a[JT][KK];
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-        for (int r = 0; r < BASQ_BS_AR; ++r)
-#pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
-                a[jt][r][kk] = A.nys[(long long)(j0 + jt * 16 + (BASQ_BS_MFMA4 ? 4 * r + (lane & 3) : c)) * KP + kk * 4 + g];
+        for (int kk = 0; kk < KK; ++kk) a[jt][kk] = A.nys[(long long)(j0 + jt * 16 + c) * KP + kk * 4 + g];
 
     double acc[JT][4];
 #pragma unroll
@@ -549,25 +499,13 @@ __global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A_in) 
     }
 }
 
-// Row tiles per wave of the 16x16x4 kernels (blocksum_sq_kernel): 4 (64 Nystrom rows) while the A fragments fit
-// comfortably; 2 for KP >= 24 (d >= 21), where 4 x KP/4 fragment registers would push the kernel to one wave per SIMD.
+// Row tiles per wave: 4 (64 Nystrom rows) while the A fragments fit comfortably; 2 for KP >= 24 (d >= 21), where
+// 4 x KP/4 fragment registers would push the kernel to one wave per SIMD.  basq_amd/_partition.py mirrors this.
 #define BASQ_JT_FOR(KK) ((KK) >= 6 ? 2 : 4)
-
-// Row tiles per wave of blocksum_kernel: its A operands are replicated over the four blocks of the 4x4x4 instruction
-// (4 JT KK doubles per lane), so 64 rows per wave up to KP = 12, 32 up to KP = 24, 16 beyond.
-// basq_amd/_partition.py::rows_per_wave mirrors this.
-#ifndef BASQ_BS_JT3
-#define BASQ_BS_JT3 4
-#endif
-#if BASQ_BS_MFMA4
-#define BASQ_BS_JT(KK) ((KK) <= 3 ? BASQ_BS_JT3 : ((KK) <= 6 ? 2 : 1))
-#else
-#define BASQ_BS_JT(KK) BASQ_JT_FOR(KK)
-#endif
 
 template <int KK, int FAM>
 static int launch_blocksum(const BlocksumArgs& A, hipStream_t st) {
-    constexpr int JT = BASQ_BS_JT(KK);
+    constexpr int JT = BASQ_JT_FOR(KK);
     BlocksumArgs B = A;
     B.n_jgroups = (A.m + 64 * JT - 1) / (64 * JT);         // 4 waves x 16*JT rows per block
     const long long npairs = (long long)A.n_stiles * A.n_chunks;
@@ -955,127 +893,26 @@ __global__ void __launch_bounds__(256) gemm_kernel(const double* __restrict__ A,
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tall-skinny f64 MFMA GEMM for the range finder (torch.svd_lowrank, BASQ/_rchq.py:29: A Q, A^T Q, Q^T A, X^T X with
+// Tall-skinny f64 GEMM for the range finder (torch.svd_lowrank, BASQ/_rchq.py:29: A Q, A^T Q, Q^T A, X^T X with
 // A the [m, m] Nystrom Gram matrix and only q + 1 <= 208 columns on the other side):
 //     Cpart[z][M, N] = sum over K slice z of  op(A)[M, K] @ B[K, N],   op(A) = A ([M, K] row-major) or A^T (A is [K, M]).
-// A wave owns 16 JT rows and ALL N columns (NT tiles of 16): its A fragments are read from HBM exactly once per launch,
-// B (a few MB) comes from L2; per 16-k trip 4 JT + 4 NT loads feed 4 JT NT MFMAs, so the kernel runs at the matrix
-// pipe's rate.  A row-major: lane (c, g) reads A[row c][k + 4 g .. + 3] -- one 128-byte line per row and trip -- and the
-// k index of MFMA step u is k + 4 g + u (any order of the contraction index is a valid order, B is read to match).
-// Split K over blockIdx.y; the slabs are added in slice order by sum_parts_kernel (fixed summation order).
-// ------------------------------------------------------------------------------------------------
-template <int NT, int JT, bool TRANS>
-__global__ void __launch_bounds__(256) skinny_gemm_kernel(const double* __restrict__ A, long long lda,
-                                                          const double* __restrict__ B, long long ldb,
-                                                          double* __restrict__ C, long long ldc, long long cstride, int M,
-                                                          int N, int K, int kslice) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    const int r0 = (blockIdx.x * 4 + wave) * (16 * JT);
-    if (r0 >= M) return;
-    const int k0 = blockIdx.y * kslice;
-    int k1 = k0 + kslice;
-    if (k1 > K) k1 = K;
-    long long aoff[JT];
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt) {
-        int r = r0 + jt * 16 + c;
-        if (r >= M) r = M - 1;
-        aoff[jt] = TRANS ? (long long)r : (long long)r * lda;
-    }
-    int bcol[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bcol[nt] = (nt * 16 + c < N) ? (nt * 16 + c) : (N - 1);
-    d4 acc[JT][NT];
-#pragma unroll
-    for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[jt][nt] = (d4){0.0, 0.0, 0.0, 0.0};
-    // contraction index of MFMA step u of the trip that starts at k, for this lane's group g
-    auto kidx = [&](int k, int u) { return TRANS ? (k + 4 * u + g) : (k + 4 * g + u); };
-    // Software pipeline: the A fragments of the NEXT trip (HBM latency) and the B fragments of the NEXT step (L2 latency)
-    // are requested before the current step's MFMAs are issued.  Out-of-range k: the address is clamped to the slice's
-    // last row and the A operand zeroed (B stays finite, the product vanishes).
-    // row-major A: a lane's four k indices are 32 contiguous bytes -- two 16-byte loads when the rows are 16-byte aligned
-    const bool a_vec = !TRANS && ((lda & 1) == 0) && (((uintptr_t)A & 15) == 0);
-    auto load_a = [&](int k, double (&av)[4][JT]) {
-        if (!TRANS && a_vec && k + 16 <= k1) {                  // wave-uniform
-#pragma unroll
-            for (int jt = 0; jt < JT; ++jt) {
-                const double2* p = reinterpret_cast<const double2*>(A + aoff[jt] + k + 4 * g);
-                const double2 lo = p[0], hi = p[1];
-                av[0][jt] = lo.x;
-                av[1][jt] = lo.y;
-                av[2][jt] = hi.x;
-                av[3][jt] = hi.y;
-            }
-            return;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int kk = kidx(k, u);
-            const int kc = (kk < k1) ? kk : (k1 - 1);
-#pragma unroll
-            for (int jt = 0; jt < JT; ++jt) {
-                const double v = TRANS ? A[(long long)kc * lda + aoff[jt]] : A[aoff[jt] + kc];
-                av[u][jt] = (kk < k1) ? v : 0.0;
-            }
-        }
-    };
-    auto load_b = [&](int k, int u, double (&bv)[NT]) {
-        const int kk = kidx(k, u);
-        const double* bp = B + (long long)((kk < k1) ? kk : (k1 - 1)) * ldb;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bv[nt] = bp[bcol[nt]];
-    };
-    double av[4][JT], bv[NT];
-    load_a(k0, av);
-    load_b(k0, 0, bv);
-    for (int k = k0; k < k1; k += 16) {
-        double avn[4][JT];
-        load_a(k + 16, avn);                                   // past the slice on the last trip: clamped, unused
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            double bvn[NT];
-            if (u < 3) load_b(k, u + 1, bvn);
-            else load_b(k + 16, 0, bvn);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int jt = 0; jt < JT; ++jt)
-                    acc[jt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][jt], bv[nt], acc[jt][nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = bvn[nt];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int jt = 0; jt < JT; ++jt) av[u][jt] = avn[u][jt];
-    }
-    double* Cz = C + (long long)blockIdx.y * cstride;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        if (nt * 16 + c >= N) continue;
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = r0 + jt * 16 + g + 4 * r;
-                if (row < M) Cz[(long long)row * ldc + nt * 16 + c] = acc[jt][nt][r];
-            }
-    }
-}
-
-// The same product on v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 products per instruction; lane map in
-// tile_accumulate's note).  On gfx950 both fp64 matrix instructions run on the vector fp64 pipe: the 4x4x4 form issues
-// once per 16.5 cycles = 4 wave-wide FMAs' worth of pipe time for 256 lane-FMAs (75.7 TF/s), the 16x16x4 form once per
-// 106 cycles for 1024 (47.4 TF/s) -- profiles/r02_l_microbench_mfma_f64_4x4x4.txt.  The price is operand traffic: four
-// times as many operand registers per flop.  So the fragments are LOADED exactly as for the 16x16x4 form (lane (c, g):
-// row / column c, contraction index by g) and the four products of a 16 x 16 tile come from four ROTATIONS of the A
-// fragment inside each row of 16 lanes (DPP row_ror 0/4/8/12: two v_mov per rotation, off the fp64 pipe): with rotation
-// rho, block b = c >> 2 multiplies the rows of lane group rg(rho, b) with its own four columns, i.e. D of lane (g, c) is
+// A wave owns 16 JT rows and ALL N columns (NT tiles of 16): its A fragments are read from HBM exactly once per launch.
+// A row-major: lane (c, g) reads A[row c][k + 4 g .. + 3] -- one 128-byte line per row and 16-k trip -- and the k index
+// of step u is k + 4 g + u (any order of the contraction index is a valid order, B is read to match).  Split K over the
+// grid; the slabs are added in slice order by sum_parts_kernel (fixed summation order).
+//
+// The products run on v_mfma_f64_4x4x4_4b_f64 (four independent 4x4x4 products per instruction; lane map found by
+// one-hot probing, tools/microbench_mfma4.hip: A lane = 16 k + 4 b + i, B lane = 16 k + 4 b + j, D lane = 16 i + 4 b + j).
+// On gfx950 both fp64 matrix instructions run on the vector fp64 pipe: this one issues once per 16.5 cycles = 4 wave-wide
+// FMAs' worth of pipe time for 256 lane-FMAs (75.7 TF/s chip-wide), v_mfma_f64_16x16x4 once per ~106 cycles for 1024
+// (47.4 TF/s) -- profiles/r02_l_microbench_mfma_f64_4x4x4.txt.  The price is operand traffic: four times as many operand
+// registers per flop.  So the fragments are LOADED exactly as for the 16x16x4 form (lane (c, g): row / column c,
+// contraction index by g) and the four products of a 16 x 16 tile come from four ROTATIONS of the A fragment inside each
+// row of 16 lanes (DPP row_ror 0/4/8/12: two v_mov per rotation, off the fp64 pipe): with rotation rho, block b = c >> 2
+// multiplies the rows of lane group rg(rho, b) with its own four columns, i.e. D of lane (g, c) is
 // C[16 jt + 4 rg + g][16 nt + c].  rg is read back from the same DPP applied to the lane index, so the code does not
 // depend on the direction of the rotation.
+// ------------------------------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ double dpp_row_f64(double v) {
     const long long b = __double_as_longlong(v);
@@ -1084,20 +921,16 @@ __device__ __forceinline__ double dpp_row_f64(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-#ifndef BASQ_SKINNY_WPE
-#define BASQ_SKINNY_WPE 2
-#endif
 template <int NT, int JT, bool TRANS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(BASQ_SKINNY_WPE)))
-skinny_gemm4_kernel(const double* __restrict__ A, long long lda, const double* __restrict__ B, long long ldb,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
+skinny_gemm_kernel(const double* __restrict__ A, long long lda, const double* __restrict__ B, long long ldb,
                     double* __restrict__ C, long long ldc, long long cstride, int M, int N, int K, int kslice, int nz) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     // Work-groups are dealt round-robin over the 8 XCDs (blockIdx.x % 8): with the K slice = blockIdx.x % nz and nz a
     // multiple of 8, an XCD only ever reads ITS slices of B, which then stay in its 4-MB L2 (B as a whole does not fit).
     const int zslice = blockIdx.x % nz;
-    const int r0 = ((blockIdx.x / nz) * 4 + wave) * (16 * JT);
-    if (r0 >= M) return;
+    const int r0 = ((blockIdx.x / nz) * 4 + wave) * (16 * JT);   // may lie past M: such a wave still helps staging B, stores nothing
     const int k0 = zslice * kslice;
     int k1 = k0 + kslice;
     if (k1 > K) k1 = K;
@@ -1128,11 +961,6 @@ skinny_gemm4_kernel(const double* __restrict__ A, long long lda, const double* _
     auto mfma_step = [&](const double (&a)[JT], const double (&bv)[NT]) {
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
-#ifdef BASQ_SKINNY_PROBE   // tools only: the loads without the products (is the kernel bound by how its operands arrive?)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[jt][0][nt] = __builtin_fma(a[jt], bv[nt], acc[jt][0][nt]);
-            continue;
-#endif
             double ar[4];
             ar[0] = a[jt];
             ar[1] = dpp_row_f64<0x124>(ar[0]);
@@ -1146,23 +974,39 @@ skinny_gemm4_kernel(const double* __restrict__ A, long long lda, const double* _
         }
     };
 
-    // Full 16-k trips: every address is a pointer that advances by a wave-uniform stride (the matrix instructions leave
-    // no idle issue slots to hide index arithmetic in), fragments of the NEXT trip (A: HBM latency) and the NEXT step
-    // (B: L2 latency) are requested before the current step's products are issued; on the last trip the strides are 0.
-    // B is read 16 NT columns wide whatever N is (one lane offset + immediate tile offsets): columns >= N of a row are
-    // the head of the following row(s) -- finite or not, they only reach accumulator columns that are never stored -- so
-    // the pipelined trips stop short of the last over_rows rows of B, where such a read would leave the matrix.
-    const int over_rows = (16 * NT + (int)ldb - 1) / (int)ldb;
+    // Full 16-k trips.  The four waves of a work-group share the K slice, hence B: its [16, 16 NT] tile of a trip goes
+    // through LDS (each thread fetches NT doubles, once per work-group instead of once per wave -- measured, the B
+    // fragments through the vector memory path cost as much time as streaming A from HBM, and the two do not overlap:
+    // profiles/r02_l_skinny_gemm_operand_paths.txt), double-buffered with one barrier per trip; the A fragments of the
+    // NEXT trip (HBM latency) are requested a trip ahead.  Every address is a wave-uniform pointer that advances on the
+    // scalar unit plus one per-lane offset: the matrix instructions leave no idle issue slots to hide index arithmetic in.
+    // The staging reads are 16 NT columns wide whatever N is: columns >= N of a row are the head of the following row(s)
+    // -- finite or not, they only reach accumulator columns that are never stored -- so the pipelined trips stop short of
+    // the last over_rows rows of B, where such a read would leave the matrix.
+    constexpr int W = 16 * NT;
+    __shared__ double btile[2][16][W];
+    const int over_rows = (W + (int)ldb - 1) / (int)ldb;
     const int kfast_end = (k1 < K - over_rows) ? k1 : (K - over_rows);
     const int ktrips = (kfast_end > k0) ? (kfast_end - k0) / 16 : 0;
     int kdone = k0;
-    if (ktrips > 0 && (TRANS || a_vec)) {                         // wave-uniform
-        // B: one wave-uniform row pointer that advances on the scalar unit + one per-lane byte offset (row of this lane's
-        // group inside the step, column c): no vector arithmetic per load.
+    if (ktrips > 0 && (TRANS || a_vec)) {                         // work-group uniform
+        const int skk = threadIdx.x >> 4, sc = threadIdx.x & 15;   // staging: thread -> (row of the tile, column in a tile)
         const char* bbase = reinterpret_cast<const char*>(B + (long long)k0 * ldb);
-        const unsigned boff = (unsigned)((long long)((TRANS ? g : 4 * g) * ldb + c) * 8);
-        const long long bstep = (TRANS ? 4 * ldb : ldb) * 8;        // step u -> u + 1, bytes
-        const long long btrip = (TRANS ? 4 * ldb : 13 * ldb) * 8;   // step 3 -> step 0 of the next trip
+        const unsigned soff = (unsigned)(((long long)skk * ldb + sc) * 8);
+        const long long btrip = 16 * ldb * 8;
+        auto stage_load = [&](double (&sr)[NT]) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) sr[i] = *reinterpret_cast<const double*>(bbase + soff + 128 * i);
+        };
+        auto stage_store = [&](int buf, const double (&sr)[NT]) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) btile[buf][skk][sc + 16 * i] = sr[i];
+        };
+        auto lds_b = [&](int buf, int u, double (&bv)[NT]) {
+            const int kk = TRANS ? (4 * u + g) : (4 * g + u);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = btile[buf][kk][16 * nt + c];
+        };
         const double* ap[JT];
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) ap[jt] = TRANS ? (A + (long long)(k0 + g) * lda + aoff[jt]) : (A + aoff[jt] + k0 + 4 * g);
@@ -1183,42 +1027,39 @@ skinny_gemm4_kernel(const double* __restrict__ A, long long lda, const double* _
                 }
             }
         };
-        auto fetch_b = [&](double (&bv)[NT]) {
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = *reinterpret_cast<const double*>(bbase + boff + 128 * nt);
-        };
-        double av[4][JT], bv[NT];
+        double av[4][JT], bv[NT], sr[NT];
         fetch_a(av);
-        fetch_b(bv);
+        stage_load(sr);
+        stage_store(0, sr);
+        __syncthreads();
+        lds_b(0, 0, bv);
         for (int t = 0; t < ktrips; ++t) {
             const bool last = (t + 1 == ktrips);
+            const int buf = t & 1;
+            if (!last) {
+                bbase += btrip;
+                stage_load(sr);
+            }
             const long long ainc = last ? 0 : atrip;
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) ap[jt] += ainc;
             double avn[4][JT];
-#if defined(BASQ_SKINNY_PROBE) && BASQ_SKINNY_PROBE == 2
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int jt = 0; jt < JT; ++jt) avn[u][jt] = av[u][jt] + 1.0;
-#else
             fetch_a(avn);
-#endif
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const long long binc = (u < 3) ? bstep : (last ? 0 : btrip);
-                bbase += binc;
                 double bvn[NT];
-#if defined(BASQ_SKINNY_PROBE) && BASQ_SKINNY_PROBE == 3
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bvn[nt] = bv[nt] + 1.0;
-#else
-                fetch_b(bvn);
-#endif
+                if (u < 3) lds_b(buf, u + 1, bvn);
                 mfma_step(av[u], bv);
+                if (u < 3) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[nt] = bvn[nt];
+                    for (int nt = 0; nt < NT; ++nt) bv[nt] = bvn[nt];
+                }
             }
+            if (!last) stage_store(buf ^ 1, sr);
+            // one barrier per trip: everybody has finished READING tile buf (its fragments were consumed above) and WRITING
+            // tile buf ^ 1; the next trip reads buf ^ 1 and overwrites buf
+            __syncthreads();
+            if (!last) lds_b(buf ^ 1, 0, bv);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -1258,34 +1099,16 @@ skinny_gemm4_kernel(const double* __restrict__ A, long long lda, const double* _
     }
 }
 
-#ifndef BASQ_SKINNY_MFMA4
-#define BASQ_SKINNY_MFMA4 1
-#endif
-#ifndef BASQ_SKINNY_JT7
-#define BASQ_SKINNY_JT7 2
-#endif
-
 template <int NT, int JT>
-static void launch_skinny4(bool trans, int M, int nz, hipStream_t st, const double* A, long long lda, const double* B,
+static void launch_skinny(bool trans, int M, int nz, hipStream_t st, const double* A, long long lda, const double* B,
                            long long ldb, double* C, long long ldc, long long cstride, int N, int K, int kslice) {
     dim3 grid((unsigned)((M + 64 * JT - 1) / (64 * JT)) * (unsigned)nz);
     if (trans)
-        hipLaunchKernelGGL((skinny_gemm4_kernel<NT, JT, true>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, cstride, M, N,
+        hipLaunchKernelGGL((skinny_gemm_kernel<NT, JT, true>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, cstride, M, N,
                            K, kslice, nz);
     else
-        hipLaunchKernelGGL((skinny_gemm4_kernel<NT, JT, false>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, cstride, M,
+        hipLaunchKernelGGL((skinny_gemm_kernel<NT, JT, false>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, cstride, M,
                            N, K, kslice, nz);
-}
-
-template <int NT, int JT>
-static void launch_skinny(bool trans, dim3 grid, hipStream_t st, const double* A, long long lda, const double* B,
-                          long long ldb, double* C, long long ldc, long long cstride, int M, int N, int K, int kslice) {
-    if (trans)
-        hipLaunchKernelGGL((skinny_gemm_kernel<NT, JT, true>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, cstride, M, N,
-                           K, kslice);
-    else
-        hipLaunchKernelGGL((skinny_gemm_kernel<NT, JT, false>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, cstride, M, N,
-                           K, kslice);
 }
 
 // Xsum[e] = sum_c Xpart[c][e]  (chunk order): one streaming pass instead of one GEMM per chunk partial
@@ -4051,7 +3874,7 @@ int basq_skinny_gemm_f64(const double* A, int64_t lda, int32_t trans, int32_t M,
                          int32_t N, int32_t ksplit, double* work, double* C, void* stream) {
     if (!A || !B || !C || M < 1 || N < 1 || K < 1 || ksplit < 1 || ldb < N) return BASQ_EINVAL;
     if (lda < (trans ? M : K)) return BASQ_EINVAL;
-    if (N > 208 || ldb > (1LL << 24)) return BASQ_EUNSUPPORTED;   // (the kernel keeps 12 ldb + N as a 32-bit byte offset)
+    if (N > 208 || ldb > (1LL << 24)) return BASQ_EUNSUPPORTED;   // (the kernel keeps 15 ldb + 16 doubles as a 32-bit byte offset)
     hipStream_t st = (hipStream_t)stream;
     int kslice = (K + ksplit - 1) / ksplit;
     kslice = ((kslice + 15) / 16) * 16;                          // whole 16-k trips per slice
@@ -4061,22 +3884,9 @@ int basq_skinny_gemm_f64(const double* A, int64_t lda, int32_t trans, int32_t M,
     const long long cstride = (long long)M * N;
     const int nt = (N + 15) / 16;
     // rows per wave: 32 while the accumulators (4 NT JT doubles) leave room for two waves per SIMD, 16 for wide outputs
-#if BASQ_SKINNY_MFMA4
-    if (nt <= 4) launch_skinny4<4, 2>(trans != 0, M, nz, st, A, lda, B, ldb, out, N, cstride, N, K, kslice);
-    else if (nt <= 7) launch_skinny4<7, BASQ_SKINNY_JT7>(trans != 0, M, nz, st, A, lda, B, ldb, out, N, cstride, N, K, kslice);
-    else launch_skinny4<13, 1>(trans != 0, M, nz, st, A, lda, B, ldb, out, N, cstride, N, K, kslice);
-#else
-    if (nt <= 4) {
-        dim3 grid((unsigned)((M + 127) / 128), (unsigned)nz);
-        launch_skinny<4, 2>(trans != 0, grid, st, A, lda, B, ldb, out, N, cstride, M, N, K, kslice);
-    } else if (nt <= 7) {
-        dim3 grid((unsigned)((M + 127) / 128), (unsigned)nz);
-        launch_skinny<7, 2>(trans != 0, grid, st, A, lda, B, ldb, out, N, cstride, M, N, K, kslice);
-    } else {
-        dim3 grid((unsigned)((M + 63) / 64), (unsigned)nz);
-        launch_skinny<13, 1>(trans != 0, grid, st, A, lda, B, ldb, out, N, cstride, M, N, K, kslice);
-    }
-#endif
+    if (nt <= 4) launch_skinny<4, 2>(trans != 0, M, nz, st, A, lda, B, ldb, out, N, cstride, N, K, kslice);
+    else if (nt <= 7) launch_skinny<7, 2>(trans != 0, M, nz, st, A, lda, B, ldb, out, N, cstride, N, K, kslice);
+    else launch_skinny<13, 1>(trans != 0, M, nz, st, A, lda, B, ldb, out, N, cstride, N, K, kslice);
     BASQ_CHECK_LAUNCH();
     if (nz > 1) {
         const long long n = cstride;

@@ -225,9 +225,12 @@ def main():
                 # contract vocabulary is hbm|mfma: this kernel is bound by the fp64 PIPE, which f64 MFMA and fp64 VALU share
                 # on gfx950 (roughly half of its busy cycles are MFMA, half the VALU exp epilogue) -- neither HBM nor a
                 # GEMM-shaped MFMA bound; "bound_detail" says so.
-                "bound": "mfma", "bound_detail": "fp64 pipe: f64 MFMA for the exponent arguments (0.78 per 64 pairs, one issue "
-                                                   "per ~106 cycles) + fp64 VALU for the table exponential (12.75 per 64 "
-                                                   "pairs x 4.2 cycles); the two do not overlap on gfx950; not HBM",
+                "bound": "mfma", "bound_detail": "fp64 pipe: on gfx950 the f64 matrix instructions (either form) and the fp64 "
+                                                   "VALU share ONE pipe of 16 lanes x 1 op per cycle per SIMD "
+                                                   "(profiles/r02_l_microbench_mfma_f64_4x4x4.txt: v_mfma_f64_4x4x4 runs at "
+                                                   "that rate, 75.7 TF/s; 16x16x4 at 47.4; interleaved with v_fma_f64 the times "
+                                                   "add).  Per pair: KP lane-FMAs for the exponent argument on the matrix "
+                                                   "instruction + ~13 VALU lane-ops for the table exponential; not HBM",
                 "kernel": "blocksum_kernel (fused pairwise-kernel block sums, BASQ/_rchq.py:79-99; MFMA distances + VALU exp)",
                 "achieved": achieved_tf, "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tf / PEAK_FP64_VECTOR_TFLOPS,
@@ -243,10 +246,15 @@ def main():
                 "reference_pairs_per_batch": ref_pairs,
                 "whole_batch_TFLOPs_by_reference_count": ref_pairs * (3 * d + 3) / (dt / args.steps) / 1e12,
                 "flops_per_pair": 3 * d + 3,
+                # executed lane operations per pair (KP = 4 ceil((d + 2) / 4) on the matrix instruction + 13.06 VALU, counted
+                # in the kernel's ISA) and the share of the kernel time the fp64 pipe needs for them at the nominal 2.4 GHz
+                "fp64_pipe_lane_ops_per_pair": 4 * ((d + 2 + 3) // 4) + 13.06,
+                "fp64_pipe_time_frac_nominal_clock": ((4 * ((d + 2 + 3) // 4) + 13.06) * k_pairs / (1024 * 16 * 2.4e9))
+                / (k_ms * 1e-3) if k_ms > 0 else None,
                 "hbm_algorithmic_GBs": bytes_alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
                 "hbm_peak_GBs": PEAK_HBM_GBS,
                 "note": "compute-bound on the fp64 pipe (SURVEY 8d): 33 flop per pair by SURVEY's count (3d + 3); the kernel "
-                        "spends 143 cycles per 64 pairs = its MFMA + VALU instruction mix; launch durations by HIP events on "
+                        "executes ~25 fp64 lane operations per pair on the one fp64 pipe; launch durations by HIP events on "
                         "the launch stream over one traced batch, rank 0; traffic / pipe occupancy: committed PMC passes",
             },
             "cpu_baseline": cpu,
