@@ -230,6 +230,8 @@ def _gaussian_test_matrix(ops, m, q, trace=None):
         u = ops.host_uniform(n, "rand_u")                        # CPU global generator
         ut = ops.host_uniform(16, "rand_ut") if n % 16 else None
     with _Timer(ops, trace, "basis.rand_h2d", sync=False):
+        # (the 8-MB copy on a stream of its own, so that it does not queue behind the round-1 block sums, was tried: no gain
+        # at the headline size, +2 ms at N = 1e5, where the host is not ahead of the GPU -- profiles/r02_l README entry)
         R = ops.box_muller(ops.from_pinned(u), None if ut is None else ops.from_pinned(ut))
     return R.view(m, q)
 

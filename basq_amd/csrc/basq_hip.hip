@@ -923,10 +923,15 @@ __device__ __forceinline__ double dpp_row_f64(double v) {
 
 template <int NT, int JT, bool TRANS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
-skinny_gemm_kernel(const double* __restrict__ A, long long lda, const double* __restrict__ B, long long ldb,
-                    double* __restrict__ C, long long ldc, long long cstride, int M, int N, int K, int kslice, int nz) {
+skinny_gemm_kernel(const double* __restrict__ A, long long lda, long long a_bstride, const double* __restrict__ B,
+                   long long ldb, double* __restrict__ C, long long ldc, long long cstride, int M, int N, int K, int kslice,
+                   int nz) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
+    // blockIdx.y = member of a batch of products that share B (the projection of every chunk partial): its own A, its own
+    // nz slabs of C
+    A += (long long)blockIdx.y * a_bstride;
+    C += (long long)blockIdx.y * nz * cstride;
     // Work-groups are dealt round-robin over the 8 XCDs (blockIdx.x % 8): with the K slice = blockIdx.x % nz and nz a
     // multiple of 8, an XCD only ever reads ITS slices of B, which then stay in its 4-MB L2 (B as a whole does not fit).
     const int zslice = blockIdx.x % nz;
@@ -1100,15 +1105,26 @@ skinny_gemm_kernel(const double* __restrict__ A, long long lda, const double* __
 }
 
 template <int NT, int JT>
-static void launch_skinny(bool trans, int M, int nz, hipStream_t st, const double* A, long long lda, const double* B,
-                           long long ldb, double* C, long long ldc, long long cstride, int N, int K, int kslice) {
-    dim3 grid((unsigned)((M + 64 * JT - 1) / (64 * JT)) * (unsigned)nz);
+static void launch_skinny(bool trans, int M, int nz, int nbatch, hipStream_t st, const double* A, long long lda,
+                          long long a_bstride, const double* B, long long ldb, double* C, long long ldc, long long cstride,
+                          int N, int K, int kslice) {
+    dim3 grid((unsigned)((M + 64 * JT - 1) / (64 * JT)) * (unsigned)nz, (unsigned)nbatch);
     if (trans)
-        hipLaunchKernelGGL((skinny_gemm_kernel<NT, JT, true>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, cstride, M, N,
-                           K, kslice, nz);
+        hipLaunchKernelGGL((skinny_gemm_kernel<NT, JT, true>), grid, dim3(256), 0, st, A, lda, a_bstride, B, ldb, C, ldc,
+                           cstride, M, N, K, kslice, nz);
     else
-        hipLaunchKernelGGL((skinny_gemm_kernel<NT, JT, false>), grid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, cstride, M,
-                           N, K, kslice, nz);
+        hipLaunchKernelGGL((skinny_gemm_kernel<NT, JT, false>), grid, dim3(256), 0, st, A, lda, a_bstride, B, ldb, C, ldc,
+                           cstride, M, N, K, kslice, nz);
+}
+
+// rows per wave: 32 while the accumulators (4 NT JT doubles) leave room for two waves per SIMD, 16 for wide outputs
+static void dispatch_skinny(bool trans, int M, int nz, int nbatch, hipStream_t st, const double* A, long long lda,
+                            long long a_bstride, const double* B, long long ldb, double* C, long long cstride, int N, int K,
+                            int kslice) {
+    const int nt = (N + 15) / 16;
+    if (nt <= 4) launch_skinny<4, 2>(trans, M, nz, nbatch, st, A, lda, a_bstride, B, ldb, C, N, cstride, N, K, kslice);
+    else if (nt <= 7) launch_skinny<7, 2>(trans, M, nz, nbatch, st, A, lda, a_bstride, B, ldb, C, N, cstride, N, K, kslice);
+    else launch_skinny<13, 1>(trans, M, nz, nbatch, st, A, lda, a_bstride, B, ldb, C, N, cstride, N, K, kslice);
 }
 
 // Xsum[e] = sum_c Xpart[c][e]  (chunk order): one streaming pass instead of one GEMM per chunk partial
@@ -3518,6 +3534,27 @@ __global__ void project_chunks_reduce_kernel(const double* __restrict__ work, in
     out[idx] = v;
 }
 
+// The same for slabs that come TRANSPOSED out of the tall-skinny kernel (work[(c nz + z)][s][i], i = basis row): threads run
+// along i, so the slab reads are coalesced; the strided writes are 2.7 MB per epoch start.
+__global__ void project_chunks_reduce_t_kernel(const double* __restrict__ work, int nz, int q, int S,
+                                               const double* __restrict__ totpart, int n_chunks, double outputscale,
+                                               double* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per = (long long)(q + 1) * S;
+    if (idx >= per * n_chunks) return;
+    const int c = (int)(idx / per);
+    const int e = (int)(idx - (long long)c * per);
+    const int s2 = e / (q + 1), r = e - s2 * (q + 1);
+    double v = 0.0;
+    if (r == 0) {
+        v = totpart[(long long)c * S + s2];
+    } else {
+        for (int z = 0; z < nz; ++z) v += work[(((long long)c * nz + z) * S + s2) * q + (r - 1)];
+        v *= outputscale;
+    }
+    out[((long long)c * (q + 1) + r) * S + s2] = v;
+}
+
 __global__ void sum_parts_kernel(const double* __restrict__ parts, int n_parts, long long n, double* __restrict__ out) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
@@ -3532,6 +3569,31 @@ int basq_project_chunks_f64(const double* Ut, int32_t q, int32_t m, const double
     if (!Ut || !Xpart || !totpart || !work || !out || q < 1 || m < 1 || S < 1 || n_chunks < 1 || ksplit < 1)
         return BASQ_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (q <= 208 && n_chunks <= 65535) {
+        // out[c][1 + i][s] = outputscale * sum_k Ut[k][i] Xpart[c][k][s] as the batch of tall-skinny products
+        // Xpart[c]^T [S, m] @ Ut [m, q]: every chunk partial (16 MB at the headline size) streams from HBM exactly once, the
+        // basis slice of a K step goes through LDS once per work-group, and the products run on the full-rate 4x4x4
+        // instruction (the 16 x 16-tile kernel below re-read the basis once per wave: 2 GB through L2 per epoch start).
+        const int rows_per_wg = (q > 112) ? 64 : 128;
+        const int rowblocks = (S + rows_per_wg - 1) / rows_per_wg;
+        // K slices: as many as fit ONE round of the chip's 2048 wave slots (two 252-register waves per SIMD) -- one wave
+        // too many and the launch takes two rounds (measured: 544 work-groups 249 us, 510 work-groups half of that)
+        int want = 2048 / (rowblocks * n_chunks * 4);
+        if (want > m / 64) want = m / 64;                        // at least four 16-k trips per slice
+        if (want > ksplit) want = ksplit;                        // (the caller sized `work` for ksplit slabs per chunk)
+        if (want < 1) want = 1;
+        int kslice = (m + want - 1) / want;
+        kslice = ((kslice + 15) / 16) * 16;
+        const int nz = (m + kslice - 1) / kslice;
+        dispatch_skinny(true, S, nz, n_chunks, st, Xpart, (long long)S, (long long)m * S, Ut, (long long)q, work,
+                        (long long)S * q, q, m, kslice);
+        BASQ_CHECK_LAUNCH();
+        const long long tot = (long long)(q + 1) * S * n_chunks;
+        hipLaunchKernelGGL(project_chunks_reduce_t_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, work, nz, q,
+                           S, totpart, n_chunks, outputscale, out);
+        BASQ_CHECK_LAUNCH();
+        return BASQ_OK;
+    }
     int kslice = (m + ksplit - 1) / ksplit;
     kslice = ((kslice + 15) / 16) * 16;
     const int nz = (m + kslice - 1) / kslice;          // <= ksplit slabs per chunk
@@ -3882,11 +3944,7 @@ int basq_skinny_gemm_f64(const double* A, int64_t lda, int32_t trans, int32_t M,
     if (nz > 1 && !work) return BASQ_EINVAL;
     double* out = (nz > 1) ? work : C;
     const long long cstride = (long long)M * N;
-    const int nt = (N + 15) / 16;
-    // rows per wave: 32 while the accumulators (4 NT JT doubles) leave room for two waves per SIMD, 16 for wide outputs
-    if (nt <= 4) launch_skinny<4, 2>(trans != 0, M, nz, st, A, lda, B, ldb, out, N, cstride, N, K, kslice);
-    else if (nt <= 7) launch_skinny<7, 2>(trans != 0, M, nz, st, A, lda, B, ldb, out, N, cstride, N, K, kslice);
-    else launch_skinny<13, 1>(trans != 0, M, nz, st, A, lda, B, ldb, out, N, cstride, N, K, kslice);
+    dispatch_skinny(trans != 0, M, nz, 1, st, A, lda, 0LL, B, ldb, out, cstride, N, K, kslice);
     BASQ_CHECK_LAUNCH();
     if (nz > 1) {
         const long long n = cstride;
