@@ -112,7 +112,9 @@ int basq_blocksum_f64(const basq_kernel_spec* spec, const double* nys, int32_t m
  * The same contraction per chunk (Ut [m, q] as above) -- out[c] = [ totpart[c] ; outputscale * U @ Xpart[c] ], each (q+1) x S --
  * for residue-class chunks: the classes' MESSAGES (100 x 200 doubles each) are all the later rounds of an epoch need
  * (basq_regroup_classes_f64 applies to them row by row), so the [m, S] class partials can be dropped right after this
- * call.  work: n_chunks * nz * q * S doubles, nz = ceil(m / (16 ceil(ceil(m / ksplit) / 16))) <= ksplit.
+ * call.  work: n_chunks * ksplit * q * S doubles (the library picks nz <= ksplit K slices per chunk so that the launch fills
+ * one round of the chip's wave slots; for q <= 208 the chunks run as one batched launch of the tall-skinny kernel of
+ * basq_skinny_gemm_f64, Xpart[c]^T [S, m] @ Ut [m, q], every partial streamed from HBM once).
  * basq_sum_parts_f64: out[e] = sum_p parts[p][e] in index order (the round's message = the sum of its class messages).
  */
 int basq_project_chunks_f64(const double* Ut, int32_t q, int32_t m, const double* Xpart, const double* totpart,
@@ -332,9 +334,11 @@ int basq_trsm_rows_f64(const double* X, int64_t ldx, int64_t rows, int32_t q, co
 /*
  * The big products of the randomised range finder (torch.svd_lowrank -> torch._lowrank.get_approximate_basis,
  * BASQ/_rchq.py:29: A @ R, A^H @ Q, A @ Q, Q^H @ A, and the Gram products X^T X of the orthonormalisations) as a
- * tall-skinny f64 MFMA GEMM:  C[M, N] = op(A) @ B[K, N],  op(A) = A[M, K] (trans = 0) or A^T with A stored [K, M]
- * (trans != 0), all row-major, N <= 208.  K is split into `ksplit` slices of whole 16-k trips; their partial products go to
- * work [>= ksplit * M * N] and are added in slice order (work may be NULL when one slice results).  C is dense (ld = N).
+ * tall-skinny f64 GEMM on v_mfma_f64_4x4x4_4b:  C[M, N] = op(A) @ B[K, N],  op(A) = A[M, K] (trans = 0) or A^T with A
+ * stored [K, M] (trans != 0), all row-major, N <= 208, ldb <= 2^24.  K is split into `ksplit` slices of whole 16-k trips;
+ * their partial products go to work [>= ksplit * M * N] and are added in slice order (work may be NULL when one slice
+ * results).  C is dense (ld = N).  B is only ever read inside its K x ldb extent (the kernel's wide row reads stop short of
+ * the last rows, which are read masked).
  */
 int basq_skinny_gemm_f64(const double* A, int64_t lda, int32_t trans, int32_t M, int32_t K, const double* B, int64_t ldb,
                          int32_t N, int32_t ksplit, double* work, double* C, void* stream);
