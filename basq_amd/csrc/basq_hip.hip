@@ -2488,7 +2488,10 @@ template <int NV>
 __global__ void __launch_bounds__(256) nullspace_apply_kernel(const double* __restrict__ V,
                                                               const double* __restrict__ tau, int m, int n,
                                                               double* __restrict__ PhiT) {
-    constexpr int PF = 4;                                 // reflector rows in flight (L2 latency ~ one reduction each)
+    // Reflector rows in flight.  V was written a moment ago by ONE work-group: for the other XCDs its lines come from
+    // memory, not from their L2 (~1.2 us), i.e. four reductions' worth of latency is not enough -- 4 rows: 31.3 us,
+    // 8: 28.1, 12: 25.7, 16: 25.6 (profiles/r02_m_nullspace_apply_rows_in_flight.txt)
+    constexpr int PF = 12;
     const int lane = threadIdx.x & 63;
     const int c0 = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c0 >= n - m) return;                              // wave-uniform
