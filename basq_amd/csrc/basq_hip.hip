@@ -921,7 +921,11 @@ __device__ __forceinline__ double dpp_row_f64(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-template <int NT, int JT, bool TRANS>
+// NT full column tiles of 16 + REM column GROUPS of 4 (N <= 16 NT + 4 REM).  A group costs ONE product per A fragment instead
+// of four: its B fragment holds the group's 4 columns in all four blocks and the A fragment goes in un-rotated, so block b
+// multiplies rows 4 b .. 4 b + 3 with those columns -- D of lane (g, c) is C[16 jt + 4 (c >> 2) + g][16 NT + 4 r + (c & 3)].
+// At N = 99 that is 25 products per fragment and step instead of 28.
+template <int NT, int REM, int JT, bool TRANS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2)))
 skinny_gemm_kernel(const double* __restrict__ A, long long lda, long long a_bstride, const double* __restrict__ B,
                    long long ldb, double* __restrict__ C, long long ldc, long long cstride, int M, int N, int K, int kslice,
@@ -951,10 +955,18 @@ skinny_gemm_kernel(const double* __restrict__ A, long long lda, long long a_bstr
         if (r >= M) r = M - 1;
         aoff[jt] = TRANS ? (long long)r : (long long)r * lda;
     }
-    int bcol[NT];
+    constexpr int NB = NT + REM;                 // B fragments per step: NT tiles + REM column groups
+    constexpr int W = 16 * NT + 4 * REM;         // columns of B the kernel works on
+    int bcol[NB];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bcol[nt] = (nt * 16 + c < N) ? (nt * 16 + c) : (N - 1);
-    double acc[JT][4][NT];
+#pragma unroll
+    for (int r = 0; r < REM; ++r) bcol[NT + r] = (16 * NT + 4 * r + (c & 3) < N) ? (16 * NT + 4 * r + (c & 3)) : (N - 1);
+    double acc[JT][4][NT], accr[JT][REM > 0 ? REM : 1];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+        for (int r = 0; r < (REM > 0 ? REM : 1); ++r) accr[jt][r] = 0.0;
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
@@ -963,7 +975,7 @@ skinny_gemm_kernel(const double* __restrict__ A, long long lda, long long a_bstr
             for (int nt = 0; nt < NT; ++nt) acc[jt][rho][nt] = 0.0;
     auto kidx = [&](int k, int u) { return TRANS ? (k + 4 * u + g) : (k + 4 * g + u); };
     const bool a_vec = !TRANS && ((lda & 1) == 0) && (((uintptr_t)A & 15) == 0);
-    auto mfma_step = [&](const double (&a)[JT], const double (&bv)[NT]) {
+    auto mfma_step = [&](const double (&a)[JT], const double (&bv)[NB]) {
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
             double ar[4];
@@ -976,6 +988,9 @@ skinny_gemm_kernel(const double* __restrict__ A, long long lda, long long a_bstr
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
                     acc[jt][rho][nt] = __builtin_amdgcn_mfma_f64_4x4x4f64(ar[rho], bv[nt], acc[jt][rho][nt], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < REM; ++r)
+                accr[jt][r] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[jt], bv[NT + r], accr[jt][r], 0, 0, 0);
         }
     };
 
@@ -988,7 +1003,7 @@ skinny_gemm_kernel(const double* __restrict__ A, long long lda, long long a_bstr
     // The staging reads are 16 NT columns wide whatever N is: columns >= N of a row are the head of the following row(s)
     // -- finite or not, they only reach accumulator columns that are never stored -- so the pipelined trips stop short of
     // the last over_rows rows of B, where such a read would leave the matrix.
-    constexpr int W = 16 * NT;
+    constexpr int NLD = (W + 15) / 16;           // staging loads per thread (the last one partial when REM > 0)
     __shared__ double btile[2][16][W];
     const int over_rows = (W + (int)ldb - 1) / (int)ldb;
     const int kfast_end = (k1 < K - over_rows) ? k1 : (K - over_rows);
@@ -999,18 +1014,22 @@ skinny_gemm_kernel(const double* __restrict__ A, long long lda, long long a_bstr
         const char* bbase = reinterpret_cast<const char*>(B + (long long)k0 * ldb);
         const unsigned soff = (unsigned)(((long long)skk * ldb + sc) * 8);
         const long long btrip = 16 * ldb * 8;
-        auto stage_load = [&](double (&sr)[NT]) {
+        auto stage_load = [&](double (&sr)[NLD]) {
 #pragma unroll
-            for (int i = 0; i < NT; ++i) sr[i] = *reinterpret_cast<const double*>(bbase + soff + 128 * i);
+            for (int i = 0; i < NLD; ++i)
+                if (16 * i + 16 <= W || sc + 16 * i < W) sr[i] = *reinterpret_cast<const double*>(bbase + soff + 128 * i);
         };
-        auto stage_store = [&](int buf, const double (&sr)[NT]) {
+        auto stage_store = [&](int buf, const double (&sr)[NLD]) {
 #pragma unroll
-            for (int i = 0; i < NT; ++i) btile[buf][skk][sc + 16 * i] = sr[i];
+            for (int i = 0; i < NLD; ++i)
+                if (16 * i + 16 <= W || sc + 16 * i < W) btile[buf][skk][sc + 16 * i] = sr[i];
         };
-        auto lds_b = [&](int buf, int u, double (&bv)[NT]) {
+        auto lds_b = [&](int buf, int u, double (&bv)[NB]) {
             const int kk = TRANS ? (4 * u + g) : (4 * g + u);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) bv[nt] = btile[buf][kk][16 * nt + c];
+#pragma unroll
+            for (int r = 0; r < REM; ++r) bv[NT + r] = btile[buf][kk][16 * NT + 4 * r + (c & 3)];
         };
         const double* ap[JT];
 #pragma unroll
@@ -1032,7 +1051,7 @@ skinny_gemm_kernel(const double* __restrict__ A, long long lda, long long a_bstr
                 }
             }
         };
-        double av[4][JT], bv[NT], sr[NT];
+        double av[4][JT], bv[NB], sr[NLD];
         fetch_a(av);
         stage_load(sr);
         stage_store(0, sr);
@@ -1052,12 +1071,12 @@ skinny_gemm_kernel(const double* __restrict__ A, long long lda, long long a_bstr
             fetch_a(avn);
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                double bvn[NT];
+                double bvn[NB];
                 if (u < 3) lds_b(buf, u + 1, bvn);
                 mfma_step(av[u], bv);
                 if (u < 3) {
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bv[nt] = bvn[nt];
+                    for (int nt = 0; nt < NB; ++nt) bv[nt] = bvn[nt];
                 }
             }
             if (!last) stage_store(buf ^ 1, sr);
@@ -1078,7 +1097,7 @@ skinny_gemm_kernel(const double* __restrict__ A, long long lda, long long a_bstr
         for (int u = 0; u < 4; ++u) {
             const int kk = kidx(k, u);
             const int kc = (kk < k1) ? kk : (k1 - 1);
-            double a[JT], bv[NT];
+            double a[JT], bv[NB];
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
                 const double v = TRANS ? A[(long long)kc * lda + aoff[jt]] : A[aoff[jt] + kc];
@@ -1086,7 +1105,7 @@ skinny_gemm_kernel(const double* __restrict__ A, long long lda, long long a_bstr
             }
             const double* bp = B + (long long)kc * ldb;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = bp[bcol[nt]];
+            for (int nt = 0; nt < NB; ++nt) bv[nt] = bp[bcol[nt]];
             mfma_step(a, bv);
         }
     }
@@ -1102,18 +1121,28 @@ skinny_gemm_kernel(const double* __restrict__ A, long long lda, long long a_bstr
                 if (row < M) Cz[(long long)row * ldc + nt * 16 + c] = acc[jt][rho][nt];
             }
     }
+#pragma unroll
+    for (int r = 0; r < REM; ++r) {
+        const int col = 16 * NT + 4 * r + (c & 3);
+        if (col >= N) continue;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const int row = r0 + jt * 16 + 4 * (c >> 2) + g;
+            if (row < M) Cz[(long long)row * ldc + col] = accr[jt][r];
+        }
+    }
 }
 
-template <int NT, int JT>
+template <int NT, int REM, int JT>
 static void launch_skinny(bool trans, int M, int nz, int nbatch, hipStream_t st, const double* A, long long lda,
                           long long a_bstride, const double* B, long long ldb, double* C, long long ldc, long long cstride,
                           int N, int K, int kslice) {
     dim3 grid((unsigned)((M + 64 * JT - 1) / (64 * JT)) * (unsigned)nz, (unsigned)nbatch);
     if (trans)
-        hipLaunchKernelGGL((skinny_gemm_kernel<NT, JT, true>), grid, dim3(256), 0, st, A, lda, a_bstride, B, ldb, C, ldc,
+        hipLaunchKernelGGL((skinny_gemm_kernel<NT, REM, JT, true>), grid, dim3(256), 0, st, A, lda, a_bstride, B, ldb, C, ldc,
                            cstride, M, N, K, kslice, nz);
     else
-        hipLaunchKernelGGL((skinny_gemm_kernel<NT, JT, false>), grid, dim3(256), 0, st, A, lda, a_bstride, B, ldb, C, ldc,
+        hipLaunchKernelGGL((skinny_gemm_kernel<NT, REM, JT, false>), grid, dim3(256), 0, st, A, lda, a_bstride, B, ldb, C, ldc,
                            cstride, M, N, K, kslice, nz);
 }
 
@@ -1121,10 +1150,13 @@ static void launch_skinny(bool trans, int M, int nz, int nbatch, hipStream_t st,
 static void dispatch_skinny(bool trans, int M, int nz, int nbatch, hipStream_t st, const double* A, long long lda,
                             long long a_bstride, const double* B, long long ldb, double* C, long long cstride, int N, int K,
                             int kslice) {
-    const int nt = (N + 15) / 16;
-    if (nt <= 4) launch_skinny<4, 2>(trans, M, nz, nbatch, st, A, lda, a_bstride, B, ldb, C, N, cstride, N, K, kslice);
-    else if (nt <= 7) launch_skinny<7, 2>(trans, M, nz, nbatch, st, A, lda, a_bstride, B, ldb, C, N, cstride, N, K, kslice);
-    else launch_skinny<13, 1>(trans, M, nz, nbatch, st, A, lda, a_bstride, B, ldb, C, N, cstride, N, K, kslice);
+    const int nt = (N + 15) / 16, ng = (N + 3) / 4;
+    // the two batch sizes of the BASELINE configurations (q = 99, 199) get their exact column-group count
+    if (ng == 25) launch_skinny<6, 1, 2>(trans, M, nz, nbatch, st, A, lda, a_bstride, B, ldb, C, N, cstride, N, K, kslice);
+    else if (ng == 50) launch_skinny<12, 2, 1>(trans, M, nz, nbatch, st, A, lda, a_bstride, B, ldb, C, N, cstride, N, K, kslice);
+    else if (nt <= 4) launch_skinny<4, 0, 2>(trans, M, nz, nbatch, st, A, lda, a_bstride, B, ldb, C, N, cstride, N, K, kslice);
+    else if (nt <= 7) launch_skinny<7, 0, 2>(trans, M, nz, nbatch, st, A, lda, a_bstride, B, ldb, C, N, cstride, N, K, kslice);
+    else launch_skinny<13, 0, 1>(trans, M, nz, nbatch, st, A, lda, a_bstride, B, ldb, C, N, cstride, N, K, kslice);
 }
 
 // Xsum[e] = sum_c Xpart[c][e]  (chunk order): one streaming pass instead of one GEMM per chunk partial

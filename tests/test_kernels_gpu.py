@@ -616,6 +616,10 @@ def test_skinny_gemm_vs_torch(hip_ops, M, K, N, trans, ksplit):
     (70, 96, 3, 0, 1),           # a row of B shorter than one tile: the wide reads span many rows, the last ones run masked
     (512, 2048, 199, 1, 2),      # 13 column tiles
     (96, 160, 112, 0, 1),        # N a whole number of tiles
+    (256, 2048, 100, 0, 2),      # 6 tiles + 1 column group, all four columns of the group in use
+    (130, 512, 97, 3, 1),        # the same kernel with one column of the group (and NaN right behind it), ragged rows
+    (128, 1024, 200, 0, 2),      # 12 tiles + 2 column groups
+    (70, 512, 197, 1, 1),        # ... with one column in the second group
 ])
 @pytest.mark.parametrize("trans", [False, True])
 def test_skinny_gemm_pipelined_path(hip_ops, M, K, N, pad, ksplit, trans):
