@@ -1151,8 +1151,15 @@ static void dispatch_skinny(bool trans, int M, int nz, int nbatch, hipStream_t s
                             long long a_bstride, const double* B, long long ldb, double* C, long long cstride, int N, int K,
                             int kslice) {
     const int nt = (N + 15) / 16, ng = (N + 3) / 4;
+    // Small launches (the Gram products of the orthonormalisations, the per-round projections of the few candidates the
+    // class messages do not cover) are latency chains of 16-k trips: 16 rows per wave halve the products per trip, and the
+    // twice as many waves still fit the chip several times over.
+    const bool small = (long long)((M + 127) / 128) * nz * nbatch <= 128;
+    if (small && ng == 25) launch_skinny<6, 1, 1>(trans, M, nz, nbatch, st, A, lda, a_bstride, B, ldb, C, N, cstride, N, K, kslice);
+    else if (small && nt <= 4) launch_skinny<4, 0, 1>(trans, M, nz, nbatch, st, A, lda, a_bstride, B, ldb, C, N, cstride, N, K, kslice);
+    else if (small && nt <= 7) launch_skinny<7, 0, 1>(trans, M, nz, nbatch, st, A, lda, a_bstride, B, ldb, C, N, cstride, N, K, kslice);
     // the two batch sizes of the BASELINE configurations (q = 99, 199) get their exact column-group count
-    if (ng == 25) launch_skinny<6, 1, 2>(trans, M, nz, nbatch, st, A, lda, a_bstride, B, ldb, C, N, cstride, N, K, kslice);
+    else if (ng == 25) launch_skinny<6, 1, 2>(trans, M, nz, nbatch, st, A, lda, a_bstride, B, ldb, C, N, cstride, N, K, kslice);
     else if (ng == 50) launch_skinny<12, 2, 1>(trans, M, nz, nbatch, st, A, lda, a_bstride, B, ldb, C, N, cstride, N, K, kslice);
     else if (nt <= 4) launch_skinny<4, 0, 2>(trans, M, nz, nbatch, st, A, lda, a_bstride, B, ldb, C, N, cstride, N, K, kslice);
     else if (nt <= 7) launch_skinny<7, 0, 2>(trans, M, nz, nbatch, st, A, lda, a_bstride, B, ldb, C, N, cstride, N, K, kslice);

@@ -4,7 +4,7 @@ set -u
 out=gpurun_out/s2s; mkdir -p $out
 timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "skinny or project" > $out/tests_skinny.log 2>&1 || { tail -30 $out/tests_skinny.log | cut -c1-200; exit 1; }
 tail -1 $out/tests_skinny.log
-timeout -k 10 200 python tools/bench_skinny_gemm.py 2>&1 | grep -v amdgpu.ids | grep "skinny\|X^T" | grep "auto\|= 16\|= 62" > $out/bench.txt; cat $out/bench.txt
+timeout -k 10 200 python tools/bench_skinny_gemm.py 2>&1 | grep -v amdgpu.ids | grep "skinny\|X^T" | grep "auto\|= 16\|= 62\|= 32\|=125" > $out/bench.txt; cat $out/bench.txt
 timeout -k 10 200 python tools/bench_skinny_gemm.py --q 199 2>&1 | grep -v amdgpu.ids | grep "auto\|=  8" > $out/bench199.txt; cat $out/bench199.txt
 timeout -k 10 1500 python -m pytest tests -x -q -m gpu > $out/gpu_tests.log 2>&1
 rc=$?; echo "gpu tests rc=$rc" >> $out/gpu_tests.log; tail -2 $out/gpu_tests.log | cut -c1-300
