@@ -1227,15 +1227,13 @@ __global__ void finalize_kernel(const double* __restrict__ parts, int n_parts, i
     }
     const int r = idx / S, s = idx % S;
     const long long stride = (long long)msg_rows * S;
-    double tot = 0.0;
-    for (int p = 0; p < n_parts; ++p) tot += parts[p * stride + s];
+    const double tot = ordered_strided_sum(parts + s, n_parts, stride);
     if (r == 0) {
         XcarT[idx] = 1.0;
         tot_out[s] = tot;
         return;
     }
-    double v = 0.0;
-    for (int p = 0; p < n_parts; ++p) v += parts[p * stride + idx];
+    double v = ordered_strided_sum(parts + idx, n_parts, stride);
     if (diagU) {
         const bool tail_set = diag_tail_row != 0 && s == S - 1;
         const double* urow = diagU + (long long)(r - 1) * ld_diag;
@@ -3202,6 +3200,10 @@ __global__ void __launch_bounds__(1024) chol_factor_panel_kernel(double* __restr
 #undef BASQ_TRI
 }
 
+// LSH: the factor is copied into LDS first (one coalesced pass).  L was written a moment ago by ONE work-group, so for the
+// other XCDs its lines come from memory (~1.2 us per dependent access), and every panel needs new rows of it twice: with L
+// in global memory the 13 panels of q = 99 cost 60 us, nearly all of it those round trips.
+template <bool LSH>
 __global__ void __launch_bounds__(512) trsm_rows_kernel(const double* __restrict__ X, long long ldx, long long rows, int q,
                                                         const double* __restrict__ L, double* __restrict__ Qo,
                                                         long long ldq) {
@@ -3209,53 +3211,60 @@ __global__ void __launch_bounds__(512) trsm_rows_kernel(const double* __restrict
     constexpr int NB = BASQ_CHOL_NB;
     const int ld = q | 1;                                 // odd leading dimension: lanes (= rows) hit distinct banks
     double* Y = sm;                                       // [64][ld]
+    double* Lsh = sm + 64 * ld;                           // [q][q] (LSH only)
     const int tid = threadIdx.x;
     const long long r0 = (long long)blockIdx.x * 64;
     const int nr = (rows - r0 < 64) ? (int)(rows - r0) : 64;
+    if (LSH)
+        for (int e = tid; e < q * q; e += 512) Lsh[e] = L[e];
     for (int e = tid; e < 64 * q; e += 512) {
         const int r = e / q, c = e - r * q;
         Y[r * ld + c] = (r < nr) ? X[(r0 + r) * ldx + c] : 0.0;
     }
     __syncthreads();
     const int r = tid & 63, c = tid >> 6;                 // wave = panel column c (uniform), lane = row
-    for (int j0 = 0; j0 < q; j0 += NB) {
-        const int nb = (q - j0 < NB) ? (q - j0) : NB;
-        if (c < nb) {
-            // s = y[r][j0 + c] - sum_{k < j0} y[r][k] L[j0 + c][k]   (L row uniform per wave; four chains)
-            const double* lrow = L + (size_t)(j0 + c) * q;
-            const double* yrow = Y + r * ld;
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            int k = 0;
-            for (; k + 3 < j0; k += 4) {
-                s0 = __builtin_fma(yrow[k], lrow[k], s0);
-                s1 = __builtin_fma(yrow[k + 1], lrow[k + 1], s1);
-                s2 = __builtin_fma(yrow[k + 2], lrow[k + 2], s2);
-                s3 = __builtin_fma(yrow[k + 3], lrow[k + 3], s3);
-            }
-            for (; k < j0; ++k) s0 = __builtin_fma(yrow[k], lrow[k], s0);
-            Y[r * ld + j0 + c] -= (s0 + s1) + (s2 + s3);
-        }
-        __syncthreads();
-        if (tid < 64) {                                   // one thread per row: the 8 x 8 block by forward substitution
-            double y[NB];
-#pragma unroll
-            for (int cc = 0; cc < NB; ++cc) y[cc] = (cc < nb) ? Y[tid * ld + j0 + cc] : 0.0;
-#pragma unroll
-            for (int cc = 0; cc < NB; ++cc) {
-                if (cc < nb) {
-                    const double* lrow = L + (size_t)(j0 + cc) * q + j0;
-                    double v = y[cc];
-#pragma unroll
-                    for (int k = 0; k < cc; ++k) v -= y[k] * lrow[k];
-                    y[cc] = v / lrow[cc];
+    auto panels = [&](const double* Lb) {
+        for (int j0 = 0; j0 < q; j0 += NB) {
+            const int nb = (q - j0 < NB) ? (q - j0) : NB;
+            if (c < nb) {
+                // s = y[r][j0 + c] - sum_{k < j0} y[r][k] L[j0 + c][k]   (L row uniform per wave; four chains)
+                const double* lrow = Lb + (size_t)(j0 + c) * q;
+                const double* yrow = Y + r * ld;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                int k = 0;
+                for (; k + 3 < j0; k += 4) {
+                    s0 = __builtin_fma(yrow[k], lrow[k], s0);
+                    s1 = __builtin_fma(yrow[k + 1], lrow[k + 1], s1);
+                    s2 = __builtin_fma(yrow[k + 2], lrow[k + 2], s2);
+                    s3 = __builtin_fma(yrow[k + 3], lrow[k + 3], s3);
                 }
+                for (; k < j0; ++k) s0 = __builtin_fma(yrow[k], lrow[k], s0);
+                Y[r * ld + j0 + c] -= (s0 + s1) + (s2 + s3);
             }
+            __syncthreads();
+            if (tid < 64) {                                   // one thread per row: the 8 x 8 block by forward substitution
+                double y[NB];
 #pragma unroll
-            for (int cc = 0; cc < NB; ++cc)
-                if (cc < nb) Y[tid * ld + j0 + cc] = y[cc];
+                for (int cc = 0; cc < NB; ++cc) y[cc] = (cc < nb) ? Y[tid * ld + j0 + cc] : 0.0;
+#pragma unroll
+                for (int cc = 0; cc < NB; ++cc) {
+                    if (cc < nb) {
+                        const double* lrow = Lb + (size_t)(j0 + cc) * q + j0;
+                        double v = y[cc];
+#pragma unroll
+                        for (int k = 0; k < cc; ++k) v -= y[k] * lrow[k];
+                        y[cc] = v / lrow[cc];
+                    }
+                }
+#pragma unroll
+                for (int cc = 0; cc < NB; ++cc)
+                    if (cc < nb) Y[tid * ld + j0 + cc] = y[cc];
+            }
+            __syncthreads();
         }
-        __syncthreads();
-    }
+    };
+    if (LSH) panels(Lsh);
+    else panels(L);
     for (int e = tid; e < 64 * q; e += 512) {
         const int rr = e / q, cc = e - rr * q;
         if (rr < nr) Qo[(r0 + rr) * ldq + cc] = Y[rr * ld + cc];
@@ -3979,10 +3988,21 @@ int basq_trsm_rows_f64(const double* X, int64_t ldx, int64_t rows, int32_t q, co
     if (rows == 0) return BASQ_OK;
     const size_t lds = (size_t)64 * (q | 1) * sizeof(double);
     if (lds > 163840 - 256) return BASQ_EUNSUPPORTED;            // q <= 318
-    if (hipFuncSetAttribute((const void*)trsm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return BASQ_ELAUNCH;
-    hipLaunchKernelGGL(trsm_rows_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(512), lds, (hipStream_t)stream, X,
-                       (long long)ldx, (long long)rows, q, L, Q, (long long)ldq);
+    const size_t lds_l = lds + (size_t)q * q * sizeof(double);   // with the factor in LDS as well: q <= 112
+    const dim3 grid((unsigned)((rows + 63) / 64));
+    if (lds_l <= 163840 - 256) {
+        if (hipFuncSetAttribute((const void*)trsm_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l) !=
+            hipSuccess)
+            return BASQ_ELAUNCH;
+        hipLaunchKernelGGL(trsm_rows_kernel<true>, grid, dim3(512), lds_l, (hipStream_t)stream, X, (long long)ldx,
+                           (long long)rows, q, L, Q, (long long)ldq);
+    } else {
+        if (hipFuncSetAttribute((const void*)trsm_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return BASQ_ELAUNCH;
+        hipLaunchKernelGGL(trsm_rows_kernel<false>, grid, dim3(512), lds, (hipStream_t)stream, X, (long long)ldx,
+                           (long long)rows, q, L, Q, (long long)ldq);
+    }
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }

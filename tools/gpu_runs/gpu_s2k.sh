@@ -12,7 +12,7 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 cm = [i for i, r in enumerate(rows) if 'col_mean' in r['Kernel_Name']]; start = cm[-2]; rows = rows[:cm[-1]]
 pass
 ns = [i for i, r in enumerate(rows) if 'bidiag' in r['Kernel_Name'] and i > start]
-a, b = ns[2], ns[5]
+gk = [i for i, r in enumerate(rows) if 'gram_kernel' in r['Kernel_Name'] and i > start]; a, b = gk[0] - 3, ns[0]
 t0 = int(rows[a]['Start_Timestamp']); prev_end = t0
 for r in rows[a:b + 1]:
     st, en = int(r['Start_Timestamp']), int(r['End_Timestamp'])
