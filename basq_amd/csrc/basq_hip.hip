@@ -3083,7 +3083,8 @@ __global__ void __launch_bounds__(1024) chol_packed_lds_kernel(double* __restric
 //   L rows that are uniform per wave), then one thread per row solves its 8 x 8 block.  Replaces W = L^-T + a GEMM.
 // ------------------------------------------------------------------------------------------------
 #define BASQ_CHOL_NB 8
-__global__ void __launch_bounds__(1024) chol_factor_panel_kernel(double* __restrict__ G, int q, int* __restrict__ info,
+template <int NTHR>
+__global__ void __launch_bounds__(NTHR) chol_factor_panel_kernel(double* __restrict__ G, int q, int* __restrict__ info,
                                                                  double rel_tol) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* Lp = sm;                                     // [q (q + 1) / 2] packed rows
@@ -3092,17 +3093,18 @@ __global__ void __launch_bounds__(1024) chol_factor_panel_kernel(double* __restr
     constexpr int NB = BASQ_CHOL_NB;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 #define BASQ_TRI(i, j) Lp[(size_t)(i) * ((i) + 1) / 2 + (j)]
-    for (int i = tid >> 7; i < q; i += 8)
+    for (int i = tid >> 7; i < q; i += NTHR / 128)
         for (int k = tid & 127; k <= i; k += 128) BASQ_TRI(i, k) = G[(size_t)i * q + k];
     __syncthreads();
-    double dm = (tid < q) ? BASQ_TRI(tid, tid) : 0.0;
+    double dm = 0.0;
+    for (int i = tid; i < q; i += NTHR) dm = fmax(dm, BASQ_TRI(i, i));
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) dm = fmax(dm, __shfl_xor(dm, o, 64));
     if (lane == 0) red[wv] = dm;
     __syncthreads();
     if (tid == 0) {
         double v = red[0];
-        for (int w = 1; w < 16; ++w) v = fmax(v, red[w]);
+        for (int w = 1; w < NTHR / 64; ++w) v = fmax(v, red[w]);
         s_dmax = v;
     }
     __syncthreads();
@@ -3152,7 +3154,7 @@ __global__ void __launch_bounds__(1024) chol_factor_panel_kernel(double* __restr
         __syncthreads();
         // the factored block goes back only now: before the barrier a slower wave may still be READING the unfactored
         // block in F1 (F3 below touches neither the block nor these rows' panel entries)
-        if (tid == 1023) {
+        if (tid == NTHR - 1) {
 #pragma unroll
             for (int r = 0; r < NB; ++r)
 #pragma unroll
@@ -3161,7 +3163,7 @@ __global__ void __launch_bounds__(1024) chol_factor_panel_kernel(double* __restr
         }
         // ---- F3: trailing triangle, 4 x 4 tiles ----
         const int nt = (R + 3) >> 2, ntiles = nt * (nt + 1) / 2;
-        for (int tile = tid; tile < ntiles; tile += 1024) {
+        for (int tile = tid; tile < ntiles; tile += NTHR) {
             int ti = (int)((__builtin_sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
             while (ti * (ti + 1) / 2 > tile) --ti;
             while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
@@ -3195,7 +3197,7 @@ __global__ void __launch_bounds__(1024) chol_factor_panel_kernel(double* __restr
         __syncthreads();
     }
     if (tid == 0) info[0] = bad;
-    for (int i = tid >> 7; i < q; i += 8)
+    for (int i = tid >> 7; i < q; i += NTHR / 128)
         for (int k = tid & 127; k <= i; k += 128) G[(size_t)i * q + k] = BASQ_TRI(i, k);
 #undef BASQ_TRI
 }
@@ -3974,10 +3976,20 @@ int basq_chol_factor_f64(double* G, int32_t q, int32_t* info, double rel_tol, vo
     if (!G || !info || q < 1 || !(rel_tol >= 0.0)) return BASQ_EINVAL;
     const size_t ldsp = (size_t)q * (q + 1) / 2 * sizeof(double);
     if (ldsp > 163840 - 512) return BASQ_EUNSUPPORTED;           // q <= 200
-    if (hipFuncSetAttribute((const void*)chol_factor_panel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsp) !=
-        hipSuccess)
-        return BASQ_ELAUNCH;
-    hipLaunchKernelGGL(chol_factor_panel_kernel, dim3(1), dim3(1024), ldsp, (hipStream_t)stream, G, q, info, rel_tol);
+    // Every thread factors the 8 x 8 diagonal block of a panel redundantly: with 16 waves that serial part runs four times
+    // per SIMD.  Up to q = 128 the trailing update has at most 465 tiles, and half the threads are the better trade
+    // (q = 99: 1024 threads 102.9 us, 512: 68.8, 256: 79.1 -- profiles/r02_m_chol_threads.txt).
+    if (q <= 128) {
+        if (hipFuncSetAttribute((const void*)chol_factor_panel_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)ldsp) != hipSuccess)
+            return BASQ_ELAUNCH;
+        hipLaunchKernelGGL(chol_factor_panel_kernel<512>, dim3(1), dim3(512), ldsp, (hipStream_t)stream, G, q, info, rel_tol);
+    } else {
+        if (hipFuncSetAttribute((const void*)chol_factor_panel_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)ldsp) != hipSuccess)
+            return BASQ_ELAUNCH;
+        hipLaunchKernelGGL(chol_factor_panel_kernel<1024>, dim3(1), dim3(1024), ldsp, (hipStream_t)stream, G, q, info, rel_tol);
+    }
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }

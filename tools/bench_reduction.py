@@ -50,6 +50,11 @@ def main():
     Y = torch.randn(4 * q + 7, q, generator=g, dtype=torch.float64)
     G = ops.to_device(Y.T @ Y)
     print(f"chol_inv q={q:<4d}{timed(lambda: ops.chol_inv(G.clone())):9.1f} us / call (incl. 1 clone)")
+    print(f"chol_factor q={q:<4d}{timed(lambda: ops.chol_factor(G.clone())):6.1f} us / call (incl. 1 clone)")
+    Xt = ops.to_device(torch.randn(10000, q, generator=g, dtype=torch.float64))
+    Lf = G.clone()
+    ops.chol_factor(Lf)
+    print(f"trsm_rows q={q:<4d}{timed(lambda: ops.trsm_rows(Xt, Lf)):8.1f} us / call ([10000, q])")
 
 
 if __name__ == "__main__":
