@@ -199,8 +199,18 @@ __global__ void col_mean_kernel(const double* __restrict__ X, long long n, int d
     const int per = blockDim.x / d;                 // threads per column
     const int k = threadIdx.x % d, t = threadIdx.x / d;
     double acc = 0.0;
-    if (t < per)
-        for (long long i = t; i < n; i += per) acc += X[i * d + k];
+    if (t < per) {
+        // eight loads in flight, added in the same order (a plain loop waits for every load before it issues the next one)
+        long long i = t;
+        for (; i + 7 * (long long)per < n; i += 8 * (long long)per) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = X[(i + u * (long long)per) * d + k];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; i < n; i += per) acc += X[i * d + k];
+    }
     part[threadIdx.x] = (t < per) ? acc : 0.0;
     __syncthreads();
     if (threadIdx.x < d) {
