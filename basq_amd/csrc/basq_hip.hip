@@ -3653,7 +3653,7 @@ int basq_project_chunks_f64(const double* Ut, int32_t q, int32_t m, const double
         const int rows_per_wg = (q > 112) ? 64 : 128;
         const int rowblocks = (S + rows_per_wg - 1) / rows_per_wg;
         // K slices: as many as fit ONE round of the chip's 2048 wave slots (two 252-register waves per SIMD) -- one wave
-        // too many and the launch takes two rounds (measured: 544 work-groups 249 us, 510 work-groups half of that)
+        // too many and the launch takes two rounds (measured: 544 work-groups 249 us, 510 work-groups 183 us)
         int want = 2048 / (rowblocks * n_chunks * 4);
         if (want > m / 64) want = m / 64;                        // at least four 16-k trips per slice
         if (want > ksplit) want = ksplit;                        // (the caller sized `work` for ksplit slabs per chunk)
