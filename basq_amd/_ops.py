@@ -23,7 +23,7 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-PROJECT_KSPLIT_MAX = 48          # K slices of the projection GEMM (A/B: tools/ab_engine.py --module _ops)
+PROJECT_KSPLIT_MAX = 64          # K slices of the projection GEMM (A/B: tools/ab_engine.py --module _ops)
 
 
 class HipOps:
