@@ -2598,70 +2598,6 @@ __global__ void __launch_bounds__(256) nullspace_apply_kernel(const double* __re
     }
 }
 
-// Apply form with SIXTEEN lanes per null vector (4 null vectors per wave): the 100-step chain y -= tau_i (v_i . y) v_i
-// is latency-bound, and a 16-lane sum is four DPP steps inside one row instead of the six stages + readlane of a
-// 64-lane sum; the lanes of a row read consecutive columns (column = lane16 + 16 k), the four rows of a wave read the
-// same reflector row (one L1 line serves them all).
-template <int NV16>
-__global__ void __launch_bounds__(256) nullspace_apply16_kernel(const double* __restrict__ V,
-                                                                const double* __restrict__ tau, int m, int n,
-                                                                double* __restrict__ PhiT) {
-    constexpr int PF = 4;                                 // reflector rows in flight
-    const int lane = threadIdx.x & 63, l16 = lane & 15;
-    const int nvec = n - m;
-    int c0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
-    const bool live = c0 < nvec;
-    if (!live) c0 = nvec - 1;                             // idle rows of the last wave shadow a real vector (no divergence)
-    double y[NV16], v[PF][NV16], tv[PF];
-#pragma unroll
-    for (int k = 0; k < NV16; ++k) y[k] = (l16 + 16 * k == m + c0) ? 1.0 : 0.0;
-#pragma unroll
-    for (int p = 0; p < PF; ++p) {
-        const int i = m - 1 - p;
-        tv[p] = (i >= 0) ? tau[i] : 0.0;
-#pragma unroll
-        for (int k = 0; k < NV16; ++k) {
-            const int c = l16 + 16 * k;
-            v[p][k] = (i >= 0 && c < n) ? V[(size_t)i * n + c] : 0.0;
-        }
-    }
-    for (int i0 = m - 1; i0 >= 0; i0 -= PF) {
-#pragma unroll
-        for (int p = 0; p < PF; ++p) {                    // static ring slot p holds row i0 - p
-            const int i = i0 - p;
-            if (i < 0) break;                             // uniform
-            double d0 = 0.0, d1 = 0.0;
-#pragma unroll
-            for (int k = 0; k + 1 < NV16; k += 2) {
-                d0 += v[p][k] * y[k];
-                d1 += v[p][k + 1] * y[k + 1];
-            }
-            if (NV16 & 1) d0 += v[p][NV16 - 1] * y[NV16 - 1];
-            double dot = d0 + d1;
-            dot += dpp_perm_f64<0xB1>(dot);               // quad_perm [1,0,3,2]
-            dot += dpp_perm_f64<0x4E>(dot);               // quad_perm [2,3,0,1]
-            dot += dpp_perm_f64<0x141>(dot);              // row_half_mirror
-            dot += dpp_perm_f64<0x140>(dot);              // row_mirror: every lane of the row of 16 holds the sum
-            const double t = tv[p] * dot;
-            const int inext = i - PF;                     // refill the slot behind the reduction
-            tv[p] = (inext >= 0) ? tau[inext] : 0.0;
-#pragma unroll
-            for (int k = 0; k < NV16; ++k) {
-                const int c = l16 + 16 * k;
-                y[k] -= t * v[p][k];
-                v[p][k] = (inext >= 0 && c < n) ? V[(size_t)inext * n + c] : 0.0;
-            }
-        }
-    }
-    if (live) {
-#pragma unroll
-        for (int k = 0; k < NV16; ++k) {
-            const int c = l16 + 16 * k;
-            if (c < n) PhiT[(size_t)c0 * n + c] = y[k];
-        }
-    }
-}
-
 template <int NV, int NREG, int NW, bool ROWS_IN_LDS>
 static int launch_bidiag(const double* X, int m, int n, double* V, double* tau, size_t lds, hipStream_t st) {
     auto kern = bidiag_reflectors_kernel<NV, NREG, NW, ROWS_IN_LDS>;
@@ -3798,10 +3734,6 @@ int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32
 #ifndef BASQ_NS_CLUSTER
 #define BASQ_NS_CLUSTER 1       // 1: cluster kernels where one CU cannot hold the matrix (M > 256); 2: also for the one-CU
 #endif                          // shapes (A/B: measured 336 vs 286 us at 100 x 200 -- the 16-wave kernel stays); 0: never
-#ifndef BASQ_NS_APPLY16
-#define BASQ_NS_APPLY16 1
-#endif
-
 int basq_nullspace_f64(const double* X, int32_t s, int32_t M, double* V, double* tau, double* PhiT, double* ws,
                        void* stream) {
     if (!X || !V || !tau || !PhiT || s < 1 || M <= s || M > 1024) return BASQ_EINVAL;
@@ -3834,15 +3766,8 @@ int basq_nullspace_f64(const double* X, int32_t s, int32_t M, double* V, double*
     }
     if (rc != BASQ_OK) return rc;
     const int nvec = M - s;
-    if (BASQ_NS_APPLY16 && M > 256 && M <= 512) {   // M <= 256: the 64-lane form is faster (31 vs 49 us at 100 x 200)
-        const dim3 grid((nvec + 15) / 16), block(256);
-        if (M <= 208) hipLaunchKernelGGL(nullspace_apply16_kernel<13>, grid, block, 0, st, V, tau, s, M, PhiT);
-        else if (M <= 256) hipLaunchKernelGGL(nullspace_apply16_kernel<16>, grid, block, 0, st, V, tau, s, M, PhiT);
-        else if (M <= 400) hipLaunchKernelGGL(nullspace_apply16_kernel<25>, grid, block, 0, st, V, tau, s, M, PhiT);
-        else hipLaunchKernelGGL(nullspace_apply16_kernel<32>, grid, block, 0, st, V, tau, s, M, PhiT);
-        BASQ_CHECK_LAUNCH();
-        return BASQ_OK;
-    }
+    // (a form with 16 lanes per null vector was the faster one for M > 256 while four reflector rows were in flight; with
+    // twelve, the 64-lane form wins there too: 68 vs 167 us at 200 x 400 -- profiles/r02_n_nullspace_apply_200x400.txt)
     const dim3 grid((nvec + 3) / 4), block(256);
     if (M <= 256) hipLaunchKernelGGL(nullspace_apply_kernel<4>, grid, block, 0, st, V, tau, s, M, PhiT);
     else if (M <= 512) hipLaunchKernelGGL(nullspace_apply_kernel<8>, grid, block, 0, st, V, tau, s, M, PhiT);
