@@ -3912,19 +3912,12 @@ int basq_chol_factor_f64(double* G, int32_t q, int32_t* info, double rel_tol, vo
     const size_t ldsp = (size_t)q * (q + 1) / 2 * sizeof(double);
     if (ldsp > 163840 - 512) return BASQ_EUNSUPPORTED;           // q <= 200
     // Every thread factors the 8 x 8 diagonal block of a panel redundantly: with 16 waves that serial part runs four times
-    // per SIMD.  Up to q = 128 the trailing update has at most 465 tiles, and half the threads are the better trade
-    // (q = 99: 1024 threads 102.9 us, 512: 68.8, 256: 79.1 -- profiles/r02_m_chol_threads.txt).
-    if (q <= 128) {
-        if (hipFuncSetAttribute((const void*)chol_factor_panel_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)ldsp) != hipSuccess)
-            return BASQ_ELAUNCH;
-        hipLaunchKernelGGL(chol_factor_panel_kernel<512>, dim3(1), dim3(512), ldsp, (hipStream_t)stream, G, q, info, rel_tol);
-    } else {
-        if (hipFuncSetAttribute((const void*)chol_factor_panel_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)ldsp) != hipSuccess)
-            return BASQ_ELAUNCH;
-        hipLaunchKernelGGL(chol_factor_panel_kernel<1024>, dim3(1), dim3(1024), ldsp, (hipStream_t)stream, G, q, info, rel_tol);
-    }
+    // per SIMD, and the trailing update (at most 1176 tiles at q = 200) does not need them: 512 threads instead of 1024:
+    // q = 99 102.9 -> 68.8 us (256 threads: 79.1), q = 199 255.5 -> 170.4 us (profiles/r02_m_chol_threads.txt).
+    if (hipFuncSetAttribute((const void*)chol_factor_panel_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)ldsp) != hipSuccess)
+        return BASQ_ELAUNCH;
+    hipLaunchKernelGGL(chol_factor_panel_kernel<512>, dim3(1), dim3(512), ldsp, (hipStream_t)stream, G, q, info, rel_tol);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }
