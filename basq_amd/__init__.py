@@ -3,6 +3,7 @@
 Public surface (mirrors the reference's names):
 
     recombination(pts_rec, pts_nys, num_pts, kernel, device, init_weights=0) -> (idx, w)
+    recombination_many([(pts_rec, pts_nys, num_pts, kernel), ...], device, in_flight=2) -> [(idx, w), ...]
     BASQ(batch_size, device).run_rchq(pts_nys, pts_rec, w_IS, kernel) -> (x, w)
     KernelQuadrature(...).rchq / .quadrature
     kernels.StationaryKernel / PosteriorKernel / WsabiKernel / from_gpytorch_model
@@ -19,7 +20,8 @@ from ._engine import EngineTrace                               # noqa: F401
 from ._acquisition_function import SquareRootAcquisitionFunction   # noqa: F401
 from ._gaussian_calc import GaussianCalc                       # noqa: F401
 from ._sampler import PriorSampler, UncertaintySampler         # noqa: F401
-from ._rchq import recombination, recombination_sharded        # noqa: F401
+from ._rchq import (recombination, recombination_many, recombination_many_sharded,   # noqa: F401
+                    recombination_sharded)
 
-__all__ = ["recombination", "recombination_sharded", "BASQ", "KernelQuadrature", "GaussianCalc", "SquareRootAcquisitionFunction", "PriorSampler", "UncertaintySampler", "EngineTrace", "kernels",
+__all__ = ["recombination", "recombination_sharded", "recombination_many", "recombination_many_sharded", "BASQ", "KernelQuadrature", "GaussianCalc", "SquareRootAcquisitionFunction", "PriorSampler", "UncertaintySampler", "EngineTrace", "kernels",
            "pools", "sober"]

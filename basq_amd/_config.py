@@ -1,0 +1,41 @@
+"""Switches of the recombination engine, in ONE place (tests and ``tools/ab_engine.py`` flip them for A/B runs).
+
+Every switch selects between two implementations of the same arithmetic; none of them changes what is selected (the
+golden tests run both sides of the ones that matter).
+"""
+from __future__ import annotations
+
+# Host LAPACK calls on small matrices (100 x 200 SVD, 1e4 x 99 QR) are slower, not faster, on a many-core
+# host with every core in the team (measured: 30 ms per 100x200 gesdd with 128 threads vs ~2 ms with 8).
+HOST_LAPACK_THREADS = 8          # tall QR of the fallback path
+HOST_SVD_THREADS = 1             # 100x200 / 99x99 SVDs: fastest single-threaded (profiles/r01_host_lapack_threads.txt)
+
+# The range finder's products on basq_skinny_gemm_f64 (False: library GEMMs through torch, for A/B comparisons).
+OWN_RANGE_GEMM = True
+# The GPU range finder may be switched off (tests compare both paths).
+GPU_RANGE_FINDER = True
+# Per-round null space (:140-143) from the bidiagonalisation's right reflectors on the GPU (basq_nullspace_f64)
+# instead of a host LAPACK SVD; False restores the host path (same rows to ~1e-13, see tests).
+GPU_NULLSPACE = True
+
+# Multi-rank: every rank reduces the gathered message itself (the kernels sum in a fixed order, so all ranks obtain
+# the same survivors bit for bit) instead of rank 0 reducing and broadcasting the result: one collective less per round.
+REPLICATED_REDUCTION = True
+SHARDED_BASIS = True             # multi-rank: split the range finder's Gram products over the ranks (False: rank 0 only)
+
+LATE_CHUNKS = 1                  # chunks of the round-1 block sums deferred behind the range finder (0 = none)
+LATE_CLASSES = 2                 # the same in class mode: the deferred classes (2 of 16 = 1.1 ms of GPU work) run while the
+                                 # host does the range finder's q x q SVD; A/B on MI355X: 42.9 / 43.35 / 43.15 batches/s for 1 / 2 / 3
+LATE_CLASSES_PIPELINED = 0       # with several batches in flight another batch's kernels fill that gap: nothing is deferred
+
+# Residue-class block sums: evaluate the pairwise kernel once per EPOCH of log2(C) + 1 rounds.  The chunks of the block
+# sums are the residue classes of the block index modulo C; a round that keeps exactly half of the sets sends the
+# survivor of (block b, kept rank k) to (block b // 2, set (b % 2) * n + k), so the next round's sums -- again per class,
+# modulo C / 2 -- are a gather + rescale of this round's (``basq_regroup_classes_f64``): no candidate is touched.  Only
+# the blocks beyond a multiple of C and the ragged tail (< (C + 1) * S points, halving every round) are evaluated directly.
+CLASS_SUMS = True
+MAX_CLASSES = 16                 # classes at the start of an epoch (power of two): 16 -> the kernel runs in rounds 1, 6, 11
+# Rounds driven by a device-resident descriptor, no host wait per round (any rank count; structured kernels except WSABI-M).
+ASYNC_ROUNDS = True
+
+PSD_EIG_MAX_M = 4096             # _make_cov_psd: largest Gram whose spectrum is checked (SOBER/_utils.py:122-124)

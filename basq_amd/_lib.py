@@ -18,7 +18,7 @@ BASQ_OK = 0
 FAMILY = {"rbf": 0, "matern52": 1, "matern32": 2}
 ROLE_A, ROLE_B = 0, 1
 MAX_DIM = 38
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class KernelSpecC(C.Structure):
@@ -53,8 +53,8 @@ SIGNATURES = {
     "basq_tail_weights_geo_f64": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp]),
     "basq_round_next_i64": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "basq_blocksum_geo_f64": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
-    "basq_reweight_compact_geo_f64": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
-                                                _vp, _vp, _vp]),
+    "basq_reweight_compact_geo_f64": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _i64,
+                                                _i32, _vp, _vp, _vp, _vp, _vp]),
     "basq_init_state_f64": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
     "basq_dense_blocksum_f64": (C.c_int, [_vp, _i32, _i64, _i64, _vp, _i64, _i64, _i32, _f64, _i32, _vp, _vp]),
     "basq_blocksum_sq_f64": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _i32,

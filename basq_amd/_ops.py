@@ -31,16 +31,29 @@ class HipOps:
 
     name = "hip"
 
-    def __init__(self, device):
+    def __init__(self, device, stream=None):
+        """``stream``: a ``torch.cuda.Stream`` every launch, copy and wait of this object goes to (one per batch in flight:
+        ``RecombinationEngine.run_many``); None = torch's current stream at the time of each call.  The caches of an
+        instance (pinned staging buffers, the cluster kernels' flag/ring workspace, the transposed basis) belong to that
+        stream: two batches in flight never share one ``HipOps``."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.BasqHipError("basq_amd runs on an AMD GPU (torch device type 'cuda'); no CPU path exists")
         if not torch.cuda.is_available():
             raise _lib.BasqHipError("no HIP device visible to torch")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.lib = _lib.load()
+        self.stream = stream
+        self._bound = None if stream is None else C.c_void_p(stream.cuda_stream)
 
     # -- helpers -----------------------------------------------------------------------------
+    def torch_stream(self):
+        return self.stream if self.stream is not None else torch.cuda.current_stream(self.device)
+
     def _stream(self):
+        if self._bound is not None:
+            return self._bound
         s = self.__dict__.get("_pinned_stream")
         return s if s is not None else C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -237,11 +250,20 @@ class HipOps:
         keep_rank = self.empty(M, dtype=torch.int32)
         ik = self.empty(2 + M, dtype=torch.int32)              # [info(2) | kept(<=M)]  (<= s unless the elimination
         info, kept = ik[:2], ik[2:]                             #  stopped early, status 1)
+        info.ik_buffer = ik                                     # (info_kept_buffer: one D2H for both)
         w_star = self.empty(M)
         check(self.lib.basq_car_eliminate_f64(_ptr(PhiT), _ptr(mu), M, s, _ptr(keep_rank), _ptr(kept), _ptr(w_star),
                                               _ptr(info), _ptr(self._reduction_ws(s, M)), self._stream()),
               "basq_car_eliminate_f64")
         return keep_rank, kept, w_star, info
+
+    @staticmethod
+    def info_kept_buffer(info, kept):
+        """``[info(2) | kept]`` as ONE tensor (``car_eliminate`` hands out views of such a buffer)."""
+        ik = getattr(info, "ik_buffer", None)
+        return ik if ik is not None else torch.cat([info, kept])
+
+    NULLSPACE_MAX_M = 1024           # largest 2 * num_pts of basq_nullspace_f64 / basq_car_eliminate_f64
 
     def reweight_compact(self, cand, mu, gid, wx, Rl, off, n_full, S, kp, keep_rank, w_star, tot, n_keep, new_off,
                          new_Rl):
@@ -256,12 +278,13 @@ class HipOps:
         return cand_o, mu_o, gid_o, wx_o
 
     # -- device-resident round descriptors (basq_round_next_i64 and the *_geo entries) -----------------------------
-    def geo_init(self, n_rounds, R, S, reg_hi):
-        """Descriptor table ``[n_rounds, 8]`` (int64, device) with row 0 = the first round's geometry."""
+    def geo_init(self, n_rounds, R, S, reg_hi, off=0, Rl=None):
+        """Descriptor table ``[n_rounds, 8]`` (int64, device) with row 0 = the first round's geometry and this rank's shard
+        ``[off, off + Rl)`` of the R live positions (default: all of them)."""
         nb = R // S
         host = self._pinned((n_rounds, 8), torch.int64, "geo")
         host.zero_()
-        host[0, 0], host[0, 1], host[0, 2], host[0, 4], host[0, 5] = R, nb * S, reg_hi, nb, R - nb * S
+        host[0] = torch.tensor([R, nb * S, reg_hi, 0, nb, R - nb * S, off, R if Rl is None else Rl], dtype=torch.int64)
         return host.to(self.device, non_blocking=True)
 
     def round_next(self, geo_row, info, keep_rank, S, class_mode, expect_half, geo_next):
@@ -283,15 +306,18 @@ class HipOps:
                                              _ptr(totpart), self._stream()), "basq_blocksum_geo_f64")
         return Xpart, totpart
 
-    def reweight_compact_geo(self, cand, mu, gid, wx, geo_row, info, R_max, S, kp, keep_rank, w_star, tot, out_rows):
-        """``reweight_compact`` on one rank with the counts read from the descriptor; outputs sized ``out_rows``."""
+    def reweight_compact_geo(self, cand, mu, gid, wx, geo_row, geo_next, info, R_max, S, kp, keep_rank, w_star, tot,
+                             out_rows, expect_keep=-1):
+        """``reweight_compact`` with the shard and the counts read from the descriptors (this round's and the next
+        round's); launch sized for ``R_max`` local candidates, outputs sized ``out_rows`` for ``expect_keep`` kept sets (a
+        round that violates that writes nothing, see ``basq_reweight_compact_geo_f64``)."""
         cand_o = self.empty(max(out_rows, 1), kp)
         mu_o = self.empty(max(out_rows, 1))
         gid_o = self.empty(max(out_rows, 1), dtype=torch.int64)
         wx_o = self.empty(max(out_rows, 1)) if wx is not None else None
-        check(self.lib.basq_reweight_compact_geo_f64(_ptr(cand), _ptr(mu), _ptr(gid), _ptr(wx), _ptr(geo_row), _ptr(info),
-                                                     int(R_max), S, kp, _ptr(keep_rank), _ptr(w_star), _ptr(tot),
-                                                     _ptr(cand_o), _ptr(mu_o), _ptr(gid_o), _ptr(wx_o), self._stream()),
+        check(self.lib.basq_reweight_compact_geo_f64(_ptr(cand), _ptr(mu), _ptr(gid), _ptr(wx), _ptr(geo_row),
+                                                     _ptr(geo_next), _ptr(info), int(max(R_max, 1)), S, kp, _ptr(keep_rank), _ptr(w_star), _ptr(tot),
+                                                     int(max(out_rows, 1)), int(expect_keep), _ptr(cand_o), _ptr(mu_o), _ptr(gid_o), _ptr(wx_o), self._stream()),
               "basq_reweight_compact_geo_f64")
         return cand_o, mu_o, gid_o, wx_o
 
@@ -446,7 +472,7 @@ class HipOps:
         buf = self._pinned(t.shape, t.dtype, tag)
         buf.copy_(t, non_blocking=True)
         # (polling an event instead of this blocking wait was tried: no measurable difference, 41.5 vs 41.6 batches/s)
-        torch.cuda.current_stream(self.device).synchronize()
+        self.torch_stream().synchronize()
         return buf
 
     def to_host_async(self, t, tag="d2h"):
@@ -455,7 +481,7 @@ class HipOps:
         buf = self._pinned(t.shape, t.dtype, tag)
         buf.copy_(t, non_blocking=True)
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
+        ev.record(self.torch_stream())
         return buf, ev
 
     def host_uniform(self, n, tag):
@@ -473,38 +499,15 @@ class HipOps:
         buf.copy_(t)
         return buf.to(self.device, non_blocking=True)
 
-    def side_stream(self):
-        """Context manager: work enqueued inside runs on a second HIP stream that starts behind everything already
-        enqueued on the current one; on exit the current stream waits for it.  Independent phases (the range finder
-        beside the round-1 block sums) then share the GPU instead of queueing behind each other."""
-        import contextlib
-
-        side = self.__dict__.get("_side_stream")
-        if side is None:
-            side = self.__dict__["_side_stream"] = torch.cuda.Stream(device=self.device)
-        cur = torch.cuda.current_stream(self.device)
-
-        @contextlib.contextmanager
-        def ctx():
-            side.wait_stream(cur)
-            pinned = self.__dict__.get("_pinned_stream")
-            with torch.cuda.stream(side):
-                if pinned is not None:
-                    self._pinned_stream = C.c_void_p(side.cuda_stream)
-                try:
-                    yield cur
-                finally:
-                    if pinned is not None:
-                        self._pinned_stream = pinned
-            cur.wait_stream(side)
-
-        return ctx()
-
     def synchronize(self):
-        torch.cuda.current_stream(self.device).synchronize()
+        self.torch_stream().synchronize()
 
-    def record_event(self):
-        """HIP event recorded on the stream the kernels are launched on (torch's current stream)."""
-        ev = torch.cuda.Event(enable_timing=True)
-        ev.record(torch.cuda.current_stream(self.device))
+    def record_event(self, timing=True):
+        """HIP event recorded on the stream the kernels are launched on."""
+        ev = torch.cuda.Event(enable_timing=timing)
+        ev.record(self.torch_stream())
         return ev
+
+    def wait_event(self, ev):
+        """Make this object's stream wait (on the GPU) for ``ev``; the host does not block."""
+        self.torch_stream().wait_event(ev)

@@ -14,8 +14,9 @@ Differences that are part of the design:
 * ``kernel``: the objects of :mod:`basq_amd.kernels` (``StationaryKernel`` / ``PosteriorKernel`` /
   ``WsabiKernel``, or ``from_gpytorch_model(model, ...)``) take the fused GPU path, which needs the kernel's
   structure; any OTHER callable ``(X[a,d], Y[b,d]) -> Tensor[a,b]`` -- the reference's contract, tutorial 02 --
-  is evaluated on the device chunk by chunk and block-summed by ``basq_dense_blocksum_f64``
-  (``kernels.CallableKernel``: correct for every kernel, HBM-bound instead of fused);
+  is evaluated on the device and block-summed by ``basq_dense_blocksum_f64`` (``kernels.CallableKernel``: correct for
+  every kernel, HBM-bound instead of fused).  A bare callable is asked for exactly the blocks the reference asks for
+  (``_rchq.py:81-99``) unless a probe shows that its values do not depend on the block (then: large chunks);
 * arithmetic is float64 whatever the default dtype (SURVEY finding 3: the reference's selection is only
   reproducible in float64);
 * ``device`` must be a HIP device (``torch.device('cuda', i)``); there is no CPU path.
@@ -24,13 +25,14 @@ from __future__ import annotations
 
 import torch
 
-from ._engine import EngineTrace, LocalComm, RecombinationEngine, TorchDistComm
+from ._engine import EngineTrace, Job, LocalComm, RecombinationEngine, TorchDistComm
 from ._ops import HipOps
 
 
 def _as_kernel_object(kernel):
     """Structured kernels pass through (fused path); any other callable is the reference's opaque ``kernel``
-    argument (``BASQ/_rchq.py:8,16``) and runs through the chunked dense path (``kernels.CallableKernel``)."""
+    argument (``BASQ/_rchq.py:8,16``) and runs through the dense path (``kernels.CallableKernel``, mode decided by its
+    probe: the reference's own block-by-block calls unless the callable provably does not depend on the block)."""
     if all(hasattr(kernel, a) for a in ("base", "posterior", "warp", "dense")):
         return kernel
     if callable(kernel):
@@ -45,7 +47,7 @@ def recombination(
     pts_rec,          # random samples for recombination          [N, d]
     pts_nys,          # samples for the Nystrom approximation       [m, d]
     num_pts,          # number of samples finally returned (batch size)
-    kernel,           # basq_amd.kernels object (fused path) or any callable (X, Y) -> Tensor (chunked dense path)
+    kernel,           # basq_amd.kernels object (fused path) or any callable (X, Y) -> Tensor (dense path)
     device,           # HIP device
     init_weights=0,   # ignored, as in the reference
     *,
@@ -70,3 +72,72 @@ def recombination_sharded(pts_local, gid0, n_total, pts_nys, num_pts, kernel, de
     ops = HipOps(device)
     eng = RecombinationEngine(ops, TorchDistComm(group))
     return eng.run(pts_local, int(gid0), int(n_total), pts_nys, int(num_pts), kernel, trace)
+
+
+# ---- several independent recombinations in flight ------------------------------------------------------------------------
+_SLOTS = {}          # (device index, slot) -> HipOps bound to its own stream (streams and workspaces are reused)
+
+
+def _slots(device, n):
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    out = []
+    for k in range(n):
+        ops = _SLOTS.get((idx, k))
+        if ops is None:
+            ops = _SLOTS[(idx, k)] = HipOps(torch.device("cuda", idx), stream=torch.cuda.Stream(device=idx))
+        out.append(ops)
+    return out
+
+
+def _run_many(jobs, device, comm, in_flight):
+    jobs = list(jobs)
+    if not jobs:
+        return []
+    slots = _slots(device, max(1, min(int(in_flight), len(jobs))))
+    cur = torch.cuda.current_stream(slots[0].device)
+    for ops in slots:
+        ops.stream.wait_stream(cur)                  # the inputs were produced on the caller's stream
+    res = RecombinationEngine(slots[0], comm).run_many(jobs, slots)
+    for ops in slots:
+        cur.wait_stream(ops.stream)
+    for idx, w in res:                               # allocated on a slot's stream, handed to the caller's
+        idx.record_stream(cur)
+        w.record_stream(cur)
+    return res
+
+
+def recombination_many(calls, device, in_flight: int = 2, seeds=None, traces=None):
+    """Several INDEPENDENT recombinations with ``in_flight`` of them on the GPU at a time -> ``[(idx, w), ...]``.
+
+    ``calls``: ``(pts_rec, pts_nys, num_pts, kernel)`` per recombination -- e.g. the two calls every BASQ iteration makes,
+    the batch selection (``BASQ/_basq.py:82-88``) and the quadrature (``:104-106`` -> ``_quadrature.py:59-60``).  Each batch
+    runs on its own HIP stream with its own workspaces; while one batch is in its chain of single-work-group reductions
+    (null space + elimination, one CU busy), the block sums and GEMMs of the other fill the chip.
+
+    Results are bit-identical to sequential ``recombination`` calls in the same order: the CPU global generator is
+    consumed in call order (one ``torch.randn(m, num_pts - 1)`` each, as in the reference), and ``seeds[k]`` (optional)
+    is what ``torch.manual_seed(seeds[k])`` right before call k would be.
+    """
+    jobs = []
+    for k, (pts_rec, pts_nys, num_pts, kernel) in enumerate(calls):
+        jobs.append(Job(pts_rec, 0, pts_rec.shape[0], pts_nys, int(num_pts), _as_kernel_object(kernel),
+                        trace=None if traces is None else traces[k], seed=None if seeds is None else seeds[k]))
+    return _run_many(jobs, device, LocalComm(), in_flight)
+
+
+def recombination_many_sharded(calls, device, group=None, in_flight: int = 4, seeds=None):
+    """``recombination_many`` with every pool sharded over the ranks of ``group``: ``calls`` holds
+    ``(pts_local, gid0, n_total, pts_nys, num_pts, kernel)`` per recombination (see ``recombination_sharded``).
+
+    On G GPUs the wide kernels of a batch shrink by G while its chain of single-work-group reductions does not
+    (replicated on every rank): keeping several batches in flight is what keeps the GPUs busy.  All ranks must pass the
+    same number of calls; the scheduler resumes batches in a fixed order, so the ranks issue their collectives in the
+    same sequence.
+    """
+    comm = TorchDistComm(group)
+    jobs = []
+    for k, (pts_local, gid0, n_total, pts_nys, num_pts, kernel) in enumerate(calls):
+        jobs.append(Job(pts_local, int(gid0), int(n_total), pts_nys, int(num_pts), _as_kernel_object(kernel),
+                        seed=None if seeds is None else seeds[k]))
+    return _run_many(jobs, device, comm, in_flight)

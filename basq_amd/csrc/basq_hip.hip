@@ -292,19 +292,23 @@ struct BlocksumArgs {
 };
 
 // Candidate range of a descriptor-driven launch (wave-uniform scalar loads and arithmetic; the formulas of blocksum_impl).
+// The descriptor carries the round's GLOBAL geometry and this rank's shard [off, off + Rl) of the live positions
+// (geo[6], geo[7]; one rank: [0, R)); the launch covers the intersection of the shard with the mode's position range.
 template <int KP>
 __device__ __forceinline__ void blocksum_apply_geo(BlocksumArgs& A) {
     const long long R = A.geo[0], n_full = A.geo[1], reg_hi = A.geo[2];
-    long long off = 0, Rl = R;
-    if (A.geo_mode == 1) {
-        Rl = reg_hi;
-    } else if (A.geo_mode == 2) {
-        off = reg_hi;
-        Rl = R - reg_hi;
-        A.cand += reg_hi * KP;
-        A.mu += reg_hi;
-        if (A.wx) A.wx += reg_hi;
-    }
+    const long long s_off = A.geo[6], s_end = A.geo[6] + A.geo[7];
+    long long lo = 0, hi = R;
+    if (A.geo_mode == 1) hi = reg_hi;
+    else if (A.geo_mode == 2) lo = reg_hi;
+    if (lo < s_off) lo = s_off;
+    if (hi > s_end) hi = s_end;
+    if (hi < lo) hi = lo;
+    const long long skip = lo - s_off;                        // local index of the first position of the launch
+    A.cand += skip * KP;
+    A.mu += skip;
+    if (A.wx) A.wx += skip;
+    const long long off = lo, Rl = hi - lo;
     A.off = off;
     A.Rl = Rl;
     A.n_full = n_full;
@@ -2647,22 +2651,29 @@ __global__ void reweight_compact_kernel(const double* __restrict__ cand, const d
     }
 }
 
-// Descriptor-driven form (single rank): the candidate count, the block geometry and the number of kept sets are read
-// from device memory (round descriptor + the elimination's info word), the grid is sized for an upper bound.
+// Descriptor-driven form: the shard [off, off + Rl) of this rank, the block geometry and the number of kept sets are read
+// from device memory (this round's and the next round's descriptors + the elimination's info word), the grid is sized
+// for an upper bound of the shard.
 __global__ void reweight_compact_geo_kernel(const double* __restrict__ cand, const double* __restrict__ mu,
                                             const long long* __restrict__ gid, const double* __restrict__ wx,
-                                            const long long* __restrict__ geo, const int* __restrict__ info, int S, int kp,
+                                            const long long* __restrict__ geo, const long long* __restrict__ geo_next,
+                                            const int* __restrict__ info, int S, int kp,
                                             const int* __restrict__ keep_rank, const double* __restrict__ w_star,
-                                            const double* __restrict__ tot, double* __restrict__ cand_out,
-                                            double* __restrict__ mu_out, long long* __restrict__ gid_out,
-                                            double* __restrict__ wx_out) {
+                                            const double* __restrict__ tot, long long out_rows, int expect_keep,
+                                            double* __restrict__ cand_out, double* __restrict__ mu_out,
+                                            long long* __restrict__ gid_out, double* __restrict__ wx_out) {
 #pragma clang fp contract(off)
-    const long long Rl = geo[0], n_full = geo[1];
+    const long long n_full = geo[1], off = geo[6], Rl = geo[7];
     const int n_keep = info[0];
+    // The host sized the outputs for `expect_keep` kept sets before it knew the outcome: a round that violates that (failed
+    // or short elimination, or the sticky flag of an earlier round) writes NOTHING -- the host repeats the rounds one
+    // read-back at a time once it reads the flag (basq_round_next_i64 publishes it and an empty next round).
+    if (geo[3] != 0 || info[1] != 0 || (expect_keep >= 0 && n_keep != expect_keep)) return;
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= Rl * kp) return;
-    const long long pg = t / kp;
-    const int k = (int)(t - pg * kp);
+    const long long p = t / kp;
+    const int k = (int)(t - p * kp);
+    const long long pg = off + p;
     int set;
     long long dst;
     if (pg < n_full) {
@@ -2676,12 +2687,14 @@ __global__ void reweight_compact_geo_kernel(const double* __restrict__ cand, con
     const int kr = keep_rank[set];
     if (kr < 0) return;
     if (pg < n_full) dst += kr;
+    dst -= geo_next[6];                                                    // this rank's new offset
+    if (dst < 0 || dst >= out_rows) return;                                // never outside the caller's buffers
     cand_out[dst * kp + k] = cand[t];
     if (k == 0) {
-        const double scaled = mu[pg] * w_star[kr];                         // :113-114 / :121-122
+        const double scaled = mu[p] * w_star[kr];                          // :113-114 / :121-122
         mu_out[dst] = scaled / tot[set];
-        gid_out[dst] = gid[pg];
-        if (wx) wx_out[dst] = wx[pg];
+        gid_out[dst] = gid[p];
+        if (wx) wx_out[dst] = wx[p];
     }
 }
 
@@ -2693,13 +2706,34 @@ __global__ void reweight_compact_geo_kernel(const double* __restrict__ cand, con
 __global__ void round_next_kernel(const long long* __restrict__ gp, const int* __restrict__ info,
                                   const int* __restrict__ keep_rank, int S, int class_mode, int expect_half,
                                   long long* __restrict__ gn) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const long long R = gp[0], n_full = gp[1];
+    // one wave: the lanes share the two prefix counts of the shard's new offset / end (survivors_before of _partition.py)
+    const int lane = threadIdx.x;
+    const long long R = gp[0], n_full = gp[1], off = gp[6], Rl = gp[7];
     const long long nb = n_full / S, n_tail = R - n_full;
     const int n_keep = info[0], status = info[1];
     long long viol = gp[3];
     if (status != 0 || (expect_half && 2 * n_keep != S)) viol = 1;
-    const long long Rn = nb * n_keep + ((keep_rank[S - 1] >= 0) ? n_tail : 0);
+    const bool last_kept = keep_rank[S - 1] >= 0;
+    long long before[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const long long P = e ? (off + Rl) : off;
+        if (P <= n_full) {
+            const long long b = P / S;
+            const int sidx = (int)(P - b * S);
+            int cnt = 0;
+            for (int j = lane; j < sidx; j += 64) cnt += (keep_rank[j] >= 0) ? 1 : 0;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+            before[e] = b * n_keep + cnt;
+        } else {
+            before[e] = nb * n_keep + (last_kept ? (P - n_full) : 0);
+        }
+    }
+    if (lane != 0 || blockIdx.x != 0) return;
+    // after a violation every later descriptor-driven launch of the batch sees an EMPTY round (the buffers the host sized
+    // for the expected survivor counts are never overrun); the flag tells the host to repeat the rounds one by one
+    const long long Rn = viol ? 0 : nb * n_keep + (last_kept ? n_tail : 0);
     const long long nbn = Rn / S;
     long long reg_blocks = 0;
     if (class_mode > 0) reg_blocks = (nbn / class_mode) * class_mode;
@@ -2710,8 +2744,8 @@ __global__ void round_next_kernel(const long long* __restrict__ gp, const int* _
     gn[3] = viol;
     gn[4] = nbn;
     gn[5] = Rn - nbn * S;
-    gn[6] = 0;
-    gn[7] = 0;
+    gn[6] = viol ? 0 : before[0];
+    gn[7] = viol ? 0 : (before[1] - before[0]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3657,9 +3691,10 @@ __global__ void tail_weights_geo_kernel(const double* __restrict__ mu, const dou
                                         const long long* __restrict__ geo, int S, double* __restrict__ out) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= S) return;
-    const long long n_full = geo[1], n_tail = geo[5];
+    const long long n_full = geo[1], n_tail = geo[5], off = geo[6], Rl = geo[7];
     double v = 0.0;
-    if (k < n_tail) v = wx ? mu[n_full + k] * wx[n_full + k] : mu[n_full + k];
+    const long long p = n_full + k - off;                     // local index of tail point k (this rank may hold only some)
+    if (k < n_tail && p >= 0 && p < Rl) v = wx ? mu[p] * wx[p] : mu[p];
     out[k] = v;
 }
 
@@ -3812,16 +3847,19 @@ int basq_blocksum_geo_f64(const basq_kernel_spec* spec, const double* nys, int32
 }
 
 int basq_reweight_compact_geo_f64(const double* cand, const double* mu, const int64_t* gid, const double* wx,
-                                  const int64_t* geo, const int32_t* info, int64_t R_max, int32_t S, int32_t kp,
-                                  const int32_t* keep_rank, const double* w_star, const double* tot, double* cand_out,
-                                  double* mu_out, int64_t* gid_out, double* wx_out, void* stream) {
-    if (!cand || !mu || !gid || !geo || !info || !keep_rank || !w_star || !tot || !cand_out || !mu_out || !gid_out)
+                                  const int64_t* geo, const int64_t* geo_next, const int32_t* info, int64_t R_max,
+                                  int32_t S, int32_t kp,
+                                  const int32_t* keep_rank, const double* w_star, const double* tot, int64_t out_rows,
+                                  int32_t expect_keep, double* cand_out, double* mu_out, int64_t* gid_out, double* wx_out,
+                                  void* stream) {
+    if (!cand || !mu || !gid || !geo || !geo_next || !info || !keep_rank || !w_star || !tot || !cand_out || !mu_out ||
+        !gid_out)
         return BASQ_EINVAL;
-    if (R_max < 1 || S < 1 || kp < 1 || (wx && !wx_out)) return BASQ_EINVAL;
+    if (R_max < 1 || S < 1 || kp < 1 || out_rows < 1 || (wx && !wx_out)) return BASQ_EINVAL;
     const long long nt = (long long)R_max * kp;
     hipLaunchKernelGGL(reweight_compact_geo_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       cand, mu, (const long long*)gid, wx, (const long long*)geo, info, S, kp, keep_rank, w_star, tot,
-                       cand_out, mu_out, (long long*)gid_out, wx_out);
+                       cand, mu, (const long long*)gid, wx, (const long long*)geo, (const long long*)geo_next, info, S, kp,
+                       keep_rank, w_star, tot, (long long)out_rows, expect_keep, cand_out, mu_out, (long long*)gid_out, wx_out);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }

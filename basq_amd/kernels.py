@@ -211,23 +211,29 @@ class CallableKernel:
     ``fn(X[a, d], Y[b, d]) -> Tensor[a, b]`` is called with tensors on the HIP device (``input_dtype``, float64 by
     default) under ``torch.no_grad()``; its result is cast to float64.  Two evaluation modes:
 
-    * chunked (default): ``fn(pts_nys, chunk)`` for chunks of up to ``chunk_bytes / (8 m)`` consecutive candidates;
     * ``block_exact=True``: exactly the reference's calls -- one ``fn(pts_nys, block of 2n points)`` per block
-      (``_rchq.py:81-86``) and one for the ragged tail (``:91-99``).  Needed only for callables whose value depends
-      on the shape of the block they are asked for, like ``predictive_covariance``, which adds the likelihood
-      noise to entries ``[k][k]`` of EVERY block (``BASQ/_gp.py:275-276``); N/(2n) Python calls per round.
+      (``_rchq.py:81-86``) and one for the ragged tail (``:91-99``); N/(2n) Python calls per round.  Needed for callables
+      whose value depends on the block they are asked for, like the reference's DEFAULT kernel ``predictive_covariance``,
+      which adds the likelihood noise to entries ``[k][k]`` of EVERY block (``BASQ/_gp.py:275-276``);
+    * ``block_exact=False``: ``fn(pts_nys, chunk)`` for chunks of up to ``chunk_bytes / (8 m)`` consecutive candidates --
+      far fewer, larger calls, but only equivalent for callables that evaluate column by column.
+
+    ``block_exact=None`` (the default, and what a bare callable handed to ``recombination`` gets): decided once per batch
+    by a probe (``resolve_mode``) -- the callable is asked for two blocks at once and one by one; unless the answers
+    agree, the exact mode is taken.  Correct by default; the chunked mode is an optimisation the probe has to earn.
     """
 
     opaque = True
     base = None
     posterior = None
     warp = "none"
+    PROBE_RTOL = 1e-13           # block dependence below this (relative to max |K|) cannot move a selection (SURVEY finding 3)
 
-    def __init__(self, fn, block_exact: bool = False, chunk_bytes: int = 256 << 20, input_dtype=torch.float64):
+    def __init__(self, fn, block_exact: bool | None = None, chunk_bytes: int = 256 << 20, input_dtype=torch.float64):
         if not callable(fn):
             raise TypeError("CallableKernel needs a callable (X, Y) -> Tensor")
         self.fn = fn
-        self.block_exact = bool(block_exact)
+        self.block_exact = None if block_exact is None else bool(block_exact)
         self.chunk_bytes = int(chunk_bytes)
         self.input_dtype = input_dtype
 
@@ -239,6 +245,27 @@ class CallableKernel:
             raise ValueError("kernel callable must return a dense [len(X), len(Y)] tensor; got %r"
                              % (getattr(K, "shape", type(K)),))
         return ops.to_device(K.detach(), torch.float64)
+
+    def resolve_mode(self, ops, pts_nys, S: int) -> bool:
+        """-> True when the batch must make the reference's own block-by-block calls.
+
+        Probe (``block_exact=None``): ``fn(pts_nys, [Y1; Y2])`` against ``[fn(pts_nys, Y1), fn(pts_nys, Y2)]`` for two
+        blocks of S points.  The blocks are cut from the Nystrom points themselves (repeated cyclically), so every rank of
+        a multi-GPU run probes the same data and reaches the same decision.  ``predictive_covariance`` fails the probe
+        through its noise on entries ``[k][S + k]`` of the second block (unless the noise is exactly negligible); a
+        callable that is a function of the pair alone passes."""
+        if self.block_exact is not None:
+            return self.block_exact
+        m = pts_nys.shape[0]
+        if m == 0 or S < 1:
+            return True
+        rows = torch.arange(2 * S, device=pts_nys.device) % m
+        Y = pts_nys[rows]
+        both = self.dense(ops, pts_nys, Y)
+        one = torch.cat([self.dense(ops, pts_nys, Y[:S]), self.dense(ops, pts_nys, Y[S:])], 1)
+        scale = float(both.abs().max().item())
+        dev = float((both - one).abs().max().item())
+        return not (dev <= self.PROBE_RTOL * scale)              # (NaNs fail the probe: exact mode)
 
     def __call__(self, x, y):
         return self.fn(x, y)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BASQ_ABI_VERSION 7
+#define BASQ_ABI_VERSION 8
 
 /* error codes */
 #define BASQ_OK            0
@@ -230,23 +230,33 @@ int basq_reweight_compact_f64(const double* cand, const double* mu, const int64_
  * round.  The number of survivors of a round depends on the data only through two facts -- how many sets the elimination
  * kept and whether the last set (which owns the ragged tail, :91-99) is among them -- so the next round's geometry is a
  * closed form of the previous one (basq_amd/_partition.py) that a one-thread kernel can evaluate:
- *   geo[8] = { R, n_full = (R / S) * S, reg_hi, violation, nb, n_tail, 0, 0 }        (int64)
+ *   geo[8] = { R, n_full = (R / S) * S, reg_hi, violation, nb, n_tail, off, Rl }     (int64)
+ *       R .. n_tail describe the round GLOBALLY; [off, off + Rl) is the slice of the live positions THIS rank holds (one
+ *       rank: [0, R)), so the same entries drive the pool-sharded multi-GPU rounds without a host wait.
  *   basq_round_next_i64: R' = nb * n_keep + (n_tail if keep_rank[S-1] >= 0), n_keep / status from the elimination's
- *       info word.  class_mode > 0: the next round evaluates its block sums afresh with that many residue classes
+ *       info word; off' / Rl' = the survivors before position off / inside the shard (closed form of
+ *       basq_amd/_partition.py: b * n_keep + #{kept sets < p mod S} below n_full, the tail behind it if set S-1 survived).  class_mode > 0: the next round evaluates its block sums afresh with that many residue classes
  *       (reg_hi' = S * the largest multiple of class_mode blocks), -1: it inherits regrouped classes (the regular
  *       region halves), 0: no classes.  violation is sticky: status != 0, or expect_half != 0 and 2 n_keep != S (the host
  *       had already enqueued a regrouping that needs exactly half of the sets): the host then repeats the batch with
- *       one read-back per round.
+ *       one read-back per round.  After a violation the descriptor describes an EMPTY round (R' = 0), so every launch
+ *       already enqueued for later rounds is a no-op inside the buffers the host sized for the expected counts.
  *   basq_blocksum_geo_f64: basq_blocksum_f64 with the candidate range taken from the descriptor -- geo_mode 1: positions
- *       [0, reg_hi) (class_mod > 0 allowed), 2: [reg_hi, R) (pointers are advanced on the device), 3: [0, R).
- *   basq_reweight_compact_geo_f64: basq_reweight_compact_f64 for one rank (off = new_off = 0) with Rl, n_full from the
- *       descriptor and n_keep from info[0]; the launch is sized for R_max >= R candidates.
+ *       [0, reg_hi) (class_mod > 0 allowed), 2: [reg_hi, R), 3: [0, R), each intersected with this rank's shard (the
+ *       pointers, which address the shard's first candidate, are advanced on the device).
+ *   basq_reweight_compact_geo_f64: basq_reweight_compact_f64 with off, Rl, n_full from the descriptor, new_off from the
+ *       NEXT round's descriptor (geo_next, written by basq_round_next_i64 just before) and n_keep from info[0]; the
+ *       launch is sized for R_max >= Rl candidates and the outputs hold out_rows
+ *       rows.  Nothing is written when the round violates what the host assumed when it sized them: geo[3] != 0 (an earlier
+ *       round's flag), info[1] != 0 (the elimination stopped early or timed out) or expect_keep >= 0 and
+ *       n_keep != expect_keep; no destination row >= out_rows is ever written.
  * Launch grids never depend on R; buffers are sized from host-side upper bounds.
  */
 /* Descriptor-driven siblings of the noise-diagonal bookkeeping (BASQ/_gp.py:275-276 on the ragged tail block):
  *   basq_finalize_geo_f64: basq_finalize_f64 with the tail length taken from geo[5]; n_tail_diag is then only a cap.
- *   basq_tail_weights_geo_f64: out[k] = mu[n_full + k] * wx[n_full + k] (wx may be NULL) for k < n_tail, 0 for k < S beyond:
- *       the message row that carries the tail weights. */
+ *   basq_tail_weights_geo_f64: out[k] = mu * wx (wx may be NULL) of tail point k (global position n_full + k) where this rank
+ *       holds it, 0 elsewhere and for n_tail <= k < S: the message row that carries the tail weights (summed over the
+ *       ranks with the rest of the message). */
 int basq_finalize_geo_f64(const double* parts, int32_t n_parts, int32_t msg_rows, int32_t q, int32_t S,
                           const double* diagU, int64_t ld_diag, int32_t n_diag, double diag_noise, int32_t diag_wrow,
                           int32_t diag_tail_row, int32_t n_tail_diag, const int64_t* geo, double* XcarT, double* tot_out,
@@ -259,9 +269,11 @@ int basq_blocksum_geo_f64(const basq_kernel_spec* spec, const double* nys, int32
                           int32_t n_chunks, int32_t class_mod, int32_t class0, double* Xpart, double* totpart,
                           void* stream);
 int basq_reweight_compact_geo_f64(const double* cand, const double* mu, const int64_t* gid, const double* wx,
-                                  const int64_t* geo, const int32_t* info, int64_t R_max, int32_t S, int32_t kp,
-                                  const int32_t* keep_rank, const double* w_star, const double* tot, double* cand_out,
-                                  double* mu_out, int64_t* gid_out, double* wx_out, void* stream);
+                                  const int64_t* geo, const int64_t* geo_next, const int32_t* info, int64_t R_max,
+                                  int32_t S, int32_t kp,
+                                  const int32_t* keep_rank, const double* w_star, const double* tot, int64_t out_rows,
+                                  int32_t expect_keep, double* cand_out, double* mu_out, int64_t* gid_out, double* wx_out,
+                                  void* stream);
 
 /* Initial state: mu[p] = 1/N_total (BASQ/_rchq.py:53), gid[p] = gid0 + p (:55). */
 int basq_init_state_f64(double* mu, int64_t* gid, int64_t Rl, int64_t gid0, int64_t n_total, void* stream);

@@ -157,10 +157,12 @@ class CpuStandInOps:
         return out
 
     def tail_weights_geo(self, mu, wx, geo_row, S, out):
-        n_full, n_tail = int(geo_row[1]), int(geo_row[5])
+        n_full, n_tail, off, Rl = (int(geo_row[k]) for k in (1, 5, 6, 7))
         out.zero_()
-        t = mu[n_full:n_full + n_tail]
-        out[:n_tail] = t if wx is None else t * wx[n_full:n_full + n_tail]
+        for k in range(n_tail):
+            p = n_full + k - off                               # local index of tail point k (held by this rank or not)
+            if 0 <= p < Rl:
+                out[k] = mu[p] if wx is None else mu[p] * wx[p]
         return out
 
     def blocksum(self, spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, out=None, class_mod=0, class0=0):
@@ -295,36 +297,49 @@ class CpuStandInOps:
         return cand_o, mu_o, gid_o, wx_o
 
     # device-resident round descriptors: on the CPU the table is simply read
-    def geo_init(self, n_rounds, R, S, reg_hi):
+    def geo_init(self, n_rounds, R, S, reg_hi, off=0, Rl=None):
         g = torch.zeros(n_rounds, 8, dtype=torch.int64)
         nb = R // S
-        g[0, 0], g[0, 1], g[0, 2], g[0, 4], g[0, 5] = R, nb * S, reg_hi, nb, R - nb * S
+        g[0] = torch.tensor([R, nb * S, reg_hi, 0, nb, R - nb * S, off, R if Rl is None else Rl], dtype=torch.int64)
         return g
 
     def round_next(self, geo_row, info, keep_rank, S, class_mode, expect_half, geo_next):
         self._count("round_next")
-        R, n_full = int(geo_row[0]), int(geo_row[1])
+        from basq_amd._partition import RoundGeometry, next_shard
+
+        R, n_full, off, Rl = int(geo_row[0]), int(geo_row[1]), int(geo_row[6]), int(geo_row[7])
         nb, n_tail = n_full // S, R - n_full
         n_keep, status = int(info[0]), int(info[1])
         viol = int(geo_row[3])
         if status != 0 or (expect_half and 2 * n_keep != S):
             viol = 1
-        Rn = nb * n_keep + (n_tail if int(keep_rank[S - 1]) >= 0 else 0)
+        Rn = 0 if viol else nb * n_keep + (n_tail if int(keep_rank[S - 1]) >= 0 else 0)
         nbn = Rn // S
         reg_blocks = (nbn // class_mode) * class_mode if class_mode > 0 else ((int(geo_row[2]) // S) // 2 if class_mode < 0 else 0)
-        geo_next[:] = torch.tensor([Rn, nbn * S, reg_blocks * S, viol, nbn, Rn - nbn * S, 0, 0], dtype=torch.int64)
+        kept = [j for j in range(S) if int(keep_rank[j]) >= 0]
+        n_off, n_Rl = (0, 0) if viol else next_shard(off, Rl, RoundGeometry.of(R, S), kept)
+        geo_next[:] = torch.tensor([Rn, nbn * S, reg_blocks * S, viol, nbn, Rn - nbn * S, n_off, n_Rl], dtype=torch.int64)
 
     def blocksum_geo(self, spec, nys, m, cand, mu, wx, geo_row, mode, S, n_chunks, out=None, class_mod=0, class0=0):
-        R, n_full, reg_hi = int(geo_row[0]), int(geo_row[1]), int(geo_row[2])
+        R, n_full, reg_hi, off, Rl = (int(geo_row[k]) for k in (0, 1, 2, 6, 7))
         lo, hi = (0, reg_hi) if mode == 1 else ((reg_hi, R) if mode == 2 else (0, R))
-        return self.blocksum(spec, nys, m, cand[lo:], mu[lo:], None if wx is None else wx[lo:], hi - lo, lo, n_full, S,
+        lo, hi = max(lo, off), min(hi, off + Rl)               # the mode's range, restricted to this rank's shard
+        hi = max(hi, lo)
+        sk = lo - off
+        return self.blocksum(spec, nys, m, cand[sk:], mu[sk:], None if wx is None else wx[sk:], hi - lo, lo, n_full, S,
                              n_chunks, out=out, class_mod=class_mod, class0=class0)
 
-    def reweight_compact_geo(self, cand, mu, gid, wx, geo_row, info, R_max, S, kp, keep_rank, w_star, tot, out_rows):
-        R, n_full = int(geo_row[0]), int(geo_row[1])
+    def reweight_compact_geo(self, cand, mu, gid, wx, geo_row, geo_next, info, R_max, S, kp, keep_rank, w_star, tot,
+                             out_rows, expect_keep=-1):
+        n_full, off, Rl = int(geo_row[1]), int(geo_row[6]), int(geo_row[7])
         n_keep = int(info[0])
-        new_R = (n_full // S) * n_keep + ((R - n_full) if int(keep_rank[S - 1]) >= 0 else 0)
-        c, u, g, w = self.reweight_compact(cand, mu, gid, wx, R, 0, n_full, S, kp, keep_rank, w_star, tot, n_keep, 0, new_R)
+        if int(geo_row[3]) != 0 or int(info[1]) != 0 or (expect_keep >= 0 and n_keep != expect_keep):
+            z = lambda *sh, dt=torch.float64: torch.zeros(*sh, dtype=dt)      # noqa: E731  a violating round writes nothing
+            return (z(max(out_rows, 1), kp), z(max(out_rows, 1)), z(max(out_rows, 1), dt=torch.int64),
+                    z(max(out_rows, 1)) if wx is not None else None)
+        new_off, new_R = int(geo_next[6]), int(geo_next[7])
+        c, u, g, w = self.reweight_compact(cand, mu, gid, wx, Rl, off, n_full, S, kp, keep_rank, w_star, tot, n_keep,
+                                           new_off, new_R)
 
         def grow(t):
             if t is None:
@@ -334,6 +349,10 @@ class CpuStandInOps:
             return o
 
         return grow(c), grow(u), grow(g), grow(w)
+
+    @staticmethod
+    def info_kept_buffer(info, kept):
+        return torch.cat([info, kept])
 
     def init_state(self, Rl, gid0, n_total):
         mu = torch.full((max(Rl, 1),), 1.0 / n_total, dtype=torch.float64)

@@ -52,7 +52,7 @@ def _worker(rank, world, port, name, q, rank0_only=False):
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        import basq_amd._engine as E
+        import basq_amd._config as E
         from basq_amd._engine import EngineTrace, RecombinationEngine, TorchDistComm
 
         if rank0_only:                                          # basis + per-round reduction on rank 0, results broadcast
@@ -132,7 +132,8 @@ def _basis_worker(rank, world, port, name, q):
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from basq_amd._engine import TorchDistComm, _ShardedProducts, nystrom_basis
+        from basq_amd._basis import _ShardedProducts, nystrom_basis
+        from basq_amd._engine import TorchDistComm
         from basq_amd._partition import initial_shards
         from tests.cpu_stand_in import CpuStandInOps
 
@@ -157,7 +158,7 @@ def test_sharded_range_finder_equals_dense(name, world):
     """Row-sharded Gram products (+ the symmetry A ~ A^T) give the same Nystrom basis as the single-process range
     finder, up to the sign of each row and rounding; the row blocks carry the structured kernels' diagonal terms on the
     true diagonal (``diag_offset``); every rank ends up with the same basis; only rank 0's generator is consumed."""
-    from basq_amd._engine import nystrom_basis
+    from basq_amd._basis import nystrom_basis
     from tests.cpu_stand_in import CpuStandInOps
 
     ctx = mp.get_context("spawn")

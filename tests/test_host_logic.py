@@ -58,7 +58,7 @@ def test_choose_chunks_bounds():
 def test_late_split_keeps_chunk_boundaries(off, Rl, n_full, S, n_chunks):
     """Cutting the round-1 block sums into two launches (the second one deferred behind the range finder) must not
     move any chunk boundary: the partial sums have to be bit-identical to the single launch's."""
-    from basq_amd._engine import _late_split
+    from basq_amd._batch import late_split as _late_split
     from basq_amd.kernels import StationaryKernel
 
     ops = CpuStandInOps()
@@ -134,7 +134,7 @@ def test_reflector_nullspace_on_real_round_matrices():
 
 def test_gpu_range_finder_equals_host_householder():
     """CholeskyQR2 range finder vs the reference-style host Householder path: same selection."""
-    import basq_amd._engine as E
+    import basq_amd._config as E
 
     c = BY_NAME["rbf_2e4_defaults"]
     pts, nys = build_pool(c)
@@ -294,7 +294,7 @@ def test_tiny_and_degenerate_pools(N, d, n, m):
 def test_make_cov_psd_follows_the_reference(kind):
     """SOBER's Gram repair (SOBER/_utils.py:113-154, restated in oracle/rchq_oracle.py): Cholesky AND a non-negative
     spectrum decide, the jitter loop runs until both hold."""
-    from basq_amd._engine import _make_cov_psd
+    from basq_amd._basis import make_cov_psd as _make_cov_psd
     from oracle.rchq_oracle import make_cov_psd_sober
 
     g = torch.Generator().manual_seed(5)
@@ -328,7 +328,7 @@ def test_make_cov_psd_follows_the_reference(kind):
 def test_descriptor_driven_rounds_equal_round_by_round(N, d, n, m, seed):
     """The rounds enqueued without a host wait (device-resident descriptor: basq_round_next_i64 + the *_geo entries) select
     the same batch as the loop with one read-back per round -- same indices, weights to rounding."""
-    import basq_amd._engine as eng
+    import basq_amd._config as eng
     from basq_amd.kernels import StationaryKernel
     from basq_amd.pools import gmm_pool
 
@@ -342,7 +342,7 @@ def test_descriptor_driven_rounds_equal_round_by_round(N, d, n, m, seed):
         try:
             torch.manual_seed(11)
             ops = CpuStandInOps()
-            res.append(eng.RecombinationEngine(ops).run(pts, 0, N, nys, n, kern))
+            res.append(RecombinationEngine(ops).run(pts, 0, N, nys, n, kern))
             counts.append(dict(ops.calls))
             after = torch.rand(1).item()                       # the generator ends in the same state on both paths
         finally:
@@ -361,7 +361,7 @@ def test_descriptor_violation_repeats_the_batch_round_by_round():
     """A violation flag in the descriptor (an elimination that failed or did not keep half of the sets while regrouped
     messages were already enqueued) makes the engine repeat the batch with one read-back per round: same result, and the
     CPU generator is consumed once, as by a single run."""
-    import basq_amd._engine as eng
+    import basq_amd._config as eng
     from basq_amd.kernels import StationaryKernel
     from basq_amd.pools import gmm_pool
 
@@ -378,14 +378,14 @@ def test_descriptor_violation_repeats_the_batch_round_by_round():
 
     torch.manual_seed(5)
     ops = Flagging()
-    ia, wa = eng.RecombinationEngine(ops).run(pts, 0, N, nys, n, kern)
+    ia, wa = RecombinationEngine(ops).run(pts, 0, N, nys, n, kern)
     ra = torch.rand(1).item()
     assert ops.calls["round_next"] >= 3                          # the flag was really raised mid-way
     old = eng.ASYNC_ROUNDS
     eng.ASYNC_ROUNDS = False
     try:
         torch.manual_seed(5)
-        ib, wb = eng.RecombinationEngine(CpuStandInOps()).run(pts, 0, N, nys, n, kern)
+        ib, wb = RecombinationEngine(CpuStandInOps()).run(pts, 0, N, nys, n, kern)
         rb = torch.rand(1).item()
     finally:
         eng.ASYNC_ROUNDS = old
@@ -397,7 +397,7 @@ def test_descriptor_violation_repeats_the_batch_round_by_round():
 def test_descriptor_driven_rounds_structured_kernels(name):
     """Posterior / WSABI-L kernels (likelihood noise on the block diagonals, incl. the ragged tail block whose length
     only the device knows) through the descriptor-driven rounds: the round-by-round loop's batch, and the golden's."""
-    import basq_amd._engine as eng
+    import basq_amd._config as eng
 
     c = BY_NAME[name]
     pts, nys = build_pool(c)
@@ -408,7 +408,7 @@ def test_descriptor_driven_rounds_structured_kernels(name):
         try:
             torch.manual_seed(c["torch_seed"])
             ops = CpuStandInOps()
-            out.append(eng.RecombinationEngine(ops).run(pts, 0, c["N"], nys, c["n"], build_product_kernel(c)))
+            out.append(RecombinationEngine(ops).run(pts, 0, c["N"], nys, c["n"], build_product_kernel(c)))
             ran = ops.calls.get("round_next", 0)
         finally:
             eng.ASYNC_ROUNDS = old

@@ -422,7 +422,7 @@ def test_box_muller_vs_torch_randn(hip_ops, n):
 def test_sharded_products_on_device(hip_ops):
     """The row-sharded range finder's device code (split-K batched GEMM on a row block, padded all-gather layout)
     against the dense range finder, on one GPU: a loop-back communicator that plays both ranks of a 2-rank group."""
-    import basq_amd._engine as E
+    import basq_amd._basis as E
     from basq_amd.kernels import StationaryKernel
     from basq_amd.pools import gmm_pool
 
@@ -466,7 +466,6 @@ def test_sharded_products_on_device(hip_ops):
     comm.other = other
     prod.a = a
     prod.at = a
-    prod.qta = lambda Q: a(Q).t().contiguous()
     torch.manual_seed(5)
     Us = E.nystrom_basis(hip_ops, prod, q)
     torch.manual_seed(5)

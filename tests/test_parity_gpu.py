@@ -198,7 +198,7 @@ def test_golden_parity_descriptor_driven_rounds(name):
     geometry in a device-resident descriptor -- against the same goldens (no trace: a trace selects the round-by-round
     loop)."""
     import basq_amd
-    import basq_amd._engine as eng
+    import basq_amd._config as eng
 
     if not has_golden(name):
         pytest.skip("fixture not generated")

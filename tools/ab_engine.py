@@ -3,7 +3,7 @@ same-process comparisons mean anything).
 
     python tools/ab_engine.py LATE_CHUNKS 0 1 [--reps 8]
 
-Sets ``basq_amd._engine.<NAME>`` to each value in turn (A B A B ...), times ``reps`` headline batches per visit and
+Sets ``basq_amd._config.<NAME>`` to each value in turn (A B A B ...), times ``reps`` headline batches per visit and
 prints the mean / min per value.
 """
 import argparse
@@ -15,7 +15,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import basq_amd                                     # noqa: E402
-import basq_amd._engine as eng                      # noqa: E402
+import basq_amd._config as eng                      # noqa: E402
 from basq_amd.pools import gmm_pool                 # noqa: E402
 
 
@@ -25,7 +25,7 @@ def main():
     ap.add_argument("values", nargs="+")
     ap.add_argument("--reps", type=int, default=8)
     ap.add_argument("--visits", type=int, default=3)
-    ap.add_argument("--module", default="_engine", help="basq_amd submodule holding the switch (_engine, _partition)")
+    ap.add_argument("--module", default="_config", help="basq_amd submodule holding the switch (_config, _partition, _ops)")
     a = ap.parse_args()
     global eng
     import importlib

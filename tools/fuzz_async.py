@@ -14,7 +14,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import basq_amd                                    # noqa: E402
-import basq_amd._engine as eng                     # noqa: E402
+import basq_amd._config as eng                     # noqa: E402
 from tests.cases import K, build_pool, build_product_kernel, case   # noqa: E402
 
 g = torch.Generator().manual_seed(int(sys.argv[1]) if len(sys.argv) > 1 else 0)

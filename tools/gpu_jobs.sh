@@ -1,0 +1,59 @@
+#!/bin/bash
+# One parameterised runner for everything this repo hands to `gpurun` (replaces the per-call scripts of rounds 1-2, whose
+# history is in git: tools/gpu_runs/ up to commit 98fa8bf).
+#
+#   gpurun --timeout 1200 -- 'bash tools/gpu_jobs.sh <tag> <job> [<job> ...]'
+#
+# Every job writes under gpurun_out/<tag>/ and prints a short tail; a job that fails or times out stops the call (no GPU
+# step is started after a killed one).  What was copied from there into profiles/ is listed in profiles/README.md.
+set -u
+tag=$1; shift
+out=gpurun_out/$tag; mkdir -p "$out"
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+export TMPDIR=/tmp
+
+note() { echo "[$(date +%H:%M:%S)] $*" | tee -a "$out/jobs.log"; }
+
+job_tests()       { timeout -k 10 1100 python -m pytest tests -x -q -m gpu > "$out/gpu_tests.log" 2>&1; rc=$?; tail -4 "$out/gpu_tests.log" | cut -c1-300; return $rc; }
+job_tests_fast()  { timeout -k 10 900 python -m pytest tests -x -q -m gpu -k "not cfg3 and not cfg4 and not cfg5 and not full_size" > "$out/gpu_tests_fast.log" 2>&1; rc=$?; tail -4 "$out/gpu_tests_fast.log" | cut -c1-300; return $rc; }
+job_smoke()       { timeout -k 10 300 python __graft_entry__.py smoke > "$out/smoke.log" 2>&1; rc=$?; tail -2 "$out/smoke.log"; return $rc; }
+job_bench()       { timeout -k 10 900 python bench.py --breakdown > "$out/bench.json" 2> "$out/bench.err"; rc=$?; cut -c1-400 "$out/bench.json"; return $rc; }
+job_bench20()     { timeout -k 10 900 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > "$out/bench20.json" 2> "$out/bench20.err"; rc=$?; cut -c1-400 "$out/bench20.json"; return $rc; }
+job_bench_nocpu() { timeout -k 10 600 python bench.py --no-cpu-baseline > "$out/bench_nocpu.json" 2> "$out/bench_nocpu.err"; rc=$?; cut -c1-400 "$out/bench_nocpu.json"; return $rc; }
+job_bench_dist1() { BASQ_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 timeout -k 10 600 python bench.py --no-cpu-baseline > "$out/bench_force_dist.json" 2> "$out/bench_force_dist.err"; rc=$?; cut -c1-300 "$out/bench_force_dist.json"; return $rc; }
+job_configs()     { timeout -k 10 900 python tools/bench_configs.py > "$out/configs.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/configs.txt" | cut -c1-330; return $rc; }
+job_concurrent()  { timeout -k 10 600 python tools/exp_concurrent.py --threads 2 --launches > "$out/concurrent.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/concurrent.txt" | cut -c1-200; return $rc; }
+job_concurrent3() { timeout -k 10 600 python tools/exp_concurrent.py --threads 3 > "$out/concurrent3.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/concurrent3.txt" | cut -c1-200; return $rc; }
+job_many()        { timeout -k 10 600 python tools/bench_many.py > "$out/many.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/many.txt" | cut -c1-250; return $rc; }
+job_opaque_cfg4() { timeout -k 10 1100 python tools/bench_opaque_cfg4.py > "$out/opaque_cfg4.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/opaque_cfg4.txt" | cut -c1-250; return $rc; }
+
+# rocprofv3 kernel statistics of a python command: prof <name> <script> [args...]  (program itself after `--`, run from /tmp)
+prof() {
+    local name=$1; shift
+    ( cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$out/prof_$name" -o "$name" -- python3 "$ROOT/$1" "${@:2}" > "$ROOT/$out/prof_$name.log" 2>&1 )
+    local rc=$?
+    head -16 "$out/prof_$name/${name}_kernel_stats.csv" 2>/dev/null | cut -c1-160
+    return $rc
+}
+job_prof_bench()  { prof bench bench.py --steps 10 --warmup 2 --no-cpu-baseline && python tools/trace_gaps.py "$(ls $out/prof_bench/*kernel_trace.csv | head -1)" > "$out/trace_gaps_bench.txt" 2>&1; rc=$?; head -6 "$out/trace_gaps_bench.txt" | cut -c1-200; return $rc; }
+job_prof_many()   { prof many tools/bench_many.py --batches 8 --inflight 2 && python tools/trace_overlap.py "$(ls $out/prof_many/*kernel_trace.csv | head -1)" > "$out/trace_overlap_many.txt" 2>&1; rc=$?; head -30 "$out/trace_overlap_many.txt" | cut -c1-200; return $rc; }
+job_prof_concurrent() { prof conc tools/exp_concurrent.py --threads 2 --batches 6 && python tools/trace_overlap.py "$(ls $out/prof_conc/*kernel_trace.csv | head -1)" > "$out/trace_overlap_conc.txt" 2>&1; rc=$?; head -30 "$out/trace_overlap_conc.txt" | cut -c1-200; return $rc; }
+job_prof_cfg4()   { prof cfg4 tools/bench_configs.py --only cfg4_matern52_1e6_d32; }
+job_prof_cfg5m()  { prof cfg5m tools/bench_configs.py --only cfg5m_wsabim_5e5; }
+job_drop_traces() { rm -f $out/prof_*/*trace.csv; }
+
+# hardware counters of the dominant kernel, one pass per counter group (never combined with a trace domain)
+pmc() {
+    local name=$1 ctrs=$2
+    ( cd /tmp && timeout -k 10 600 rocprofv3 --pmc $ctrs --output-format csv -d "$ROOT/$out/pmc_$name" -o "$name" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline-batch > "$ROOT/$out/pmc_$name.log" 2>&1 )
+}
+job_pmc()         { pmc fetch "FETCH_SIZE" && pmc write "WRITE_SIZE" && pmc pipe "SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" && python tools/pmc_summary.py "$out" > "$out/pmc_summary.json"; rc=$?; cut -c1-400 "$out/pmc_summary.json"; return $rc; }
+
+for j in "$@"; do
+    note "job $j"
+    if ! "job_$j"; then
+        note "job $j FAILED (rc != 0): stopping"
+        exit 1
+    fi
+done
+note "all jobs done"
