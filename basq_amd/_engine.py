@@ -16,6 +16,7 @@ scheduler then resumes them in a fixed order, so that all ranks issue their coll
 from __future__ import annotations
 
 import contextlib
+import time
 from collections import deque
 from dataclasses import dataclass, field
 
@@ -98,6 +99,7 @@ class Job:
     init_weights: object = None
     objective: object = None
     seed: int | None = None                         # ``torch.manual_seed(seed)`` right before this batch's draw
+    times: dict = field(default_factory=dict)       # filled by run_many: host clock at "start" and "done" (latency)
 
 
 class RecombinationEngine:
@@ -151,6 +153,7 @@ class RecombinationEngine:
                     return True
                 except StopIteration as stop:
                     results[k] = stop.value
+                    jobs[k].times["done"] = time.perf_counter()
                     free.append(ops)
                     return False
 
@@ -160,6 +163,7 @@ class RecombinationEngine:
                 ops = free.popleft()
                 if job.seed is not None:
                     torch.manual_seed(job.seed)
+                job.times["start"] = time.perf_counter()
                 batch = Batch(ops, self.comm, job.pts_local, job.gid0, job.n_total, job.pts_nys, job.num_pts, job.kernel,
                               job.trace, job.variant, job.init_weights, job.objective, pipelined=pipelined)
                 entry = [k, batch.steps(), ops, None]

@@ -55,6 +55,11 @@ CPU_CASES = [
     ("posterior_noise_ragged", True, 256 << 20),    # noise 1e-3: the per-block diagonal decides the selection
     ("wsabil_noise_ragged", True, 256 << 20),
     ("wsabim_noise_ragged", True, 256 << 20),       # WSABI-M as an opaque callable: no structure needed at all
+    # block_exact=None (what a BARE callable gets): the probe must find the block dependence by itself ...
+    ("posterior_noise_ragged", None, 256 << 20),
+    ("cfg1_posterior_1e4", None, 256 << 20),        # ... even at the reference's default noise of 1e-10
+    ("wsabim_noise_ragged", None, 256 << 20),
+    ("rbf_ragged", None, 123 * 8 * 1000),           # ... and must let a plain kernel take the chunked mode
 ]
 
 
@@ -71,6 +76,34 @@ def test_opaque_callable_host_logic_reproduces_golden(name, block_exact, chunk_b
     _check(c, fx, idx, w, tr)
     if c["N"] > 2 * c["n"]:
         assert ops.calls.get("dense", 0) > 0 and ops.calls.get("blocksum", 0) == 0      # the dense path did the work
+    if block_exact is None:
+        post = c["kernel"]["posterior"] is not None
+        assert kern.resolve_mode(ops, nys, 2 * min(c["n"], c["m"] + 1)) == post          # exact iff the kernel needs it
+
+
+def test_probe_decisions():
+    """``CallableKernel.resolve_mode``: exact calls unless the callable provably evaluates column by column."""
+    ops = CpuStandInOps()
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(40, 3, generator=g, dtype=torch.float64)
+    rbf = lambda x, y: torch.exp(-0.5 * torch.cdist(x, y) ** 2)                        # noqa: E731
+
+    def noisy(noise):
+        def fn(x, y):
+            K = rbf(x, y)
+            k = min(len(x), len(y))
+            K[range(k), range(k)] += noise                                             # BASQ/_gp.py:275-276
+            return K
+        return fn
+
+    assert CallableKernel(rbf).resolve_mode(ops, X, 16) is False
+    assert CallableKernel(noisy(1e-3)).resolve_mode(ops, X, 16) is True
+    assert CallableKernel(noisy(1e-10)).resolve_mode(ops, X, 16) is True               # the reference's default lik_var
+    assert CallableKernel(noisy(0.0)).resolve_mode(ops, X, 16) is False
+    assert CallableKernel(lambda x, y: rbf(x, y) * float("nan")).resolve_mode(ops, X, 16) is True   # NaNs: stay exact
+    assert CallableKernel(lambda x, y: rbf(x, y) / len(y)).resolve_mode(ops, X, 16) is True         # depends on the block size
+    assert CallableKernel(noisy(1e-3), block_exact=False).resolve_mode(ops, X, 16) is False         # explicit opt-in wins
+    assert CallableKernel(rbf, block_exact=True).resolve_mode(ops, X, 16) is True
 
 
 def test_callable_is_called_like_the_reference_in_block_exact_mode():
@@ -97,7 +130,7 @@ def test_bare_callable_is_wrapped_and_rejects_bad_returns():
     from basq_amd._rchq import _as_kernel_object
 
     k = _as_kernel_object(lambda x, y: x @ y.T)
-    assert isinstance(k, CallableKernel) and not k.block_exact
+    assert isinstance(k, CallableKernel) and k.block_exact is None         # mode decided by the probe, per batch
     with pytest.raises(TypeError):
         _as_kernel_object(3.0)
     bad = CallableKernel(lambda x, y: (x @ y.T)[:, :-1])
@@ -114,7 +147,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, name, q):
+def _worker(rank, world, port, name, q, block_exact=False):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -131,21 +164,28 @@ def _worker(rank, world, port, name, q):
         off, n = initial_shards(c["N"], world)[rank]
         torch.manual_seed(c["torch_seed"])
         idx, w = RecombinationEngine(CpuStandInOps(), TorchDistComm()).run(
-            pts[off:off + n].clone(), off, c["N"], nys, c["n"], CallableKernel(lambda x, y: ko(x, y), chunk_bytes=123 * 8 * 700))
+            pts[off:off + n].clone(), off, c["N"], nys, c["n"],
+            CallableKernel(lambda x, y: ko(x, y), block_exact=block_exact, chunk_bytes=123 * 8 * 700))
         q.put((rank, idx.tolist(), w.tolist()))
     finally:
         dist.destroy_process_group()
 
 
-def test_opaque_callable_sharded_matches_golden():
+@pytest.mark.parametrize("name,world,block_exact", [
+    ("rbf_ragged", 2, False),
+    ("posterior_noise_ragged", 2, None),      # a bare predictive_covariance-style callable on two ranks: blocks that straddle
+    ("posterior_noise_ragged", 3, True),      # the shard border are evaluated whole by the owner of their first point
+    ("wsabim_noise_ragged", 4, None),
+    ("rbf_tiny_final", 2, True),              # single reduction of the points, shards shorter than a block
+])
+def test_opaque_callable_sharded_matches_golden(name, world, block_exact):
     import torch.multiprocessing as mp
 
-    name, world = "rbf_ragged", 2
     fx = load_golden(name)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, q, block_exact)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
@@ -167,6 +207,9 @@ GPU_CASES = [
     ("posterior_noise_ragged", True, 256 << 20),
     ("wsabim_noise_ragged", True, 256 << 20),
     ("cfg2_rbf_1e5", False, 256 << 20),
+    ("posterior_noise_ragged", None, 256 << 20),    # a BARE lambda, no keyword: the probe selects the reference's calls
+    ("wsabil_noise_ragged", None, 256 << 20),
+    ("matern32_8e3", None, 256 << 20),              # a bare lambda over a plain kernel: whatever the probe picks, same batch
 ]
 
 
@@ -182,7 +225,7 @@ def test_opaque_callable_gpu_reproduces_golden(name, block_exact, chunk_bytes):
     ko = _to_device(ko, dev)
     tr = basq_amd.EngineTrace()
     torch.manual_seed(c["torch_seed"])
-    if block_exact or chunk_bytes != 256 << 20:
+    if block_exact is not None:
         kern = CallableKernel(lambda x, y: ko(x, y), block_exact=block_exact, chunk_bytes=chunk_bytes)
     else:
         kern = lambda x, y: ko(x, y)                # noqa: E731  a bare lambda, exactly what the reference accepts

@@ -276,3 +276,56 @@ def test_global_rng_stays_in_lock_step_across_ranks():
                 assert res[r][b][0] == one[b][0], f"world {world} rank {r} batch {b}: indices differ from the 1-rank run"
                 w, w1 = torch.tensor(res[r][b][1]), torch.tensor(one[b][1])
                 assert ((w - w1).abs() / w1).max().item() <= 1e-9
+
+
+# ---- descriptor-driven rounds on several ranks (no host wait per round; the exchange is stream-ordered) ----------------
+def _async_worker(rank, world, port, name, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from basq_amd._engine import EngineTrace, RecombinationEngine, TorchDistComm
+        from basq_amd._partition import initial_shards
+        from tests.cpu_stand_in import CpuStandInOps
+
+        c = BY_NAME[name]
+        pts, nys = build_pool(c)
+        off, n = initial_shards(c["N"], world)[rank]
+        tr = EngineTrace(host_sync=False)                       # the path an untraced call takes, rounds read back after
+        ops = CpuStandInOps()
+        torch.manual_seed(c["torch_seed"])
+        idx, w = RecombinationEngine(ops, TorchDistComm()).run(pts[off:off + n].clone(), off, c["N"], nys, c["n"],
+                                                               build_product_kernel(c), tr)
+        q.put((rank, idx.tolist(), w.tolist(), [r["kept"] for r in tr.rounds], ops.calls.get("round_next", 0)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world", [("rbf_ragged", 2), ("rbf_ragged", 4), ("rbf_ragged", 8),
+                                        ("cfg1_posterior_1e4", 2), ("cfg1_posterior_1e4", 4),
+                                        ("posterior_noise_ragged", 3), ("wsabil_noise_ragged", 2), ("wsabil_2e4", 4),
+                                        ("rbf_2e4_defaults", 8), ("matern52_posterior", 2)])
+def test_sharded_descriptor_driven_rounds(name, world):
+    """The N > 1 fast path: every rank's shard of every round comes from the device-resident descriptor
+    (``basq_round_next_i64`` evaluates ``next_shard`` in closed form), the per-round all-gather is enqueued like any other
+    launch, and the host reads the descriptor table once.  Golden indices and per-round survivor sets on every rank,
+    ranks bit-identical among themselves."""
+    fx = load_golden(name)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_async_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    gw = torch.tensor(fx["w"], dtype=torch.float64)
+    for rank, idx, w, kept, n_next in res:
+        assert n_next > 0, "the descriptor-driven rounds did not run"
+        assert idx == fx["idx"], f"rank {rank}: indices differ"
+        assert kept == [r["kept"] for r in fx["rounds"]]
+        assert ((torch.tensor(w, dtype=torch.float64) - gw).abs() / gw).max().item() <= 1e-6
+    assert all(r[1] == res[0][1] and r[2] == res[0][2] for r in res)

@@ -418,3 +418,28 @@ def test_descriptor_driven_rounds_structured_kernels(name):
     assert torch.allclose(wa, wb, rtol=1e-11, atol=0)
     if has_golden(name):
         assert ia.tolist() == load_golden(name)["idx"]
+
+
+def test_exact_unit_plan_brute_force():
+    """Multi-rank ``block_exact`` callables: every kernel call of the reference (blocks of S positions, then the
+    remainder) is made exactly once, by the rank that holds its first position, and reaches < S positions past it."""
+    from basq_amd._batch import exact_unit_plan
+
+    rnd = random.Random(1)
+    for _ in range(4000):
+        S, R, W = rnd.choice([2, 3, 4, 7, 10]), rnd.randint(1, 60), rnd.randint(1, 6)
+        bounds = [0] + sorted(rnd.randint(0, R) for _ in range(W - 1)) + [R]
+        n_full = (R // S) * S
+        units = [(b * S, (b + 1) * S) for b in range(R // S)] + ([(n_full, R)] if R > n_full else [])
+        got = []
+        for r in range(W):
+            off, Rl = bounds[r], bounds[r + 1] - bounds[r]
+            first, need = exact_unit_plan(off, Rl, n_full, R, S)
+            assert 0 <= need < S
+            p = first if first is not None else off + Rl
+            while p < off + Rl:
+                hi = p + S if p < n_full else R
+                assert hi <= off + Rl + need
+                got.append((p, hi))
+                p = hi
+        assert sorted(got) == units

@@ -407,6 +407,59 @@ def test_quadrature_step_vs_oracle(hip_ops):
         assert VarZy == pytest.approx(float(w @ kern_o(X, X) @ w), rel=1e-6, abs=1e-14)
 
 
+def test_prior_max_and_uniform_trans_vs_oracle(hip_ops):
+    """``KernelQuadrature.prior_max`` (BASQ/_quadrature.py:66-84) and ``uniform_trans`` (:86-107) against the oracle:
+    same pools (drawn where the reference draws them, from the CPU global generator), same selection, same estimates."""
+    import basq_amd
+    from basq_amd.pools import gmm_pool
+    from oracle.kernels_oracle import PosteriorOracle, StationaryOracle, synthetic_gp_state
+    from oracle.rchq_oracle import recombination_oracle
+
+    d, n_obs, N, m, n = 4, 50, 5000, 80, 24
+    Xobs = gmm_pool(n_obs, d, 51)
+    base_o = StationaryOracle("rbf", 1.6, 1.2)
+    W, const, mc, _ = synthetic_gp_state(Xobs, base_o, 1e-6, 4)
+    K = basq_amd.kernels
+    post = K.PosteriorKernel(K.StationaryKernel("rbf", 1.6, 1.2), Xobs, W, 1e-6, const, mc)
+    post_o = PosteriorOracle(base_o, Xobs, W, 1e-6)
+    kq = basq_amd.KernelQuadrature(N, m, N, n, None, post, "cuda:0")
+
+    def oracle_run(pool, kern_o):
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(torch.float64)
+        try:
+            return recombination_oracle(pool, pool[:m], n, kern_o)
+        finally:
+            torch.set_default_dtype(prev)
+
+    def gp_mean(X):
+        return const + base_o(X, Xobs) @ mc
+
+    # prior_max: pool ~ mvn_max, posterior kernel, predictive mean
+    mvn = torch.distributions.MultivariateNormal(torch.zeros(d, dtype=torch.float64), 1.5 * torch.eye(d, dtype=torch.float64))
+    torch.manual_seed(9)
+    EZy, VarZy = kq.prior_max(mvn)
+    torch.manual_seed(9)
+    pool = mvn.sample(sample_shape=torch.Size([N]))
+    idx, w = oracle_run(pool, post_o)
+    X = pool[idx]
+    assert EZy == pytest.approx(float(w @ gp_mean(X)), rel=1e-8)
+    assert VarZy == pytest.approx(float(w @ post_o(X, X) @ w), rel=1e-6, abs=1e-14)
+
+    # uniform_trans: uniform pool, PRIOR kernel of the importance-weighted model, its predictive mean
+    def uni_sampler(k):
+        return torch.rand(k, d, dtype=torch.float64) * 6.0 - 3.0
+
+    torch.manual_seed(10)
+    EZu, VarZu = kq.uniform_trans(post, uni_sampler)
+    torch.manual_seed(10)
+    pool = uni_sampler(N)
+    idx, w = oracle_run(pool, base_o)
+    X = pool[idx]
+    assert EZu == pytest.approx(float(w @ gp_mean(X)), rel=1e-8)
+    assert VarZu == pytest.approx(float(w @ base_o(X, X) @ w), rel=1e-6, abs=1e-14)
+
+
 @pytest.mark.parametrize("n", [990_000, 4_428, 16, 31])
 def test_box_muller_vs_torch_randn(hip_ops, n):
     """Device Box-Muller of torch.rand's uniforms == torch.randn from the same generator state, to round-off."""
@@ -637,41 +690,56 @@ def test_skinny_gemm_pipelined_path(hip_ops, M, K, N, pad, ksplit, trans):
     assert (got - want).abs().max().item() <= 1e-13 * K ** 0.5 * max(1.0, want.abs().max().item())
 
 
-@pytest.mark.parametrize("R,S,n_keep,reg_blocks,class_mod,drop_last", [
-    (10_000, 200, 100, 48, 16, False),     # regular region of 48 blocks in 16 classes + 2 blocks irregular, no tail
-    (10_123, 200, 100, 48, 16, True),      # ragged tail, last set dropped
-    (10_123, 200, 100, 0, 0, False),       # no classes: everything through mode 3
-    (4_321, 100, 37, 40, 8, False),        # an elimination that kept fewer than half of the sets
+@pytest.mark.parametrize("R,S,n_keep,reg_blocks,class_mod,drop_last,shard", [
+    (10_000, 200, 100, 48, 16, False, None),     # regular region of 48 blocks in 16 classes + 2 blocks irregular, no tail
+    (10_123, 200, 100, 48, 16, True, None),      # ragged tail, last set dropped
+    (10_123, 200, 100, 0, 0, False, None),       # no classes: everything through mode 3
+    (4_321, 100, 37, 40, 8, False, None),        # an elimination that kept fewer than half of the sets
+    (10_123, 200, 100, 48, 16, False, (3_333, 3_456)),   # a rank's shard in the middle: mid-block start and end
+    (10_123, 200, 100, 48, 16, True, (9_550, 573)),      # the last rank: end of the regular region, irregular blocks, tail
+    (10_123, 200, 100, 48, 16, False, (10_050, 73)),     # a shard inside the ragged tail only
+    (10_123, 200, 100, 0, 0, False, (0, 150)),           # a shard shorter than one block
 ])
-def test_descriptor_driven_kernels_vs_host_geometry(hip_ops, R, S, n_keep, reg_blocks, class_mod, drop_last):
+def test_descriptor_driven_kernels_vs_host_geometry(hip_ops, R, S, n_keep, reg_blocks, class_mod, drop_last, shard):
     """basq_blocksum_geo_f64 / basq_reweight_compact_geo_f64 / basq_round_next_i64: the same results as the
-    host-geometry entries given the same numbers, with launches and buffers sized for an upper bound."""
+    host-geometry entries given the same numbers, with launches and buffers sized for an upper bound -- for the whole
+    pool on one rank and for a rank's shard ``[off, off + Rl)`` of it (multi-GPU rounds without a host wait)."""
+    from basq_amd._partition import RoundGeometry, next_shard
+
     cpu = CpuStandInOps()
     d, m = 5, 130
     spec = _spec("rbf", d)
-    nys, cand = _rand(m, d, 81), _rand(R, d, 82)
+    off, Rl = shard if shard is not None else (0, R)
+    nys, cand = _rand(m, d, 81), _rand(R, d, 82)[off:off + Rl]
     g = torch.Generator().manual_seed(9)
-    mu = torch.rand(R, generator=g, dtype=torch.float64) + 0.05
+    mu = (torch.rand(R, generator=g, dtype=torch.float64) + 0.05)[off:off + Rl]
     center = hip_ops.to_device(nys.mean(0))
     pa = hip_ops.pack(spec, hip_ops.to_device(nys), center, 0, pad_rows_to=64)
-    R_max = R + 777                                               # buffers and grids are sized for an upper bound
+    R_max = Rl + 777                                              # buffers and grids are sized for an upper bound
     pb = hip_ops.zeros(R_max, hip_ops.kp(d))
-    pb[:R] = hip_ops.pack(spec, hip_ops.to_device(cand), center, 1)
+    pb[:Rl] = hip_ops.pack(spec, hip_ops.to_device(cand), center, 1)
     mu_d = hip_ops.zeros(R_max)
-    mu_d[:R] = hip_ops.to_device(mu)
+    mu_d[:Rl] = hip_ops.to_device(mu)
     nb = R // S
     n_full, reg_hi = nb * S, reg_blocks * S
-    geo = hip_ops.geo_init(4, R, S, reg_hi)
+    geo = hip_ops.geo_init(4, R, S, reg_hi, off, Rl)
+
+    def host_range(lo, hi, n_ch, **kw):
+        """The host-geometry entry over the global positions [lo, hi) restricted to the shard."""
+        lo, hi = max(lo, off), min(hi, off + Rl)
+        hi = max(hi, lo)
+        return hip_ops.blocksum(spec, pa, m, pb[lo - off:], mu_d[lo - off:], None, hi - lo, lo, n_full, S, n_ch, **kw)
+
     # block sums: regular region (classes), the rest, everything
     if class_mod:
         Xa, ta = hip_ops.blocksum_geo(spec, pa, m, pb, mu_d, None, geo[0], 1, S, class_mod, class_mod=class_mod)
-        Xb, tb = hip_ops.blocksum(spec, pa, m, pb, mu_d, None, reg_hi, 0, n_full, S, class_mod, class_mod=class_mod)
+        Xb, tb = host_range(0, reg_hi, class_mod, class_mod=class_mod)
         assert torch.equal(Xa, Xb) and torch.equal(ta, tb)
         Xa, ta = hip_ops.blocksum_geo(spec, pa, m, pb, mu_d, None, geo[0], 2, S, 1)
-        Xb, tb = hip_ops.blocksum(spec, pa, m, pb[reg_hi:], mu_d[reg_hi:], None, R - reg_hi, reg_hi, n_full, S, 1)
+        Xb, tb = host_range(reg_hi, R, 1)
         assert torch.equal(Xa, Xb) and torch.equal(ta, tb)
     Xa, ta = hip_ops.blocksum_geo(spec, pa, m, pb, mu_d, None, geo[0], 3, S, 3)
-    Xb, tb = hip_ops.blocksum(spec, pa, m, pb, mu_d, None, R, 0, n_full, S, 3)
+    Xb, tb = host_range(0, R, 3)
     assert torch.equal(Xa, Xb) and torch.equal(ta, tb)
     # an elimination outcome: n_keep sets kept (the last one or not), arbitrary positive weights
     kept_sets = sorted(torch.randperm(S - 1, generator=g)[:n_keep - (0 if drop_last else 1)].tolist() + ([] if drop_last else [S - 1]))
@@ -683,20 +751,67 @@ def test_descriptor_driven_kernels_vs_host_geometry(hip_ops, R, S, n_keep, reg_b
     gid = torch.arange(R_max, dtype=torch.int64) * 3 + 1
     kr_d, ws_d, tot_d, info_d, gid_d = (hip_ops.to_device(t) for t in (keep_rank, w_star, tot, info, gid))
     new_R = nb * len(kept_sets) + (0 if drop_last else R - n_full)
-    out_rows = new_R + 55
-    ca, ma, ga, _ = hip_ops.reweight_compact_geo(pb, mu_d, gid_d, None, geo[0], info_d, R_max, S, hip_ops.kp(d), kr_d, ws_d,
-                                                 tot_d, out_rows)
-    cb, mb, gb, _ = hip_ops.reweight_compact(pb, mu_d, gid_d, None, R, 0, n_full, S, hip_ops.kp(d), kr_d, ws_d, tot_d,
-                                             len(kept_sets), 0, new_R)
-    assert torch.equal(ca[:new_R], cb[:new_R]) and torch.equal(ma[:new_R], mb[:new_R]) and torch.equal(ga[:new_R], gb[:new_R])
-    # next descriptor: fresh classes, inherited classes, none -- against the stand-in's closed form
+    new_off, new_Rl = next_shard(off, Rl, RoundGeometry.of(R, S), kept_sets)
+    # next descriptor (no expectation on the survivor count): the shard's closed form, then the compaction that reads it
+    hip_ops.round_next(geo[0], info_d, kr_d, S, 0, False, geo[1])
+    g1 = hip_ops.to_host(geo[1], "g1").clone()
+    assert g1[0].item() == new_R and g1[3].item() == 0 and (g1[6].item(), g1[7].item()) == (new_off, new_Rl)
+    out_rows = new_Rl + 55
+    ca, ma, ga, _ = hip_ops.reweight_compact_geo(pb, mu_d, gid_d, None, geo[0], geo[1], info_d, R_max, S, hip_ops.kp(d), kr_d,
+                                                 ws_d, tot_d, out_rows)
+    cb, mb, gb, _ = hip_ops.reweight_compact(pb, mu_d, gid_d, None, Rl, off, n_full, S, hip_ops.kp(d), kr_d, ws_d, tot_d,
+                                             len(kept_sets), new_off, new_Rl)
+    assert torch.equal(ca[:new_Rl], cb[:new_Rl]) and torch.equal(ma[:new_Rl], mb[:new_Rl]) and torch.equal(ga[:new_Rl], gb[:new_Rl])
+    # next descriptor with the host's expectation: fresh classes, inherited classes, none -- against the stand-in's closed form
     for mode in (8, -1, 0):
-        hip_ops.round_next(geo[0], info_d, kr_d, S, mode, True, geo[1])
+        hip_ops.round_next(geo[0], info_d, kr_d, S, mode, True, geo[2])
         want = torch.zeros(8, dtype=torch.int64)
         cpu.round_next(hip_ops.to_host(geo[0], "g0").clone(), info, keep_rank, S, mode, True, want)
-        got = hip_ops.to_host(geo[1], "g1").clone()
+        got = hip_ops.to_host(geo[2], "g2").clone()
         assert got.tolist() == want.tolist()
-        assert got[0].item() == new_R and got[3].item() == (1 if 2 * len(kept_sets) != S else 0)
+        viol = 2 * len(kept_sets) != S
+        assert got[3].item() == (1 if viol else 0)
+        assert got[0].item() == (0 if viol else new_R)           # after a violation the next round is EMPTY
+        assert (got[6].item(), got[7].item()) == ((0, 0) if viol else (new_off, new_Rl))
+
+
+def test_violated_descriptor_round_writes_nothing(hip_ops):
+    """when an elimination keeps MORE sets than the host sized the next buffers for (early stop, status
+    1) the descriptor-driven compaction must not write a single row, and every later ``*_geo`` launch must see an empty
+    round.  The outputs are poisoned first; rows, weights and ids must come back untouched."""
+    import ctypes as C
+
+    from basq_amd._ops import _ptr
+
+    d, S, R = 4, 40, 2_000
+    spec = _spec("rbf", d)
+    kp = hip_ops.kp(d)
+    cand = hip_ops.pack(spec, hip_ops.to_device(_rand(R, d, 3)), hip_ops.to_device(torch.zeros(d, dtype=torch.float64)), 1)
+    mu = hip_ops.zeros(R) + 1.0 / R
+    gid = hip_ops.to_device(torch.arange(R, dtype=torch.int64))
+    geo = hip_ops.geo_init(4, R, S, 0)
+    keep_rank = torch.arange(S, dtype=torch.int32)                # EVERY set "kept": 2x what the host expects
+    for info_v in ([S, 1], [S, 0], [S // 2, 2]):                  # early stop / too many sets / cluster time-out
+        info = hip_ops.to_device(torch.tensor(info_v, dtype=torch.int32))
+        kr = hip_ops.to_device(keep_rank)
+        w_star, tot = hip_ops.zeros(S) + 0.5, hip_ops.zeros(S) + 1.0
+        hip_ops.round_next(geo[0], info, kr, S, 0, True, geo[1])
+        g1 = hip_ops.to_host(geo[1], "g1").tolist()
+        assert g1[3] == 1 and g1[0] == 0 and g1[7] == 0
+        out_rows = (R // S) * (S // 2) + S - 1                    # what the engine allocates for the next round
+        co, mo, go = hip_ops.zeros(out_rows, kp) - 3.0, hip_ops.zeros(out_rows) - 3.0, hip_ops.zeros(out_rows, dtype=torch.int64) - 3
+        rc = hip_ops.lib.basq_reweight_compact_geo_f64(_ptr(cand), _ptr(mu), _ptr(gid), None, _ptr(geo[0]), _ptr(geo[1]),
+                                                       _ptr(info), R, S, kp, _ptr(kr), _ptr(w_star), _ptr(tot), out_rows,
+                                                       S // 2, _ptr(co), _ptr(mo), _ptr(go), None,
+                                                       C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert bool((co == -3.0).all()) and bool((mo == -3.0).all()) and bool((go == -3).all())
+        # launches already enqueued for the following rounds see an empty round: zero sums, nothing read past the buffers
+        X, t = hip_ops.blocksum_geo(spec, hip_ops.pack(spec, hip_ops.to_device(_rand(64, d, 4)),
+                                                       hip_ops.to_device(torch.zeros(d, dtype=torch.float64)), 0, pad_rows_to=64),
+                                    64, co, mo, None, geo[1], 3, S, 2)
+        assert float(X.abs().max()) == 0.0 and float(t.abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("d", [1, 10, 26, 27, 38])
