@@ -159,6 +159,24 @@ class Batch:
     # ------------------------------------------------------------------------------------------------
     def steps(self):
         """-> ``(idx int64[<=num_pts] ascending, w float64)`` on the ops device (identical on every rank)."""
+        try:
+            return (yield from self._steps())
+        finally:
+            self._release()
+
+    def _release(self):
+        """Drop every reference the batch holds (the strategy object points back at the batch: without this the cycle
+        keeps hundreds of MB of device buffers alive until Python's cycle collector runs, and the next batch allocates
+        afresh instead of reusing them)."""
+        sums = self.__dict__.get("sums")
+        if sums is not None:
+            sums.b = None
+        keep = ("notes", "plan")
+        for k in list(self.__dict__):
+            if k not in keep:
+                self.__dict__[k] = None
+
+    def _steps(self):
         ops = self.ops
         if self.n_total == 0:                                   # empty pool: nothing to select (the reference returns [])
             dev = getattr(ops, "device", "cpu")
@@ -530,7 +548,8 @@ class Batch:
             if comm.rank == 0 or replicate:
                 XcarT, tot = ops.finalize(parts, parts.shape[0], parts.shape[1], q, S_r, self.diagU, m, min(m, S_r),
                                           self.diag_noise, self.wrow, tail_row, n_tail_diag)
-                PhiT = yield from self._nullspace(XcarT, s, M)
+                with _Timer(ops, trace, "nullspace"):
+                    PhiT = yield from self._nullspace(XcarT, s, M)   # :140-143 (rows = null-space vectors)
                 with _Timer(ops, trace, "eliminate"):
                     keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, tot.clone(), M, s)
             Mn = None
@@ -604,13 +623,18 @@ class Batch:
             self.R_lo = min((self.R_lo // S_r) * s, self.R)
             self._trace_phase("compact", t0)
 
+    def _gpu_nullspace(self, M):
+        return cfg.GPU_NULLSPACE and M <= getattr(self.ops, "NULLSPACE_MAX_M", 1 << 30)
+
     def _nullspace(self, XcarT, s, M):
         """Rows s..M-1 of the full ``Vh`` of ``svd(XcarT)`` (:140-143; rows = null-space vectors)."""
+        if self._gpu_nullspace(M):
+            return self.ops.nullspace(XcarT, s, M)
+        return (yield from self._host_nullspace(XcarT, s, M))
+
+    def _host_nullspace(self, XcarT, s, M):
+        """The same rows from a full SVD on host LAPACK (``GPU_NULLSPACE = False``, or M beyond the kernels' limit)."""
         ops, trace = self.ops, self.trace
-        use_gpu = cfg.GPU_NULLSPACE and M <= getattr(ops, "NULLSPACE_MAX_M", 1 << 30)
-        if use_gpu:
-            with _Timer(ops, trace, "nullspace"):
-                return ops.nullspace(XcarT, s, M)
         if cfg.GPU_NULLSPACE and not getattr(self, "_warned_big_m", False):
             self._warned_big_m = True
             self.notes.append(f"2 * num_pts = {M} exceeds the GPU null-space kernels' limit "

@@ -18,7 +18,7 @@ BASQ_OK = 0
 FAMILY = {"rbf": 0, "matern52": 1, "matern32": 2}
 ROLE_A, ROLE_B = 0, 1
 MAX_DIM = 38
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class KernelSpecC(C.Structure):

@@ -10,8 +10,12 @@ Rank 0 prints ONE JSON line.
               n=100, m=N/100=1e4, synthetic Gaussian-mixture pool (``basq_amd.pools.gmm_pool``), float64;
 * residency = the pool is on the GPU(s) before the clock starts (the reference's boundary hands over torch
               tensors; H2D of the pool is reported separately in DESIGN.md, never in ``value``);
-* N > 1     = the SAME batch with the pool sharded over the ranks (strong scaling; one small all-gather +
-              broadcast per round);
+* N > 1     = the SAME batch with the pool sharded over the ranks (strong scaling; one small all-gather per round,
+              stream-ordered: no host wait per round on any rank count);
+* value     = steps one after the other (each call returns before the next starts: the reference's synchronous call);
+              ``value_concurrent2`` (``concurrent`` object) = the same K steps with TWO independent batches in flight
+              (``basq_amd.recombination_many``: the reference's own pair, selection + quadrature, ``BASQ/_basq.py:82-88,
+              104-106``), results bit-identical to the sequential runs; multi-GPU lines add ``value_concurrent4``;
 * roofline  = the dominant kernel (``blocksum_kernel``): algorithmic flops = pairs * (3d + 3)
               (SURVEY §8d) over its HIP-event time on the launch stream, against the fp64 vector peak;
 * cpu_baseline = the oracle (= the reference's CPU op sequence) on this host's cores, bounded sample.
@@ -55,6 +59,9 @@ def parse():
     ap.add_argument("--cpu-stride", type=int, default=0, help="run every k-th hot-loop block on the CPU (0 = auto)")
     ap.add_argument("--cpu-threads", type=str, default="", help="comma list of CPU thread counts (default: 8 and all cores)")
     ap.add_argument("--breakdown", action="store_true", help="print a per-phase host timer breakdown to stderr")
+    ap.add_argument("--no-roofline-batch", action="store_true", help="skip the traced batch, the per-seed latencies and the "
+                    "pipelined runs (counter passes: tools/gpu_jobs.sh pmc)")
+    ap.add_argument("--no-concurrent", action="store_true", help="skip the runs with several batches in flight")
     return ap.parse_args()
 
 
@@ -128,17 +135,51 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    # ---- several batches in flight (outside the timed region of `value`): the same K steps through recombination_many ----
+    concurrent = {}
+    if not (args.no_concurrent or args.no_roofline_batch):
+        for k_fl in ([2] if world == 1 and not force_dist else [2, 4]):
+            calls, seeds = [], [1] * args.steps
+            for k in range(args.steps):
+                pts_nys, pts_local = pools_dev[k % len(pools_dev)]
+                calls.append((pts_local, pts_nys, n, kern) if (world == 1 and not force_dist)
+                             else (pts_local, off, N, pts_nys, n, kern))
+
+            def many():
+                if world == 1 and not force_dist:
+                    return basq_amd.recombination_many(calls, dev, in_flight=k_fl, seeds=seeds)
+                return basq_amd.recombination_many_sharded(calls, dev, in_flight=k_fl, seeds=seeds)
+
+            many()                                                   # warm-up: the slots' streams, buffers, workspaces
+            barrier()
+            t1 = time.perf_counter()
+            res_c = many()
+            barrier()
+            dtc = time.perf_counter() - t1
+            if dist is not None:
+                tt = torch.tensor([dtc], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dtc = float(tt.item())
+            # every pipelined result against the sequential run of the same step (same pool, same seed): bit for bit
+            same = True
+            for k in range(min(args.steps, len(pools_dev))):
+                i1, w1 = one_batch(k=k)
+                same = same and torch.equal(i1, res_c[k][0]) and torch.equal(w1, res_c[k][1])
+            concurrent[k_fl] = dict(in_flight=k_fl, value=args.steps / dtc, unit="batches/s", steps=args.steps,
+                                    ms_per_step=1e3 * dtc / args.steps, bit_identical_to_sequential=bool(same))
+
     # ---- per-seed latencies (outside the timed region): one synchronised batch per pool seed, median reported ----
     per_seed_ms = []
-    for k in range(len(POOL_SEEDS)):
+    for k in range(0 if args.no_roofline_batch else len(POOL_SEEDS)):
         barrier()
         t1 = time.perf_counter()
         one_batch(k=k)
         barrier()
         per_seed_ms.append(1e3 * (time.perf_counter() - t1))
 
-    # ---- kernel-level roofline: one extra traced batch (HIP events on the launch stream, no host syncs) ----
-    tr = basq_amd.EngineTrace(time_kernels=True, host_sync=False)
+    # ---- kernel-level roofline: one extra traced batch (HIP events on the launch stream, no host syncs: the batch stays on
+    #      the code path the timed steps take -- descriptor-driven rounds -- and reports its launches after the fact) ----
+    tr = basq_amd.EngineTrace(time_kernels=not args.no_roofline_batch, host_sync=False)
     one_batch(tr)
     torch.cuda.synchronize()
     k_ms = sum(a.elapsed_time(b) for a, b, _ in tr.kernel_events)
@@ -151,18 +192,17 @@ def main():
     bytes_alg = sum(info["R"] * (8 * d + 16) + 8 * info["m"] * d for _, _, info in tr.kernel_events)
     achieved_tf = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
 
-    # HBM bytes of the largest block-sum launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-    # WRITE_SIZE in separate runs, KiB units; 8-B-per-lane loads, so the gfx950 16-B half-count does not apply)
-    traffic, traffic_src, pipe_busy = None, None, None
-    pmc = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    if os.path.exists(pmc) and N == WORKLOAD["N"] and d == WORKLOAD["d"] and world == 1:
-        with open(pmc) as f:
-            rec = json.load(f)
-        traffic, traffic_src = rec["bytes_per_launch"], rec["source"]
-        try:                                                         # (4 INSTS_VALU + MFMA_BUSY) / SIMD-cycles, same passes
-            pipe_busy = float(rec["pipe"]["fp64_pipe_busy"].rsplit("=", 1)[1])
-        except (KeyError, ValueError, IndexError):
-            pipe_busy = None
+    # Hardware counters of the block-sum launches of one batch: rocprofv3 --pmc passes of THIS bench command (one counter
+    # group per pass, tools/gpu_jobs.sh pmc -> tools/pmc_summary.py), committed with the commit they were taken on.
+    # FETCH_SIZE / WRITE_SIZE in KiB; the kernel's loads are 8 B per lane (not the 16-B-per-lane streams whose gfx950
+    # half-count the micro-architecture guide describes): calibrated in the file against the launch's compulsory bytes.
+    pmc_rec = None
+    for name in ("r03_pmc.json",):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path) and N == WORKLOAD["N"] and d == WORKLOAD["d"] and world == 1:
+            with open(path) as f:
+                pmc_rec = json.load(f)
+            break
 
     if args.breakdown:
         tb = basq_amd.EngineTrace(time_kernels=False, host_sync=True)
@@ -179,7 +219,9 @@ def main():
         # SURVEY §8d matrix: {float64, float32} x {8 threads, all host cores}; ~5 s of CPU work per cell at N=1e6
         stride = args.cpu_stride or max(1, N // 25_000)
         ncpu = os.cpu_count() or 1
-        threads = [int(t) for t in args.cpu_threads.split(",") if t] or sorted({min(8, ncpu), ncpu})
+        # 8 threads (comparable with SURVEY's probe) and 32 (the largest team that still helps: beyond it the 200-column
+        # blocks of the hot loop thrash -- profiles/r02_cpu_full_batch.txt); never more than the host has
+        threads = [int(t) for t in args.cpu_threads.split(",") if t] or sorted({min(8, ncpu), min(32, ncpu)})
         cells = baseline_matrix(pool, pool[:m], n, StationaryOracle(WORKLOAD["family"], WORKLOAD["lengthscale"],
                                                                     WORKLOAD["outputscale"]), stride, seed=1,
                                 thread_counts=threads)
@@ -211,7 +253,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
-            "median_ms_per_seed": sorted(per_seed_ms)[len(per_seed_ms) // 2],
+            "median_ms_per_seed": sorted(per_seed_ms)[len(per_seed_ms) // 2] if per_seed_ms else None,
             "ms_per_seed": [round(v, 3) for v in per_seed_ms],
             "higher_is_better": True,
             "scaling": "strong",
@@ -221,16 +263,15 @@ def main():
             "config": {"workload": f"RBF kernel l=2, N={N} candidates, d={d}, n={n} recombination, m={m} Nystrom points, "
                                    f"float64, pool sharded over {world} GPU(s); pool seeds {list(POOL_SEEDS)} cycled over steps",
                        "N": N, "d": d, "n": n, "m": m, "kernel": "rbf", "parallelism": f"pool-sharded x{world}"},
+            "value_concurrent2": concurrent[2]["value"] if 2 in concurrent else None,
+            "value_concurrent4": concurrent[4]["value"] if 4 in concurrent else None,
+            "concurrent": [concurrent[k] for k in sorted(concurrent)] or None,
             "roofline": {
-                # contract vocabulary is hbm|mfma: this kernel is bound by the fp64 PIPE, which f64 MFMA and fp64 VALU share
-                # on gfx950 (roughly half of its busy cycles are MFMA, half the VALU exp epilogue) -- neither HBM nor a
-                # GEMM-shaped MFMA bound; "bound_detail" says so.
-                "bound": "mfma", "bound_detail": "fp64 pipe: on gfx950 the f64 matrix instructions (either form) and the fp64 "
-                                                   "VALU share ONE pipe of 16 lanes x 1 op per cycle per SIMD "
-                                                   "(profiles/r02_l_microbench_mfma_f64_4x4x4.txt: v_mfma_f64_4x4x4 runs at "
-                                                   "that rate, 75.7 TF/s; 16x16x4 at 47.4; interleaved with v_fma_f64 the times "
-                                                   "add).  Per pair: KP lane-FMAs for the exponent argument on the matrix "
-                                                   "instruction + ~13 VALU lane-ops for the table exponential; not HBM",
+                # The contract's vocabulary is hbm | mfma.  On gfx950 the f64 matrix instructions and the fp64 VALU share ONE
+                # pipe per SIMD (16 lanes x 1 op per cycle; profiles/r02_l_microbench_mfma_f64_4x4x4.txt), and this kernel
+                # keeps it busy with both -- KP lane-FMAs per pair for the exponent argument on the matrix instruction, ~13
+                # VALU lane-ops for the table exponential -- so "mfma" stands for that pipe; HBM is three orders below.
+                "bound": "mfma",
                 "kernel": "blocksum_kernel (fused pairwise-kernel block sums, BASQ/_rchq.py:79-99; MFMA distances + VALU exp)",
                 "achieved": achieved_tf, "peak": PEAK_FP64_VECTOR_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tf / PEAK_FP64_VECTOR_TFLOPS,
@@ -238,10 +279,14 @@ def main():
                 "frac_of_measured_peak": achieved_tf / MEASURED_FP64_TFLOPS["mixed_fma_mfma"],
                 "peak_measured_source": "profiles/r02_microbench_fp64_rates.txt (fma-only 72.9, mfma-only 47.2, both "
                                         "interleaved 63.1 TF/s: the figure that applies to this kernel's instruction mix)",
-                "traffic": traffic,
-                "traffic_source": ("committed PMC pass, not measured in this run: " + traffic_src) if traffic_src else None,
-                "fp64_pipe_busy_pmc": pipe_busy,
-                "fp64_pipe_busy_source": "committed PMC pass (same file), not measured in this run" if pipe_busy else None,
+                # counters (rocprofv3 --pmc passes over this command, per BATCH = all block-sum launches of one batch)
+                "traffic": pmc_rec["hbm_bytes_per_batch"] if pmc_rec else None,
+                "hbm_GBs_counter": (pmc_rec["hbm_bytes_per_batch"] / (k_ms * 1e-3) / 1e9) if (pmc_rec and k_ms > 0) else None,
+                "hbm_frac": (pmc_rec["hbm_bytes_per_batch"] / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if (pmc_rec and k_ms > 0) else None,
+                "mfma_util": pmc_rec.get("mfma_util") if pmc_rec else None,
+                "fp64_pipe_busy_pmc": pmc_rec.get("fp64_pipe_busy") if pmc_rec else None,
+                "counters_source": (f"profiles/r03_pmc.json (commit {pmc_rec.get('commit')}, {pmc_rec.get('source')}); bytes per "
+                                    "batch from the counters, time from this run's HIP events") if pmc_rec else None,
                 "launches_per_batch": k_launches, "kernel_ms_per_batch": k_ms, "pairs_per_batch": k_pairs,
                 "reference_pairs_per_batch": ref_pairs,
                 "whole_batch_TFLOPs_by_reference_count": ref_pairs * (3 * d + 3) / (dt / args.steps) / 1e12,
@@ -253,9 +298,8 @@ def main():
                 / (k_ms * 1e-3) if k_ms > 0 else None,
                 "hbm_algorithmic_GBs": bytes_alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
                 "hbm_peak_GBs": PEAK_HBM_GBS,
-                "note": "compute-bound on the fp64 pipe (SURVEY 8d): 33 flop per pair by SURVEY's count (3d + 3); the kernel "
-                        "executes ~25 fp64 lane operations per pair on the one fp64 pipe; launch durations by HIP events on "
-                        "the launch stream over one traced batch, rank 0; traffic / pipe occupancy: committed PMC passes",
+                "note": "33 flop per pair by SURVEY's count (3d + 3); launch durations by HIP events on the launch stream over "
+                        "one traced batch that takes the timed code path (descriptor-driven rounds), rank 0",
             },
             "cpu_baseline": cpu,
             "result_digest": {"n_selected": int(idx.numel()), "w_sum": float(w.sum().item())},

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BASQ_ABI_VERSION 8
+#define BASQ_ABI_VERSION 9
 
 /* error codes */
 #define BASQ_OK            0
