@@ -39,7 +39,8 @@ from dataclasses import dataclass
 import torch
 
 from . import _config as cfg
-from ._basis import _lapack_threads, _ShardedProducts, _skip_test_matrix_draw, _Timer, make_cov_psd, nystrom_basis_steps
+from ._basis import (_lapack_threads, _mm_splitk, _ShardedProducts, _skip_test_matrix_draw, _Timer, make_cov_psd,
+                     nystrom_basis_steps)
 from ._lib import ROLE_A, ROLE_B
 from ._partition import (RoundGeometry, choose_chunks, initial_shards, local_blocks, next_shard, survivors_before)
 
@@ -146,13 +147,23 @@ class Batch:
         if n_total >= 2 ** 31:
             raise ValueError("pool sizes >= 2^31 are not supported")
         self.ops, self.comm, self.trace = ops, comm, trace
+        self.notes = []                                  # conditions the caller should know about (-> warnings)
+        d = int(pts_nys.shape[1]) if pts_nys.dim() == 2 else 0
+        if not getattr(kernel, "opaque", False) and not kernel.base.fits_packed_rows(d):
+            # envelope: the fused kernels pack a point into <= 40 doubles (d <= 38).  The reference accepts any d
+            # (_rchq.py:4-25), so wider points degrade to the dense path -- the structured kernel, which is a callable with
+            # the reference's semantics, evaluated block by block like any other callable -- instead of raising
+            from .kernels import CallableKernel
+
+            self.notes.append(f"dimension {d} exceeds the fused kernels' packed-row limit ({kernel.base.__class__.__name__}: "
+                              "d <= 38); the kernel is evaluated densely on the device (basq_dense_blocksum_f64 path)")
+            kernel = CallableKernel(kernel)
         self.kernel, self.variant = kernel, variant
         self.pts_local_in, self.pts_nys_in = pts_local, pts_nys
         self.gid0, self.n_total, self.num_pts = int(gid0), int(n_total), int(num_pts)
         self.init_weights, self.objective = init_weights, objective
         self.pipelined = pipelined
         self.plan = Plan.of(kernel, variant, objective, comm, ops, trace)
-        self.notes = []                                  # conditions the caller should know about (-> warnings)
 
     # ------------------------------------------------------------------------------------------------
     # the step generator
@@ -356,8 +367,9 @@ class Batch:
         self.bmatT = None
         if self.post is not None:
             W = ops.to_device(self.post.W, torch.float64)
-            Bmat = self.base.dense(ops, self.pts_nys, self.Xo, self.center) @ W      # [m, n_obs] (small library GEMM, once per batch)
-            U_cols.append(-(Um @ Bmat))
+            # [m, n_obs] and [q, n_obs], once per batch, on the own tall-skinny kernel (n_obs <= 208; wider: library GEMM)
+            Bmat = _mm_splitk(ops, self.base.dense(ops, self.pts_nys, self.Xo, self.center), W, 1)
+            U_cols.append(-_mm_splitk(ops, Um, Bmat, 8))
             if plan.warp == "wsabim":
                 # B^T, zero-padded to whole MFMA fragments: the A operand of the fused squared-covariance block sums
                 self.bmatT = ops.zeros(((self.n_obs + 3) // 4) * 4, ((m + 63) // 64) * 64)
@@ -517,13 +529,19 @@ class Batch:
             S_r = R if final else S
             geo = RoundGeometry.of(R, S_r)
             t0 = time.perf_counter()
-            msg, Mc, C_cur, reg_blocks = self.sums.message(geo, S_r, final, pre)
+            retry = getattr(self, "_retry_msg", None)
+            if retry is not None:                                # same round again (cluster time-out): reuse its message
+                msg, Mc, C_cur, reg_blocks = retry
+                self._retry_msg = None
+            else:
+                msg, Mc, C_cur, reg_blocks = self.sums.message(geo, S_r, final, pre)
+                if plan.warp == "wsabim":
+                    # + U @ (0.5 sum mu cov^2): the one term of wsabim_kernel that is not linear in the block sums
+                    with _Timer(ops, trace, "wsabim_sq"):
+                        msg[1:q + 1] += _mm_splitk(ops, self.U, self.sums.wsabim_square_term(geo, S_r), 8)
+            msg0 = (msg, Mc, C_cur, reg_blocks)
             pre = None
             self.cls = None
-            if plan.warp == "wsabim":
-                # + U @ (0.5 sum mu cov^2): the one term of wsabim_kernel that is not linear in the block sums
-                with _Timer(ops, trace, "wsabim_sq"):
-                    msg[1:q + 1] += ops.matmul(self.U, self.sums.wsabim_square_term(geo, S_r))
             tail_row, n_tail_diag = 0, 0
             if self.diag_noise != 0.0 and not final and geo.n_tail > 0:
                 # the ragged tail is a kernel block of its own (:91-99): predictive_covariance adds the noise to ITS
@@ -545,13 +563,13 @@ class Batch:
             M = S_r
             replicate = cfg.REPLICATED_REDUCTION and comm.world > 1
             XcarT = None
+            cluster = not getattr(self, "_no_cluster", False)
             if comm.rank == 0 or replicate:
                 XcarT, tot = ops.finalize(parts, parts.shape[0], parts.shape[1], q, S_r, self.diagU, m, min(m, S_r),
                                           self.diag_noise, self.wrow, tail_row, n_tail_diag)
-                with _Timer(ops, trace, "nullspace"):
-                    PhiT = yield from self._nullspace(XcarT, s, M)   # :140-143 (rows = null-space vectors)
+                PhiT = yield from self._nullspace(XcarT, s, M, cluster)      # :140-143 (rows = null-space vectors)
                 with _Timer(ops, trace, "eliminate"):
-                    keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, tot.clone(), M, s)
+                    keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, tot.clone(), M, s, cluster)
             Mn = None
             if Mc is not None and C_cur >= 2 and not final and (comm.world == 1 or replicate):
                 # Enqueued BEFORE the host waits for this round's outcome: if exactly half of the sets survive (checked
@@ -585,8 +603,16 @@ class Batch:
                 n_keep, status = hl[0], hl[1]
                 kept_list = hl[2:2 + n_keep]
             if status == 2:
-                raise ReductionTimeout("a cluster reduction kernel timed out waiting for its sibling work-groups (the GPU "
-                                       "is shared with work that keeps them from being co-resident)")
+                # a 4-work-group cluster kernel gave up waiting for its siblings (they must be co-resident; a GPU shared
+                # with other work may not grant that within the spin limit): nothing of this round has been applied yet --
+                # redo its reduction, and every later one of the batch, on the single-work-group kernels
+                if not cluster:
+                    raise ReductionTimeout("a reduction kernel reported a time-out on the single-work-group path")
+                self._no_cluster = True
+                self.notes.append("a cluster reduction kernel timed out waiting for its sibling work-groups (GPU shared with "
+                                  "other work?); the batch continued on the single-work-group kernels")
+                self._retry_msg = msg0
+                continue
             if status != 0 and not plan.sober:
                 raise RuntimeError("Caratheodory elimination: a null vector has no positive entry "
                                    "(the reference fails here too: argmin of an empty tensor, _rchq.py:152)")
@@ -626,10 +652,11 @@ class Batch:
     def _gpu_nullspace(self, M):
         return cfg.GPU_NULLSPACE and M <= getattr(self.ops, "NULLSPACE_MAX_M", 1 << 30)
 
-    def _nullspace(self, XcarT, s, M):
+    def _nullspace(self, XcarT, s, M, cluster=True):
         """Rows s..M-1 of the full ``Vh`` of ``svd(XcarT)`` (:140-143; rows = null-space vectors)."""
         if self._gpu_nullspace(M):
-            return self.ops.nullspace(XcarT, s, M)
+            with _Timer(self.ops, self.trace, "nullspace"):
+                return self.ops.nullspace(XcarT, s, M, cluster)
         return (yield from self._host_nullspace(XcarT, s, M))
 
     def _host_nullspace(self, XcarT, s, M):

@@ -18,7 +18,7 @@ BASQ_OK = 0
 FAMILY = {"rbf": 0, "matern52": 1, "matern32": 2}
 ROLE_A, ROLE_B = 0, 1
 MAX_DIM = 38
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class KernelSpecC(C.Structure):
@@ -44,7 +44,7 @@ SIGNATURES = {
     "basq_project_chunks_f64": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _f64, _i32, _vp, _vp, _vp]),
     "basq_sum_parts_f64": (C.c_int, [_vp, _i32, _i64, _vp, _vp]),
     "basq_finalize_f64": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _f64, _i32, _i32, _i32, _vp, _vp, _vp]),
-    "basq_nullspace_f64": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "basq_nullspace_f64": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "basq_reduction_ws_doubles": (C.c_int64, [_i32, _i32]),
     "basq_car_eliminate_f64": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "basq_reweight_compact_f64": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _i32,

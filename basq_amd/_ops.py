@@ -222,14 +222,22 @@ class HipOps:
               "basq_tail_weights_geo_f64")
         return out
 
-    def nullspace(self, XcarT, s, M):
-        """Rows s..M-1 of the full ``Vh`` of ``svd(XcarT [s, M])`` (``_rchq.py:140-143``) -> PhiT [M-s, M]."""
+    def nullspace(self, XcarT, s, M, cluster=True):
+        """Rows s..M-1 of the full ``Vh`` of ``svd(XcarT [s, M])`` (``_rchq.py:140-143``) -> PhiT [M-s, M].
+
+        Shapes that need the 4-work-group cluster kernels (M > 256) attach ``PhiT.ns_info`` (device int32[1]: 2 = a
+        cluster spin timed out), which ``car_eliminate`` folds into its status word; ``cluster=False`` selects the
+        single-work-group kernels (the retry path after such a time-out)."""
         self._chk(XcarT)
         V = self.empty(s, M)
         tau = self.empty(s)
         PhiT = self.empty(M - s, M)
-        check(self.lib.basq_nullspace_f64(_ptr(XcarT), s, M, _ptr(V), _ptr(tau), _ptr(PhiT),
-                                          _ptr(self._reduction_ws(s, M)), self._stream()), "basq_nullspace_f64")
+        ws = self._reduction_ws(s, M) if cluster else None
+        info = self.empty(1, dtype=torch.int32) if ws is not None else None
+        check(self.lib.basq_nullspace_f64(_ptr(XcarT), s, M, _ptr(V), _ptr(tau), _ptr(PhiT), _ptr(ws), _ptr(info),
+                                          self._stream()), "basq_nullspace_f64")
+        if info is not None:
+            PhiT.ns_info = info
         return PhiT
 
     def _reduction_ws(self, s, M):
@@ -243,18 +251,58 @@ class HipOps:
             buf = cache[n] = self.zeros(n)
         return buf
 
-    def car_eliminate(self, PhiT, mu, M, s):
-        """In place on PhiT/mu.  -> (keep_rank[M] i32, kept[s] i32, w_star[s] f64, info[2] i32)."""
+    def car_eliminate(self, PhiT, mu, M, s, cluster=True):
+        """In place on PhiT/mu.  -> (keep_rank[M] i32, kept[s] i32, w_star[s] f64, info[2] i32 = [n_keep, status]);
+        status 0 ok, 1 = a null vector without a positive entry, 2 = a cluster kernel (this one or the null space's) timed
+        out waiting for its sibling work-groups."""
         self._chk(PhiT)
         self._chk(mu)
+        if M > self.NULLSPACE_MAX_M:
+            return self._car_eliminate_wide(PhiT, mu, M, s)
         keep_rank = self.empty(M, dtype=torch.int32)
         ik = self.empty(2 + M, dtype=torch.int32)              # [info(2) | kept(<=M)]  (<= s unless the elimination
         info, kept = ik[:2], ik[2:]                             #  stopped early, status 1)
         info.ik_buffer = ik                                     # (info_kept_buffer: one D2H for both)
         w_star = self.empty(M)
         check(self.lib.basq_car_eliminate_f64(_ptr(PhiT), _ptr(mu), M, s, _ptr(keep_rank), _ptr(kept), _ptr(w_star),
-                                              _ptr(info), _ptr(self._reduction_ws(s, M)), self._stream()),
-              "basq_car_eliminate_f64")
+                                              _ptr(info), _ptr(self._reduction_ws(s, M) if cluster else None),
+                                              self._stream()), "basq_car_eliminate_f64")
+        ns_info = getattr(PhiT, "ns_info", None)
+        if ns_info is not None:                                 # a timed-out null space must not pass as status 1
+            torch.maximum(info[1:2], ns_info, out=info[1:2])
+        return keep_rank, kept, w_star, info
+
+    def _car_eliminate_wide(self, PhiT, mu, M, s):
+        """``basq_car_eliminate_f64``'s contract for M = 2 * num_pts > 1024, beyond the kernels' one-thread-per-set layout:
+        the steps of ``BASQ/_rchq.py:146-171`` as device tensor operations in the reference's own order (one small launch
+        per operation, ~10 per step: the envelope path, an order of magnitude slower than the kernel)."""
+        Phi = PhiT.t().contiguous()                             # [M, M - s], columns = null vectors
+        status = 0
+        for _ in range(M - s):
+            col = Phi[:, 0]
+            pos = col > 0
+            if not bool(pos.any()):                             # :152 would raise (argmin of an empty tensor)
+                status = 1
+                break
+            alpha = torch.where(pos, mu / col, torch.full_like(mu, float("inf")))
+            j = torch.argmin(alpha)
+            mu = mu - alpha[j] * col                            # :156
+            mu[j] = 0.0
+            cj = col[j]
+            Phi = Phi[:, 1:] - torch.outer(col, Phi[j, 1:]) / cj      # :165-167 (outer product, then the division)
+            Phi[j, :] = 0.0
+        keep = mu > 0
+        n_keep = int(keep.sum())
+        idx = torch.nonzero(keep).reshape(-1).to(torch.int32)
+        keep_rank = torch.full((M,), -1, dtype=torch.int32, device=self.device)
+        keep_rank[idx.long()] = torch.arange(n_keep, dtype=torch.int32, device=self.device)
+        ik = torch.zeros(2 + M, dtype=torch.int32, device=self.device)
+        ik[0], ik[1] = n_keep, status
+        ik[2:2 + n_keep] = idx
+        w_star = self.zeros(M)
+        w_star[:n_keep] = mu[keep]
+        info, kept = ik[:2], ik[2:]
+        info.ik_buffer = ik
         return keep_rank, kept, w_star, info
 
     @staticmethod

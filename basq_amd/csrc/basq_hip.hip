@@ -2311,7 +2311,7 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
 template <int NV, int NR, int NCU>
 __global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const double* __restrict__ X, int m, int n,
                                                              double* __restrict__ V, double* __restrict__ tau_g,
-                                                             double* ws, int cluster_stride) {
+                                                             double* ws, int cluster_stride, int* __restrict__ info_g) {
     static_assert(NV % 2 == 0, "lanes own column pairs");
     constexpr int WPG = BASQ_WPG, W = WPG * NCU, NC = NV * 64, NG = (NR + 3) / 4, MSG = NC + 8;
     constexpr bool GLOBAL = NCU > 1;
@@ -2548,7 +2548,10 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const dou
         }
         BASQ_NS_STAMP(t + 1, 3);
     }
-    if (aborted && gw == 0 && lane == 0) tau_g[0] = __builtin_nan("");   // poisons the null space: the caller's elimination fails loudly
+    if (aborted && gw == 0 && lane == 0) {
+        tau_g[0] = __builtin_nan("");   // poisons the null space: an elimination that ignores `info` still fails loudly
+        if (info_g) info_g[0] = 2;      // status 2: a bounded spin expired (sibling work-groups not co-resident)
+    }
 }
 
 template <int NV>
@@ -3770,19 +3773,20 @@ int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32
 #define BASQ_NS_CLUSTER 1       // 1: cluster kernels where one CU cannot hold the matrix (M > 256); 2: also for the one-CU
 #endif                          // shapes (A/B: measured 336 vs 286 us at 100 x 200 -- the 16-wave kernel stays); 0: never
 int basq_nullspace_f64(const double* X, int32_t s, int32_t M, double* V, double* tau, double* PhiT, double* ws,
-                       void* stream) {
+                       int32_t* info, void* stream) {
     if (!X || !V || !tau || !PhiT || s < 1 || M <= s || M > 1024) return BASQ_EINVAL;
     hipStream_t st = (hipStream_t)stream;
+    if (info && hipMemsetAsync(info, 0, sizeof(int32_t), st) != hipSuccess) return BASQ_ELAUNCH;
     const size_t LDS_MAX = 163840 - 64;                         // per-CU LDS minus the kernel's static scalar
     int rc;
     constexpr int T = BASQ_WPG * 64;
     if (BASQ_NS_CLUSTER == 2 && M <= 256 && s <= BASQ_WPG * 14) {   // one CU, 8 waves (A/B builds)
-        if (s <= BASQ_WPG * 4) hipLaunchKernelGGL((bidiag_cluster_kernel<4, 4, 1>), dim3(1), dim3(T), 0, st, X, s, M, V, tau, (double*)nullptr, 1);
-        else hipLaunchKernelGGL((bidiag_cluster_kernel<4, 14, 1>), dim3(1), dim3(T), 0, st, X, s, M, V, tau, (double*)nullptr, 1);
+        if (s <= BASQ_WPG * 4) hipLaunchKernelGGL((bidiag_cluster_kernel<4, 4, 1>), dim3(1), dim3(T), 0, st, X, s, M, V, tau, (double*)nullptr, 1, info);
+        else hipLaunchKernelGGL((bidiag_cluster_kernel<4, 14, 1>), dim3(1), dim3(T), 0, st, X, s, M, V, tau, (double*)nullptr, 1, info);
         rc = (hipGetLastError() == hipSuccess) ? BASQ_OK : BASQ_ELAUNCH;
     } else if (BASQ_NS_CLUSTER && !(M <= 256 && s <= 112) && M <= 512 && s <= 4 * BASQ_WPG * 8 && ws) {   // 4-CU cluster
         if (hipMemsetAsync(ws, 0, 16 * sizeof(double), st) != hipSuccess) return BASQ_ELAUNCH;
-        hipLaunchKernelGGL((bidiag_cluster_kernel<8, 8, 4>), dim3(4 * 8), dim3(T), 0, st, X, s, M, V, tau, ws, 8);
+        hipLaunchKernelGGL((bidiag_cluster_kernel<8, 8, 4>), dim3(4 * 8), dim3(T), 0, st, X, s, M, V, tau, ws, 8, info);
         rc = (hipGetLastError() == hipSuccess) ? BASQ_OK : BASQ_ELAUNCH;
     } else if (M <= 256 && s <= 112) {                          // whole matrix in registers (16 waves)
         if (s <= 32) hipLaunchKernelGGL((bidiag_reflectors_reg_kernel<4, 2>), dim3(1), dim3(1024), 0, st, X, s, M, V, tau);

@@ -48,6 +48,14 @@ def _ops_for(x):
     return HipOps(x.device)
 
 
+def _mm(ops, A, B):
+    """``A @ B`` on the library's own f64 MFMA GEMM (``basq_gemm_f64``) where the ops object has one."""
+    g = getattr(ops, "gemm", None)
+    if g is None or A.dtype != torch.float64 or B.dtype != torch.float64 or A.dim() != 2 or B.dim() != 2:
+        return A @ B
+    return g(A.contiguous(), B.contiguous())
+
+
 class StationaryKernel:
     """``outputscale * base(|x - y| / lengthscale)``, base in {rbf, matern52, matern32}, shared lengthscale."""
 
@@ -65,15 +73,39 @@ class StationaryKernel:
             raise ValueError(f"dimension {d} outside 1..{MAX_DIM}")
         return KernelSpec(self.family, int(d), self.lengthscale, self.outputscale)
 
+    def fits_packed_rows(self, d: int) -> bool:
+        """The fused kernels hold a point as a packed row of at most 40 doubles (d <= 38); beyond that the kernel is
+        evaluated by device tensor ops (``_dense_wide``) and the recombination takes the dense path."""
+        return 1 <= d <= MAX_DIM
+
     def dense(self, ops, x, y, center=None, diag_offset=0):
         """``diag_offset``: ``x`` is rows ``diag_offset..`` of the first operand of a square block (the structured
         kernels add their diagonal terms on the TRUE diagonal then); no effect for a stationary kernel."""
-        spec = self.spec(x.shape[1])
         if center is None:
             center = ops.col_mean(x)          # gpytorch centres on the first operand
+        if not self.fits_packed_rows(x.shape[1]):
+            return self._dense_wide(x, y, center)
+        spec = self.spec(x.shape[1])
         pa = ops.pack(spec, x, center, ROLE_A)
         pb = ops.pack(spec, y, center, ROLE_B)
         return ops.gram(spec, pa, x.shape[0], pb, y.shape[0])
+
+    def _dense_wide(self, x, y, center):
+        """The same kernel values for d > 38, by tensor operations on the device (one GEMM for the scaled squared
+        distances of the centred points, as gpytorch forms them, then the family's closed form): the envelope path --
+        correct for any d, unfused (the [len(x), len(y)] matrix is materialised)."""
+        xs = (x - center) * (1.0 / self.lengthscale)
+        ys = (y - center) * (1.0 / self.lengthscale)
+        D = xs @ ys.T - 0.5 * (xs * xs).sum(1, keepdim=True) - 0.5 * (ys * ys).sum(1).unsqueeze(0)   # -|x - y|^2 / (2 l^2)
+        if self.family == "rbf":
+            return self.outputscale * torch.exp(D.clamp_max(0.0))
+        r2 = (-2.0 * D).clamp_min(1e-30)
+        r = r2.sqrt()
+        if self.family == "matern52":
+            a = (5.0 ** 0.5) * r
+            return self.outputscale * (((a + 1.0) + (5.0 / 3.0) * r2) * torch.exp(-a))
+        a = (3.0 ** 0.5) * r
+        return self.outputscale * ((a + 1.0) * torch.exp(-a))
 
     def __call__(self, x, y):
         x = x.to(torch.float64).contiguous()
@@ -112,7 +144,7 @@ class PosteriorKernel:
         cov = self.base.dense(ops, x, y, center)
         KxX = self.base.dense(ops, x, Xo, center)
         KXy = self.base.dense(ops, Xo, y, center)
-        cov = cov - KxX @ W @ KXy
+        cov = cov - _mm(ops, _mm(ops, KxX, W), KXy)
         k = min(x.shape[0], y.shape[0] - diag_offset)
         if k > 0:
             cov.diagonal(diag_offset)[:k] += self.noise       # _gp.py:275-276
@@ -127,11 +159,13 @@ class PosteriorKernel:
         """GP posterior mean ``predict(x, model)[0]`` (``BASQ/_gp.py:213-230``) through the HIP kernel mat-vec."""
         if self.mean_cache is None or self.mean_const is None:
             raise ValueError("PosteriorKernel was built without the GP mean (mean_const / mean_cache)")
-        spec = self.base.spec(x.shape[1])
         Xo = ops.to_device(self.Xobs, torch.float64)
         v = ops.to_device(self.mean_cache, torch.float64)
         if center is None:
             center = ops.col_mean(x)
+        if not self.base.fits_packed_rows(x.shape[1]):
+            return self.mean_const + self.base.dense(ops, x, Xo, center) @ v
+        spec = self.base.spec(x.shape[1])
         pa = ops.pack(spec, x, center, ROLE_A, pad_rows_to=64)
         pb = ops.pack(spec, Xo, center, ROLE_B)
         return ops.matvec(spec, pa, x.shape[0], pb, Xo.shape[0], v, self.mean_const)
@@ -143,7 +177,7 @@ class PosteriorKernel:
         if center is None:
             center = ops.col_mean(x)
         KxX = self.base.dense(ops, x, Xo, center)
-        return self.base.outputscale - ((KxX @ W) * KxX).sum(1) + self.noise
+        return self.base.outputscale - (_mm(ops, KxX, W) * KxX).sum(1) + self.noise
 
     def predict_mean(self, x):
         """``VanillaGP.predict_mean`` (``BASQ/_vbq.py:141-151``): the ``mean_predict`` of the quadrature."""
@@ -168,11 +202,13 @@ class WsabiKernel:
 
     def mean(self, ops, x, center=None):
         """``predict(x, model)[0]`` (``BASQ/_gp.py:213-230``) = const + k(x, Xobs) @ mean_cache, via the HIP mat-vec."""
-        spec = self.base.spec(x.shape[1])
         Xo = ops.to_device(self.posterior.Xobs, torch.float64)
         v = ops.to_device(self.mean_cache, torch.float64)
         if center is None:
             center = ops.col_mean(x)
+        if not self.base.fits_packed_rows(x.shape[1]):
+            return self.mean_const + self.base.dense(ops, x, Xo, center) @ v
+        spec = self.base.spec(x.shape[1])
         pa = ops.pack(spec, x, center, ROLE_A, pad_rows_to=64)
         pb = ops.pack(spec, Xo, center, ROLE_B)
         return ops.matvec(spec, pa, x.shape[0], pb, Xo.shape[0], v, self.mean_const)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BASQ_ABI_VERSION 9
+#define BASQ_ABI_VERSION 10
 
 /* error codes */
 #define BASQ_OK            0
@@ -182,9 +182,13 @@ int basq_finalize_f64(const double* parts, int32_t n_parts, int32_t msg_rows, in
  *     PhiT [M-s, M]  (rows = null vectors, what basq_car_eliminate_f64 consumes).
  * Scratch: V [s, M] (reflector vectors; also row storage when s*M exceeds the LDS), tau [s].
  * Agreement with the host LAPACK rows is at rounding level (~1e-13); 1 <= s < M <= 1024.
+ * info (optional, device int32[1]): 0, or 2 = a cluster work-group gave up waiting for its siblings (bounded spins:
+ * the four work-groups of a cluster must be co-resident, which a GPU shared with other work may not grant within the
+ * limit); PhiT is then poisoned with NaNs.  Passing ws = NULL selects the single-work-group kernels for every shape
+ * (slower for M > 256, no co-residency requirement): the caller's retry path.
  */
 int basq_nullspace_f64(const double* XcarT, int32_t s, int32_t M, double* V, double* tau, double* PhiT, double* ws,
-                       void* stream);
+                       int32_t* info, void* stream);
 
 /*
  * Workspace (in doubles) that basq_nullspace_f64 / basq_car_eliminate_f64 need in `ws` for an [s, M] reduction:

@@ -239,11 +239,11 @@ class CpuStandInOps:
         XcarT = torch.cat([torch.ones(1, S, dtype=torch.float64), feat / tot.unsqueeze(0)], 0)
         return XcarT, tot
 
-    def nullspace(self, XcarT, s, M):
+    def nullspace(self, XcarT, s, M, cluster=True):
         self._count("nullspace")
         return householder_nullspace(XcarT)
 
-    def car_eliminate(self, PhiT, mu, M, s):
+    def car_eliminate(self, PhiT, mu, M, s, cluster=True):
         self._count("car")
         Phi = PhiT.T.clone()                                   # [M, M-s]
         status = 0

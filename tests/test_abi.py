@@ -59,9 +59,9 @@ def test_argument_validation_without_gpu(lib_path):
     bad = _lib.KernelSpecC(7, 10, 2.0, 1.0)
     assert lib.basq_gram_f64(ctypes.byref(bad), None, 1, None, 1, None, 1, None) == -1
     assert lib.basq_car_eliminate_f64(None, None, 2000, 10, None, None, None, None, None, None) == -1
-    assert lib.basq_nullspace_f64(None, 10, 20, None, None, None, None, None) == -1
-    assert lib.basq_nullspace_f64(1, 20, 20, 1, 1, 1, None, None) == -1    # needs s < M (checked before any launch)
-    assert lib.basq_nullspace_f64(1, 10, 2000, 1, 1, 1, None, None) == -1  # M <= 1024
+    assert lib.basq_nullspace_f64(None, 10, 20, None, None, None, None, None, None) == -1
+    assert lib.basq_nullspace_f64(1, 20, 20, 1, 1, 1, None, None, None) == -1    # needs s < M (checked before any launch)
+    assert lib.basq_nullspace_f64(1, 10, 2000, 1, 1, 1, None, None, None) == -1  # M <= 1024
     assert lib.basq_reduction_ws_doubles(100, 200) == 0                    # one CU: no workspace
     assert lib.basq_reduction_ws_doubles(200, 400) > 0                     # 4-CU cluster: ring + flags
 

@@ -443,3 +443,34 @@ def test_exact_unit_plan_brute_force():
                 got.append((p, hi))
                 p = hi
         assert sorted(got) == units
+
+
+def test_cluster_timeout_is_retried_on_single_workgroup_kernels():
+    """status 2 (a 4-work-group cluster kernel's bounded spin expired) is not the reference's "no positive entry"
+    failure: the round is redone on the single-work-group kernels, the batch finishes with the same result, and the caller
+    is told (RuntimeWarning).  Descriptor-driven rounds hit the flag first and fall back to the round-by-round loop."""
+    from basq_amd.kernels import StationaryKernel
+    from basq_amd.pools import gmm_pool
+
+    N, d, n, m = 20_000, 3, 20, 150
+    pts = gmm_pool(N, d, 18)
+    kern = StationaryKernel("rbf", 1.5, 1.0)
+
+    class TimingOut(CpuStandInOps):
+        seen_cluster_false = 0
+
+        def car_eliminate(self, PhiT, mu, M, s, cluster=True):
+            out = super().car_eliminate(PhiT, mu, M, s, cluster)
+            if not cluster:
+                TimingOut.seen_cluster_false += 1
+            if cluster and self.calls["car"] % 2 == 0 and self.calls["car"] <= 12:   # time-outs in both kinds of rounds
+                out[3][1] = 2
+            return out
+
+    torch.manual_seed(2)
+    ia, wa = RecombinationEngine(CpuStandInOps()).run(pts, 0, N, pts[:m], n, kern)
+    torch.manual_seed(2)
+    with pytest.warns(RuntimeWarning, match="timed out"):
+        ib, wb = RecombinationEngine(TimingOut()).run(pts, 0, N, pts[:m], n, kern)
+    assert TimingOut.seen_cluster_false > 0
+    assert torch.equal(ia, ib) and torch.allclose(wa, wb, rtol=1e-11, atol=0)
