@@ -48,6 +48,12 @@ def _ops_for(x):
     return HipOps(x.device)
 
 
+def _col_mean(ops, x):
+    """Column means of ``x`` (gpytorch centres on the first operand): ``basq_col_mean_f64``, or a tensor reduction for
+    points wider than the library's packed rows."""
+    return ops.col_mean(x) if x.shape[1] <= MAX_DIM else x.mean(0)
+
+
 def _mm(ops, A, B):
     """``A @ B`` on the library's own f64 MFMA GEMM (``basq_gemm_f64``) where the ops object has one."""
     g = getattr(ops, "gemm", None)
@@ -82,7 +88,7 @@ class StationaryKernel:
         """``diag_offset``: ``x`` is rows ``diag_offset..`` of the first operand of a square block (the structured
         kernels add their diagonal terms on the TRUE diagonal then); no effect for a stationary kernel."""
         if center is None:
-            center = ops.col_mean(x)          # gpytorch centres on the first operand
+            center = _col_mean(ops, x)          # gpytorch centres on the first operand
         if not self.fits_packed_rows(x.shape[1]):
             return self._dense_wide(x, y, center)
         spec = self.spec(x.shape[1])
@@ -140,7 +146,7 @@ class PosteriorKernel:
         Xo = ops.to_device(self.Xobs, torch.float64)
         W = ops.to_device(self.W, torch.float64)
         if center is None:
-            center = ops.col_mean(x)
+            center = _col_mean(ops, x)
         cov = self.base.dense(ops, x, y, center)
         KxX = self.base.dense(ops, x, Xo, center)
         KXy = self.base.dense(ops, Xo, y, center)
@@ -162,7 +168,7 @@ class PosteriorKernel:
         Xo = ops.to_device(self.Xobs, torch.float64)
         v = ops.to_device(self.mean_cache, torch.float64)
         if center is None:
-            center = ops.col_mean(x)
+            center = _col_mean(ops, x)
         if not self.base.fits_packed_rows(x.shape[1]):
             return self.mean_const + self.base.dense(ops, x, Xo, center) @ v
         spec = self.base.spec(x.shape[1])
@@ -175,7 +181,7 @@ class PosteriorKernel:
         Xo = ops.to_device(self.Xobs, torch.float64)
         W = ops.to_device(self.W, torch.float64)
         if center is None:
-            center = ops.col_mean(x)
+            center = _col_mean(ops, x)
         KxX = self.base.dense(ops, x, Xo, center)
         return self.base.outputscale - (_mm(ops, KxX, W) * KxX).sum(1) + self.noise
 
@@ -205,7 +211,7 @@ class WsabiKernel:
         Xo = ops.to_device(self.posterior.Xobs, torch.float64)
         v = ops.to_device(self.mean_cache, torch.float64)
         if center is None:
-            center = ops.col_mean(x)
+            center = _col_mean(ops, x)
         if not self.base.fits_packed_rows(x.shape[1]):
             return self.mean_const + self.base.dense(ops, x, Xo, center) @ v
         spec = self.base.spec(x.shape[1])
@@ -215,7 +221,7 @@ class WsabiKernel:
 
     def dense(self, ops, x, y, center=None, diag_offset=0):
         if center is None:
-            center = ops.col_mean(x)
+            center = _col_mean(ops, x)
         cov = self.posterior.dense(ops, x, y, center, diag_offset)
         out = self.mean(ops, x, center).unsqueeze(1) * cov * self.mean(ops, y, center).unsqueeze(0)
         if self.warp == "wsabim":
@@ -234,7 +240,7 @@ class WsabiKernel:
         """``wsabil_mean_predict`` / ``wsabim_mean_predict`` (``BASQ/_wsabi.py:278-300``)."""
         x = x.to(torch.float64).contiguous()
         ops = _ops_for(x)
-        center = ops.col_mean(x)
+        center = _col_mean(ops, x)
         mu_w = self.mean(ops, x, center)
         if self.warp == "wsabil":
             return self.alpha + 0.5 * mu_w ** 2

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--N", type=int, default=1_000_000)
     ap.add_argument("--d", type=int, default=10)
     ap.add_argument("--n", type=int, default=100)
+    ap.add_argument("--case", default="", help="a tests/cases.py case (e.g. cfg4_matern52_1e6_d32) instead of the headline workload")
     ap.add_argument("--pipelined-only", action="store_true", help="no sequential reference runs (profiles of the pipeline alone)")
     ap.add_argument("--set", action="append", default=[], help="NAME=VALUE for basq_amd._config (e.g. PIPELINE_GATE=0)")
     a = ap.parse_args()
@@ -36,14 +37,25 @@ def main():
         setattr(cfg, k, type(getattr(cfg, k))(int(v)))
         print(f"config: {k} = {getattr(cfg, k)}")
     dev = torch.device("cuda", 0)
-    m = a.N // 100
-    kern = basq_amd.kernels.StationaryKernel("rbf", 2.0, 1.0)
-    pools = []
-    for sd in range(3):
-        p = gmm_pool(a.N, a.d, sd).to(dev)
-        pools.append((p, p[:m].contiguous()))
-    calls = [(pools[k % 3][0], pools[k % 3][1], a.n, kern) for k in range(a.batches)]
-    seeds = [1] * a.batches
+    if a.case:
+        from tests.cases import BY_NAME, build_pool, build_product_kernel
+
+        c = BY_NAME[a.case]
+        pts, nys = build_pool(c)
+        pts, nys = pts.to(dev), nys.to(dev)
+        kern = build_product_kernel(c)
+        calls = [(pts, nys, c["n"], kern) for _ in range(a.batches)]
+        seeds = [c["torch_seed"]] * a.batches
+        print(f"case {a.case}: N={c['N']} d={c['d']} n={c['n']} m={c['m']}")
+    else:
+        m = a.N // 100
+        kern = basq_amd.kernels.StationaryKernel("rbf", 2.0, 1.0)
+        pools = []
+        for sd in range(3):
+            p = gmm_pool(a.N, a.d, sd).to(dev)
+            pools.append((p, p[:m].contiguous()))
+        calls = [(pools[k % 3][0], pools[k % 3][1], a.n, kern) for k in range(a.batches)]
+        seeds = [1] * a.batches
 
     def sequential():
         out = []

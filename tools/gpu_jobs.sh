@@ -25,6 +25,8 @@ job_configs()     { timeout -k 10 900 python tools/bench_configs.py > "$out/conf
 job_concurrent()  { timeout -k 10 600 python tools/exp_concurrent.py --threads 2 --launches > "$out/concurrent.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/concurrent.txt" | cut -c1-200; return $rc; }
 job_concurrent3() { timeout -k 10 600 python tools/exp_concurrent.py --threads 3 > "$out/concurrent3.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/concurrent3.txt" | cut -c1-200; return $rc; }
 job_many()        { timeout -k 10 600 python tools/bench_many.py > "$out/many.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/many.txt" | cut -c1-250; return $rc; }
+job_many_cfg4()   { timeout -k 10 600 python tools/bench_many.py --case cfg4_matern52_1e6_d32 --batches 8 --inflight 2,3 > "$out/many_cfg4.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/many_cfg4.txt" | cut -c1-250; return $rc; }
+job_many_cfg5m()  { timeout -k 10 600 python tools/bench_many.py --case cfg5m_wsabim_5e5 --batches 8 --inflight 2 > "$out/many_cfg5m.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/many_cfg5m.txt" | cut -c1-250; return $rc; }
 job_opaque_cfg4() { timeout -k 10 1100 python tools/bench_opaque_cfg4.py > "$out/opaque_cfg4.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/opaque_cfg4.txt" | cut -c1-250; return $rc; }
 
 # rocprofv3 kernel statistics of a python command: prof <name> <script> [args...]  (program itself after `--`, run from /tmp)
@@ -38,6 +40,7 @@ prof() {
 job_prof_bench()  { prof bench bench.py --steps 10 --warmup 2 --no-cpu-baseline && python tools/trace_gaps.py "$(ls $out/prof_bench/*kernel_trace.csv | head -1)" > "$out/trace_gaps_bench.txt" 2>&1; rc=$?; head -6 "$out/trace_gaps_bench.txt" | cut -c1-200; return $rc; }
 job_prof_many()   { prof many tools/bench_many.py --batches 12 --inflight 2 --pipelined-only && python tools/trace_overlap.py --tail-fraction 0.7 "$(ls $out/prof_many/*kernel_trace.csv | head -1)" > "$out/trace_overlap_many.txt" 2>&1; rc=$?; head -30 "$out/trace_overlap_many.txt" | cut -c1-200; return $rc; }
 job_prof_concurrent() { prof conc tools/exp_concurrent.py --threads 2 --batches 6 && python tools/trace_overlap.py "$(ls $out/prof_conc/*kernel_trace.csv | head -1)" > "$out/trace_overlap_conc.txt" 2>&1; rc=$?; head -30 "$out/trace_overlap_conc.txt" | cut -c1-200; return $rc; }
+job_prof_opaque() { prof opaque tools/bench_opaque_cfg4.py --reps 1; }
 job_prof_cfg4()   { prof cfg4 tools/bench_configs.py --only cfg4_matern52_1e6_d32; }
 job_prof_cfg5m()  { prof cfg5m tools/bench_configs.py --only cfg5m_wsabim_5e5; }
 job_drop_traces() { rm -f $out/prof_*/*trace.csv; }
