@@ -56,8 +56,23 @@ __device__ __forceinline__ double exp_nonpos(double x) {
 // hardware involved.  (Round 1 A/B-timed three other evaluations -- a degree-10 polynomial without a table, a 32-entry
 // table in LDS or in global memory with a degree-5 polynomial; profiles/r01_blocksum_exp_modes_ab.txt -- this one won.)
 // The constants are pinned in VGPRs: an fp64 literal costs an SGPR pair and a constant-bus slot per use.
-#define BASQ_TAB_N 2048
-__device__ const double basq_exp_tab_g[2048] = BASQ_EXP_TAB2048;
+// Scheme 2 (template parameter XS of the block-sum kernel): 4096-entry table (32 KB of LDS per work-group), degree-2
+// interpolant in r (|r| < 8.5e-5, max relative error 2.5e-14) -- one fp64 instruction fewer per kernel value: 7.47 vs 7.79 ms
+// per 1e10 pairs (profiles/r03_n_exp_scheme_ab.txt).  Used by the recombination's block sums, whose selection is stable under
+// kernel perturbations up to 1e-7 (SURVEY finding 3); the kernel mat-vec (GP means, Gaussian moments: sums with
+// cancellation) and the squared-covariance sums keep scheme 1 (1e-17).
+__device__ const double basq_exp_tab2048_g[2048] = BASQ_EXP_TAB2048;
+__device__ const double basq_exp_tab4096_g[4096] = BASQ_EXP_TAB4096;
+
+#ifndef BASQ_BLOCKSUM_EXP_SCHEME
+#define BASQ_BLOCKSUM_EXP_SCHEME 2      // the recombination's block sums (A/B builds: -DBASQ_BLOCKSUM_EXP_SCHEME=1)
+#endif
+
+template <int XS>
+struct ExpScheme {
+    static constexpr int N = (XS == 2) ? 4096 : 2048;
+    static constexpr int SHIFT = (XS == 2) ? 12 : 11;
+};
 
 struct ExpK {
     double k32, nhi, magic, c3, c2, one;
@@ -68,32 +83,45 @@ __device__ __forceinline__ double vgpr_const(double x) {
     return x;
 }
 
+template <int XS>
 __device__ __forceinline__ void expk_init(ExpK& k) {
     k.magic = vgpr_const(0x1.8p52);
-    k.k32 = vgpr_const(BASQ_2048_OVER_LN2);
-    k.nhi = vgpr_const(-BASQ_LN2_2048_HI);
-    k.c3 = vgpr_const(BASQ_EXP_U3);
-    k.c2 = vgpr_const(BASQ_EXP_U2);
-    k.one = vgpr_const(1.0);
+    if (XS == 2) {
+        k.k32 = vgpr_const(BASQ_4096_OVER_LN2);
+        k.nhi = vgpr_const(-BASQ_LN2_4096_HI);
+        k.c3 = vgpr_const(BASQ_EXP_V2);
+        k.c2 = vgpr_const(BASQ_EXP_V1);
+        k.one = vgpr_const(BASQ_EXP_V0);
+    } else {
+        k.k32 = vgpr_const(BASQ_2048_OVER_LN2);
+        k.nhi = vgpr_const(-BASQ_LN2_2048_HI);
+        k.c3 = vgpr_const(BASQ_EXP_U3);
+        k.c2 = vgpr_const(BASQ_EXP_U2);
+        k.one = vgpr_const(1.0);
+    }
 }
 
 // `tab` = LDS copy of the table (exp_table_init); valid for -1.4e9 < x <= ~1, exact 0 below ~-745.
+template <int XS>
 __device__ __forceinline__ double exp_nonpos_k(double x, const ExpK& k, const double* tab) {
     const double t = __builtin_fma(x, k.k32, k.magic);
-    const int ti = __double2loint(t);                 // 2048 n + j  (two's complement)
-    const double T = tab[ti & (BASQ_TAB_N - 1)];
+    const int ti = __double2loint(t);                 // N n + j  (two's complement)
+    const double T = tab[ti & (ExpScheme<XS>::N - 1)];
     const double nf = t - k.magic;
-    // ln2/2048 is used as ONE correctly rounded constant; the dropped tail |nf| * 1.1e-20 is a relative error of
+    // ln2/N is used as ONE correctly rounded constant; the dropped tail |nf| * 1.1e-20 is a relative error of
     // < 2e-15 in the kernel value for every argument whose exp exceeds 1e-22 (|nf| < 1.5e5)
     const double r = __builtin_fma(nf, k.nhi, x);
     double w = __builtin_fma(k.c3, r, k.c2);
     w = __builtin_fma(w, r, k.one);
-    const double e = __builtin_fma(T * r, w, T);      // T (1 + r w)
-    return ldexp(e, ti >> 11);
+    const double e = (XS == 2) ? (T * w)                          // T (v0 + v1 r + v2 r^2)
+                               : __builtin_fma(T * r, w, T);      // T (1 + r w)
+    return ldexp(e, ti >> ExpScheme<XS>::SHIFT);
 }
 
+template <int XS>
 __device__ __forceinline__ void exp_table_init(double* tab) {
-    for (int i = threadIdx.x; i < BASQ_TAB_N; i += blockDim.x) tab[i] = basq_exp_tab_g[i];
+    const double* src = (XS == 2) ? basq_exp_tab4096_g : basq_exp_tab2048_g;
+    for (int i = threadIdx.x; i < ExpScheme<XS>::N; i += blockDim.x) tab[i] = src[i];
     __syncthreads();
 }
 
@@ -116,20 +144,20 @@ __device__ __forceinline__ double kernel_from_arg(double D) {
     }
 }
 
-template <int FAM>
+template <int FAM, int XS>
 __device__ __forceinline__ double kernel_from_arg_k(double D, const ExpK& k, const double* tab) {
     if (FAM == BASQ_FAMILY_RBF) {
-        return exp_nonpos_k(D, k, tab);
+        return exp_nonpos_k<XS>(D, k, tab);
     } else {
         const double r2 = fmax(-2.0 * D, 1e-30);
         const double r = sqrt(r2);
         if (FAM == BASQ_FAMILY_MATERN52) {
             const double a = 0x1.1e3779b97f4a8p+1 * r;
             const double poly = (a + 1.0) + (5.0 / 3.0) * r2;
-            return poly * exp_nonpos_k(-a, k, tab);
+            return poly * exp_nonpos_k<XS>(-a, k, tab);
         } else {
             const double a = 0x1.bb67ae8584caap+0 * r;
-            return (a + 1.0) * exp_nonpos_k(-a, k, tab);
+            return (a + 1.0) * exp_nonpos_k<XS>(-a, k, tab);
         }
     }
 }
@@ -344,7 +372,7 @@ __device__ __forceinline__ void load_cand(CandFrag<KK>& f, const BlocksumArgs& A
     f.w = ok ? m_ * x_ : 0.0;
 }
 
-template <int KK, int FAM, int JT>
+template <int KK, int FAM, int JT, int XS>
 __device__ __forceinline__ void tile_accumulate(const double (&a)[JT][KK], const CandFrag<KK>& f, double (&acc)[JT][4],
                                                 const ExpK& ek, const double* tab) {
 #pragma unroll
@@ -353,11 +381,11 @@ __device__ __forceinline__ void tile_accumulate(const double (&a)[JT][KK], const
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) D = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt][kk], f.b[kk], D, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[jt][r] = __builtin_fma(kernel_from_arg_k<FAM>(D[r], ek, tab), f.w, acc[jt][r]);
+        for (int r = 0; r < 4; ++r) acc[jt][r] = __builtin_fma(kernel_from_arg_k<FAM, XS>(D[r], ek, tab), f.w, acc[jt][r]);
     }
 }
 
-template <int KK, int FAM, int JT>
+template <int KK, int FAM, int JT, int XS>
 __global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A_in) {
     constexpr int KP = KK * 4;
     BlocksumArgs A = A_in;
@@ -375,13 +403,13 @@ __global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A_in) 
     const int st = gidx % A.n_stiles;
     const int chunk = gidx / A.n_stiles;
     const int j0 = (jg * 4 + wave) * (16 * JT);
-    __shared__ double exp_tab[BASQ_TAB_N];
-    exp_table_init(exp_tab);   // the only barrier of this kernel, before any early exit
+    __shared__ double exp_tab[ExpScheme<XS>::N];
+    exp_table_init<XS>(exp_tab);   // the only barrier of this kernel, before any early exit
     if (chunk >= A.n_chunks) return;   // padding work-groups of the last group of 8 pairs (work-group uniform)
     if (j0 >= A.m) return;     // wave-uniform
     const int s0 = st * 16;
     ExpK ek;
-    expk_init(ek);
+    expk_init<XS>(ek);
 
     double a[JT][KK];
 #pragma unroll
@@ -426,7 +454,7 @@ __global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A_in) 
             const long long pg = i * A.S + s0 + c;
             CandFrag<KK> f;
             load_cand<KK>(f, A, pg - A.off, col_ok && pg >= A.off && pg < lim, g);
-            tile_accumulate<KK, FAM, JT>(a, f, acc, ek, exp_tab);
+            tile_accumulate<KK, FAM, JT, XS>(a, f, acc, ek, exp_tab);
             tot += f.wm;
         }
         const long long bF1 = (last_ok + 1 < bB) ? (last_ok + 1) : bB;           // end of the fast range
@@ -455,7 +483,7 @@ __global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A_in) 
                 } else {
                     nxt.w = nxt.wm;
                 }
-                tile_accumulate<KK, FAM, JT>(a, cur, acc, ek, exp_tab);
+                tile_accumulate<KK, FAM, JT, XS>(a, cur, acc, ek, exp_tab);
                 tot += cur.wm;
                 cur = nxt;
                 rp = rn;
@@ -467,7 +495,7 @@ __global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A_in) 
             const long long pg = i * A.S + s0 + c;
             CandFrag<KK> f;
             load_cand<KK>(f, A, pg - A.off, col_ok && pg >= A.off && pg < lim, g);
-            tile_accumulate<KK, FAM, JT>(a, f, acc, ek, exp_tab);
+            tile_accumulate<KK, FAM, JT, XS>(a, f, acc, ek, exp_tab);
             tot += f.wm;
         }
     }
@@ -485,7 +513,7 @@ __global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A_in) 
         for (long long p = t0; p < A.Rl; p += 16) {
             CandFrag<KK> f;
             load_cand<KK>(f, A, p + c, (p + c) < A.Rl, g);
-            tile_accumulate<KK, FAM, JT>(a, f, tacc, ek, exp_tab);
+            tile_accumulate<KK, FAM, JT, XS>(a, f, tacc, ek, exp_tab);
             ttot += f.wm;
         }
         const int c_last = (A.S - 1) - s0;
@@ -517,7 +545,7 @@ __global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A_in) 
 // 4 x KP/4 fragment registers would push the kernel to one wave per SIMD.  basq_amd/_partition.py mirrors this.
 #define BASQ_JT_FOR(KK) ((KK) >= 6 ? 2 : 4)
 
-template <int KK, int FAM>
+template <int KK, int FAM, int XS>
 static int launch_blocksum(const BlocksumArgs& A, hipStream_t st) {
     constexpr int JT = BASQ_JT_FOR(KK);
     BlocksumArgs B = A;
@@ -525,33 +553,42 @@ static int launch_blocksum(const BlocksumArgs& A, hipStream_t st) {
     const long long npairs = (long long)A.n_stiles * A.n_chunks;
     const long long nblk = ((npairs + 7) / 8) * 8 * B.n_jgroups;   // (set tile, chunk) pairs padded to the 8 XCDs
     if (nblk <= 0 || nblk > 0x7fffffffLL) return BASQ_EINVAL;
-    hipLaunchKernelGGL((blocksum_kernel<KK, FAM, JT>), dim3((unsigned)nblk), dim3(256), 0, st, B);
+    hipLaunchKernelGGL((blocksum_kernel<KK, FAM, JT, XS>), dim3((unsigned)nblk), dim3(256), 0, st, B);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }
 
 template <int KK>
-static int dispatch_blocksum_fam(int fam, const BlocksumArgs& A, hipStream_t st) {
+static int dispatch_blocksum_fam(int fam, const BlocksumArgs& A, hipStream_t st, int xs) {
+    if (xs == 2) {
+        switch (fam) {
+            case BASQ_FAMILY_RBF: return launch_blocksum<KK, BASQ_FAMILY_RBF, 2>(A, st);
+            case BASQ_FAMILY_MATERN52: return launch_blocksum<KK, BASQ_FAMILY_MATERN52, 2>(A, st);
+            case BASQ_FAMILY_MATERN32: return launch_blocksum<KK, BASQ_FAMILY_MATERN32, 2>(A, st);
+        }
+        return BASQ_EUNSUPPORTED;
+    }
     switch (fam) {
-        case BASQ_FAMILY_RBF: return launch_blocksum<KK, BASQ_FAMILY_RBF>(A, st);
-        case BASQ_FAMILY_MATERN52: return launch_blocksum<KK, BASQ_FAMILY_MATERN52>(A, st);
-        case BASQ_FAMILY_MATERN32: return launch_blocksum<KK, BASQ_FAMILY_MATERN32>(A, st);
+        case BASQ_FAMILY_RBF: return launch_blocksum<KK, BASQ_FAMILY_RBF, 1>(A, st);
+        case BASQ_FAMILY_MATERN52: return launch_blocksum<KK, BASQ_FAMILY_MATERN52, 1>(A, st);
+        case BASQ_FAMILY_MATERN32: return launch_blocksum<KK, BASQ_FAMILY_MATERN32, 1>(A, st);
     }
     return BASQ_EUNSUPPORTED;
 }
 
-static int dispatch_blocksum(int kk, int fam, const BlocksumArgs& A, hipStream_t st) {
+// xs: exponential scheme (1: 2048-entry table + cubic, 1e-17; 2: 4096-entry table + quadratic, 2.5e-14, one instruction less)
+static int dispatch_blocksum(int kk, int fam, const BlocksumArgs& A, hipStream_t st, int xs) {
     switch (kk) {
-        case 1: return dispatch_blocksum_fam<1>(fam, A, st);
-        case 2: return dispatch_blocksum_fam<2>(fam, A, st);
-        case 3: return dispatch_blocksum_fam<3>(fam, A, st);
-        case 4: return dispatch_blocksum_fam<4>(fam, A, st);
-        case 5: return dispatch_blocksum_fam<5>(fam, A, st);
-        case 6: return dispatch_blocksum_fam<6>(fam, A, st);
-        case 7: return dispatch_blocksum_fam<7>(fam, A, st);
-        case 8: return dispatch_blocksum_fam<8>(fam, A, st);
-        case 9: return dispatch_blocksum_fam<9>(fam, A, st);
-        case 10: return dispatch_blocksum_fam<10>(fam, A, st);
+        case 1: return dispatch_blocksum_fam<1>(fam, A, st, xs);
+        case 2: return dispatch_blocksum_fam<2>(fam, A, st, xs);
+        case 3: return dispatch_blocksum_fam<3>(fam, A, st, xs);
+        case 4: return dispatch_blocksum_fam<4>(fam, A, st, xs);
+        case 5: return dispatch_blocksum_fam<5>(fam, A, st, xs);
+        case 6: return dispatch_blocksum_fam<6>(fam, A, st, xs);
+        case 7: return dispatch_blocksum_fam<7>(fam, A, st, xs);
+        case 8: return dispatch_blocksum_fam<8>(fam, A, st, xs);
+        case 9: return dispatch_blocksum_fam<9>(fam, A, st, xs);
+        case 10: return dispatch_blocksum_fam<10>(fam, A, st, xs);
     }
     return BASQ_EUNSUPPORTED;
 }
@@ -620,8 +657,8 @@ __device__ __forceinline__ void sq_pair_accumulate(const double (&a)[JT][KK], co
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = jrow + jt * 16 + 4 * r;
-            double v0 = __builtin_fma(Q.outputscale, kernel_from_arg_k<FAM>(D0[r], ek, tab), -E0[jt][r]);
-            double v1 = __builtin_fma(Q.outputscale, kernel_from_arg_k<FAM>(D1[r], ek, tab), -E1[jt][r]);
+            double v0 = __builtin_fma(Q.outputscale, kernel_from_arg_k<FAM, 1>(D0[r], ek, tab), -E0[jt][r]);
+            double v1 = __builtin_fma(Q.outputscale, kernel_from_arg_k<FAM, 1>(D1[r], ek, tab), -E1[jt][r]);
             if (noisy) {
                 if (j == kap0) v0 += Q.noise;
                 if (j == kap1) v1 += Q.noise;
@@ -643,13 +680,13 @@ __global__ void __launch_bounds__(256) blocksum_sq_kernel(const BlocksumArgs A, 
     const int st = gidx % A.n_stiles;
     const int chunk = gidx / A.n_stiles;
     const int j0 = (jg * 4 + wave) * (16 * JT);
-    __shared__ double exp_tab[BASQ_TAB_N];
-    exp_table_init(exp_tab);
+    __shared__ double exp_tab[ExpScheme<1>::N];
+    exp_table_init<1>(exp_tab);
     if (chunk >= A.n_chunks) return;
     if (j0 >= A.m) return;
     const int s0 = st * 16;
     ExpK ek;
-    expk_init(ek);
+    expk_init<1>(ek);
     double a[JT][KK];
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt)
@@ -3423,7 +3460,7 @@ int basq_gram_f64(const basq_kernel_spec* spec, const double* packA, int64_t na,
 static int blocksum_impl(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
                          const double* mu, const double* wx, int64_t Rl, int64_t off, int64_t n_full, int32_t S,
                          int32_t n_chunks, int32_t class_mod, int32_t class0, double* Xpart, double* totpart,
-                         void* stream) {
+                         void* stream, int xs) {
     if (!spec_ok(spec) || !nys || !cand || !mu || !Xpart) return BASQ_EINVAL;
     if (m < 1 || Rl < 1 || off < 0 || n_full < 0 || S < 1 || n_chunks < 1) return BASQ_EINVAL;
     if (n_full % S != 0) return BASQ_EINVAL;
@@ -3447,7 +3484,7 @@ static int blocksum_impl(const basq_kernel_spec* spec, const double* nys, int32_
     const long long nblk = A.blk_hi - A.blk_lo;
     A.blk_per_chunk = (nblk + n_chunks - 1) / n_chunks;
     if (A.blk_per_chunk < 1) A.blk_per_chunk = 1;
-    return dispatch_blocksum(basq_kp(spec->d) / 4, spec->family, A, (hipStream_t)stream);
+    return dispatch_blocksum(basq_kp(spec->d) / 4, spec->family, A, (hipStream_t)stream, xs);
 }
 
 int basq_blocksum_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
@@ -3455,7 +3492,7 @@ int basq_blocksum_f64(const basq_kernel_spec* spec, const double* nys, int32_t m
                       int32_t n_chunks, int32_t class_mod, int32_t class0, double* Xpart, double* totpart, void* stream) {
     if (!totpart) return BASQ_EINVAL;
     return blocksum_impl(spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, class_mod, class0, Xpart, totpart,
-                         stream);
+                         stream, BASQ_BLOCKSUM_EXP_SCHEME);
 }
 
 int basq_blocksum_sq_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
@@ -3527,7 +3564,7 @@ int basq_kernel_matvec_f64(const basq_kernel_spec* spec, const double* packA, in
     // blocksum with a single set and everything in the "tail": out[i] = sum_j k(A_i, B_j) v_j.
     if (!spec_ok(spec) || !packA || !packB || !v || !out || na < 1 || nb < 1 || na > 0x7fffffffLL)
         return BASQ_EINVAL;
-    int rc = blocksum_impl(spec, packA, (int32_t)na, packB, v, nullptr, nb, 0, 0, 1, 1, 0, 0, out, nullptr, stream);
+    int rc = blocksum_impl(spec, packA, (int32_t)na, packB, v, nullptr, nb, 0, 0, 1, 1, 0, 0, out, nullptr, stream, 1);
     if (rc != BASQ_OK) return rc;
     hipLaunchKernelGGL(axpb_strided_kernel, dim3((unsigned)((na + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out,
                        (long long)na, 1LL, spec->outputscale, bias, out);
@@ -3847,7 +3884,7 @@ int basq_blocksum_geo_f64(const basq_kernel_spec* spec, const double* nys, int32
     A.class_mod = class_mod; A.class0 = class0;
     A.geo = (const long long*)geo; A.geo_mode = geo_mode;
     A.n_stiles = (S + 15) / 16;
-    return dispatch_blocksum(basq_kp(spec->d) / 4, spec->family, A, (hipStream_t)stream);
+    return dispatch_blocksum(basq_kp(spec->d) / 4, spec->family, A, (hipStream_t)stream, BASQ_BLOCKSUM_EXP_SCHEME);
 }
 
 int basq_reweight_compact_geo_f64(const double* cand, const double* mu, const int64_t* gid, const double* wx,
