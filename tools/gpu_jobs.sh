@@ -39,7 +39,7 @@ prof() {
     head -16 "$out/prof_$name/${name}_kernel_stats.csv" 2>/dev/null | cut -c1-160
     return $rc
 }
-job_prof_bench()  { prof bench bench.py --steps 10 --warmup 2 --no-cpu-baseline && python tools/trace_gaps.py "$(ls $out/prof_bench/*kernel_trace.csv | head -1)" > "$out/trace_gaps_bench.txt" 2>&1; rc=$?; head -6 "$out/trace_gaps_bench.txt" | cut -c1-200; return $rc; }
+job_prof_bench()  { prof bench bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-concurrent && python tools/trace_gaps.py "$(ls $out/prof_bench/*kernel_trace.csv | head -1)" > "$out/trace_gaps_bench.txt" 2>&1; rc=$?; head -6 "$out/trace_gaps_bench.txt" | cut -c1-200; return $rc; }
 job_prof_many()   { prof many tools/bench_many.py --batches 12 --inflight 2 --pipelined-only && python tools/trace_overlap.py --tail-fraction 0.7 "$(ls $out/prof_many/*kernel_trace.csv | head -1)" > "$out/trace_overlap_many.txt" 2>&1; rc=$?; head -30 "$out/trace_overlap_many.txt" | cut -c1-200; return $rc; }
 job_prof_concurrent() { prof conc tools/exp_concurrent.py --threads 2 --batches 6 && python tools/trace_overlap.py "$(ls $out/prof_conc/*kernel_trace.csv | head -1)" > "$out/trace_overlap_conc.txt" 2>&1; rc=$?; head -30 "$out/trace_overlap_conc.txt" | cut -c1-200; return $rc; }
 job_prof_opaque() { prof opaque tools/bench_opaque_cfg4.py --reps 1; }
