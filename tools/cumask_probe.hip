@@ -18,6 +18,31 @@ __global__ void where_am_i(uint32_t* out, int spin) {
     if (threadIdx.x == 0) { out[2 * blockIdx.x] = xcc; out[2 * blockIdx.x + 1] = hw; }
 }
 
+// The stand-in for the reductions: one 1024-thread work-group that needs ALL of a CU's LDS (like car_eliminate_lds_kernel).
+__global__ void __launch_bounds__(1024) whole_cu(uint32_t* out, int spin) {
+    extern __shared__ double big[];
+    uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+    uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    big[threadIdx.x] = (double)hw;
+    long long t0 = clock64();
+    while (clock64() - t0 < spin) { }
+    if (threadIdx.x == 0) { out[0] = xcc; out[1] = hw + (uint32_t)(big[1] * 0.0); }
+}
+
+// A chip-filling PERSISTENT grid (3 work-groups of 256 threads per CU, limited by 52 KB of LDS each, like the block sums'
+// register-limited occupancy) whose work-groups retire at once when they find themselves on CU 0 / SE 0 / SH 0 of their XCD:
+// "software CU reservation" without a queue mask.
+__global__ void __launch_bounds__(256) persistent_spin(uint32_t* out, long long spin, int reserve) {
+    __shared__ double pad[6656];                                               // 52 KB -> 3 work-groups per CU
+    uint32_t hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    const bool on_reserved = ((hw >> 8) & 0xf) == 0 && ((hw >> 12) & 1) == 0 && ((hw >> 13) & 7) == 0;
+    if (reserve && on_reserved) return;
+    pad[threadIdx.x] = (double)hw;
+    long long t0 = clock64();
+    while (clock64() - t0 < spin) { }
+    if (threadIdx.x == 0) out[blockIdx.x] = (uint32_t)pad[0];
+}
+
 static int run(hipStream_t st, const char* name, uint32_t* d_out, int nwg) {
     std::vector<uint32_t> h(2 * nwg);
     hipLaunchKernelGGL(where_am_i, dim3(nwg), dim3(1024), 0, st, d_out, 20000);
@@ -106,6 +131,27 @@ int main() {
         CHECK(hipEventElapsedTime(&tc, c, d));
         printf("%-52s: wide kernel %.2f ms; 1-work-group kernel enqueued right behind it on another stream took %.3f ms (alone: ~0.1)\n",
                names[variant], tw, tc);
+    }
+    // software reservation: persistent 768-work-group grid, work-groups on CU0/SE0/SH0 retire at once
+    for (int reserve = 0; reserve < 2; ++reserve) {
+        hipStream_t w, ch;
+        CHECK(hipStreamCreate(&w)); CHECK(hipStreamCreate(&ch));
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(a, w));
+        hipLaunchKernelGGL(persistent_spin, dim3(768), dim3(256), 0, w, d_out2, 12000000LL, reserve);   // ~5 ms
+        CHECK(hipEventRecord(b, w));
+        CHECK(hipEventRecord(c, ch));
+        CHECK(hipFuncSetAttribute((const void*)whole_cu, hipFuncAttributeMaxDynamicSharedMemorySize, 160000));
+        hipLaunchKernelGGL(whole_cu, dim3(1), dim3(1024), 160000, ch, d_out, 200000);
+        CHECK(hipEventRecord(d, ch));
+        CHECK(hipDeviceSynchronize());
+        float tw, tc;
+        CHECK(hipEventElapsedTime(&tw, a, b));
+        CHECK(hipEventElapsedTime(&tc, c, d));
+        uint32_t h[2];
+        CHECK(hipMemcpy(h, d_out, 8, hipMemcpyDeviceToHost));
+        printf("persistent 768-work-group grid, reserve=%d: %.2f ms; 1024-thread / 160-KB-LDS work-group on another stream: %.3f ms, ran on x%u.se%u.sh%u.cu%u\n",
+               reserve, tw, tc, h[0] & 0xf, (h[1] >> 13) & 7, (h[1] >> 12) & 1, (h[1] >> 8) & 0xf);
     }
     return 0;
 }
