@@ -642,8 +642,6 @@ class Batch:
             self.cand, self.mu, self.gid, self.wx = ops.reweight_compact(
                 self.cand, self.mu, self.gid, self.wx, Rl, off, geo.n_full, S_r, self.kp, keep_rank, w_star, tot, n_keep,
                 new_off, new_Rl)
-            if self.obj_live is not None:
-                pass                                             # (objective batches never reach a second round)
             self.R = survivors_before(R, geo, kept_list)
             self.off, self.Rl = new_off, new_Rl
             self.R_lo = min((self.R_lo // S_r) * s, self.R)

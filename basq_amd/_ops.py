@@ -5,7 +5,7 @@ for memory, streams and a few small dense products outside the per-batch loop (p
 All pairwise-kernel work, the range finder's tall-skinny GEMMs, the Nystrom contraction,
 the elimination and the compaction run in ``libbasq_hip.so``.
 
-The engine (``_engine.py``) is written against this interface so that the CPU tests can
+The engine (``_batch.py`` / ``_engine.py``) is written against this interface so that the CPU tests can
 drive its host logic (sharding, offsets, collectives) with a stand-in defined under
 ``tests/`` -- the product never does.
 """

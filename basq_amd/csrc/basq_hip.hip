@@ -543,7 +543,10 @@ __global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A_in) 
 
 // Row tiles per wave: 4 (64 Nystrom rows) while the A fragments fit comfortably; 2 for KP >= 24 (d >= 21), where
 // 4 x KP/4 fragment registers would push the kernel to one wave per SIMD.  basq_amd/_partition.py mirrors this.
-#define BASQ_JT_FOR(KK) ((KK) >= 6 ? 2 : 4)
+#ifndef BASQ_JT_SMALL
+#define BASQ_JT_SMALL 4         // row tiles per wave for KP <= 20 (A/B builds: -DBASQ_JT_SMALL=2)
+#endif
+#define BASQ_JT_FOR(KK) ((KK) >= 6 ? 2 : BASQ_JT_SMALL)
 
 template <int KK, int FAM, int XS>
 static int launch_blocksum(const BlocksumArgs& A, hipStream_t st) {

@@ -28,8 +28,9 @@ job_many()        { timeout -k 10 600 python tools/bench_many.py > "$out/many.tx
 job_many_cfg4()   { timeout -k 10 600 python tools/bench_many.py --case cfg4_matern52_1e6_d32 --batches 8 --inflight 2,3 > "$out/many_cfg4.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/many_cfg4.txt" | cut -c1-250; return $rc; }
 job_many_cfg5m()  { timeout -k 10 600 python tools/bench_many.py --case cfg5m_wsabim_5e5 --batches 8 --inflight 2 > "$out/many_cfg5m.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/many_cfg5m.txt" | cut -c1-250; return $rc; }
 # A/B of a tuning-variant build of the library (BASQ_HIP_LIB): block-sum micro-benchmark A B A B, then the golden parity tests on B
-job_ab_lib()      { B=${AB_LIB:-basq_amd/csrc/libbasq_hip_exp2.so}; for i in 1 2 3; do for lib in basq_amd/csrc/libbasq_hip.so $B; do echo "== $lib" >> "$out/ab_lib.txt"; BASQ_HIP_LIB=$PWD/$lib timeout -k 10 120 python tools/bench_blocksum.py --reps 6 2>&1 | grep -v amdgpu.ids >> "$out/ab_lib.txt" || return 1; BASQ_HIP_LIB=$PWD/$lib timeout -k 10 120 python tools/bench_blocksum.py --family matern52 --d 32 --n 200 --reps 3 2>&1 | grep -v amdgpu.ids >> "$out/ab_lib.txt" || return 1; done; done; cat "$out/ab_lib.txt"; BASQ_HIP_LIB=$PWD/$B timeout -k 10 900 python -m pytest tests -x -q -m gpu -k "golden or fuzz or moment" > "$out/ab_lib_tests.log" 2>&1; rc=$?; tail -3 "$out/ab_lib_tests.log"; return $rc; }
+job_ab_lib()      { B=${AB_LIB:-basq_amd/csrc/libbasq_hip_jt2.so}; for i in 1 2 3; do for lib in basq_amd/csrc/libbasq_hip.so $B; do echo "== $lib" >> "$out/ab_lib.txt"; BASQ_HIP_LIB=$PWD/$lib timeout -k 10 120 python tools/bench_blocksum.py --reps 6 2>&1 | grep -v amdgpu.ids >> "$out/ab_lib.txt" || return 1; BASQ_HIP_LIB=$PWD/$lib timeout -k 10 120 python tools/bench_blocksum.py --family matern52 --d 32 --n 200 --reps 3 2>&1 | grep -v amdgpu.ids >> "$out/ab_lib.txt" || return 1; done; done; cat "$out/ab_lib.txt"; BASQ_HIP_LIB=$PWD/$B timeout -k 10 900 python -m pytest tests -x -q -m gpu -k "golden or fuzz or moment" > "$out/ab_lib_tests.log" 2>&1; rc=$?; tail -3 "$out/ab_lib_tests.log"; return $rc; }
 job_fuzz()        { ( timeout -k 10 500 python tools/fuzz_async.py 5 80 2>&1 | grep -v amdgpu.ids | tail -4; timeout -k 10 500 python tools/fuzz_structured.py 11 120 2>&1 | grep -v "amdgpu.ids\|Warning\|warn" | tail -8 ) > "$out/fuzz.txt" 2>&1; cat "$out/fuzz.txt"; }
+job_ab_lib_bench() { B=${AB_LIB:-basq_amd/csrc/libbasq_hip_jt2.so}; for i in 1 2; do for lib in basq_amd/csrc/libbasq_hip.so $B; do echo "== $lib" >> "$out/ab_lib_bench.txt"; BASQ_HIP_LIB=$PWD/$lib timeout -k 10 200 python bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-concurrent 2>/dev/null | cut -c1-260 >> "$out/ab_lib_bench.txt" || return 1; done; done; cat "$out/ab_lib_bench.txt"; }
 job_opaque_cfg4() { timeout -k 10 1100 python tools/bench_opaque_cfg4.py > "$out/opaque_cfg4.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/opaque_cfg4.txt" | cut -c1-250; return $rc; }
 
 # rocprofv3 kernel statistics of a python command: prof <name> <script> [args...]  (program itself after `--`, run from /tmp)
@@ -41,6 +42,7 @@ prof() {
     return $rc
 }
 job_prof_bench()  { prof bench bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-concurrent && python tools/trace_gaps.py "$(ls $out/prof_bench/*kernel_trace.csv | head -1)" > "$out/trace_gaps_bench.txt" 2>&1; rc=$?; head -6 "$out/trace_gaps_bench.txt" | cut -c1-200; return $rc; }
+job_trace_round() { prof round bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-concurrent --no-roofline-batch && python tools/trace_round.py "$(ls $out/prof_round/*kernel_trace.csv | head -1)" --first 2 --count 2 > "$out/trace_round.txt" 2>&1; rc=$?; cat "$out/trace_round.txt" | cut -c1-140; return $rc; }
 job_prof_many()   { prof many tools/bench_many.py --batches 12 --inflight 2 --pipelined-only && python tools/trace_overlap.py --tail-fraction 0.7 "$(ls $out/prof_many/*kernel_trace.csv | head -1)" > "$out/trace_overlap_many.txt" 2>&1; rc=$?; head -30 "$out/trace_overlap_many.txt" | cut -c1-200; return $rc; }
 job_prof_concurrent() { prof conc tools/exp_concurrent.py --threads 2 --batches 6 && python tools/trace_overlap.py "$(ls $out/prof_conc/*kernel_trace.csv | head -1)" > "$out/trace_overlap_conc.txt" 2>&1; rc=$?; head -30 "$out/trace_overlap_conc.txt" | cut -c1-200; return $rc; }
 job_prof_opaque() { prof opaque tools/bench_opaque_cfg4.py --reps 1; }
