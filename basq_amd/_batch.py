@@ -246,6 +246,11 @@ class Batch:
         nys_rows = [pts_nys]
         self.diag_noise, self.n_obs = 0.0, 0
         if self.post is not None:
+            cond = self.post.condition_number() if hasattr(self.post, "condition_number") else 0.0
+            if cond > self.post.COND_WARN:
+                self.notes.append(f"the observation Gram of the GP posterior is ill-conditioned (cond ~ {cond:.1e}): the "
+                                  "posterior covariance is a catastrophic cancellation, and the reference's own selection is "
+                                  "not reproducible to the last ulp in this regime (DESIGN.md section 2)")
             self.Xo = ops.to_device(self.post.Xobs, torch.float64)
             self.n_obs = self.Xo.shape[0]
             nys_rows.append(self.Xo)

@@ -142,6 +142,21 @@ class PosteriorKernel:
     def posterior(self):
         return self
 
+    COND_WARN = 1e7
+
+    def condition_number(self):
+        """2-norm condition number of the Woodbury matrix ``W = (K(X, X) + noise I)^-1`` -- that of the observation Gram
+        -- computed once per kernel object (an ``n_obs x n_obs`` symmetric eigenvalue problem on the host).  Above
+        ~1e7 the posterior covariance ``k - k(.,X) W k(X,.)`` is a catastrophic cancellation: the reference's own selection
+        then changes when its base kernel moves by one ulp, and no implementation can reproduce it."""
+        c = self.__dict__.get("_cond")
+        if c is None:
+            Wh = self.W.detach().to("cpu", torch.float64)
+            ev = torch.linalg.eigvalsh(0.5 * (Wh + Wh.T)).abs()
+            lo = float(ev.min())
+            c = self.__dict__["_cond"] = float(ev.max()) / lo if lo > 0 else float("inf")
+        return c
+
     def dense(self, ops, x, y, center=None, diag_offset=0):
         Xo = ops.to_device(self.Xobs, torch.float64)
         W = ops.to_device(self.W, torch.float64)

@@ -474,3 +474,23 @@ def test_cluster_timeout_is_retried_on_single_workgroup_kernels():
         ib, wb = RecombinationEngine(TimingOut()).run(pts, 0, N, pts[:m], n, kern)
     assert TimingOut.seen_cluster_false > 0
     assert torch.equal(ia, ib) and torch.allclose(wa, wb, rtol=1e-11, atol=0)
+
+
+def test_ill_conditioned_posterior_is_reported():
+    """Round-2 review: the engine gave no signal in the regime where the parity claim ends.  A GP posterior whose observation
+    Gram has condition number > 1e7 now produces a RuntimeWarning (the batch is still computed)."""
+    from basq_amd.kernels import PosteriorKernel, StationaryKernel
+    from basq_amd.pools import gmm_pool
+
+    d = 2
+    Xobs = gmm_pool(60, d, 3) * 0.05                                # 60 observations almost on top of each other
+    base = StationaryKernel("rbf", 2.0, 1.0)
+    ops = CpuStandInOps()
+    K = base.dense(ops, Xobs, Xobs) + 1e-10 * torch.eye(60, dtype=torch.float64)
+    post = PosteriorKernel(base, Xobs, torch.linalg.inv(K), 1e-10)
+    assert post.condition_number() > 1e7
+    pts = gmm_pool(3_000, d, 4)
+    with pytest.warns(RuntimeWarning, match="ill-conditioned"):
+        RecombinationEngine(CpuStandInOps()).run(pts, 0, 3_000, pts[:60], 20, post)
+    well = PosteriorKernel(base, gmm_pool(20, d, 5) * 3.0, torch.eye(20, dtype=torch.float64), 1e-2)
+    assert well.condition_number() < 10
