@@ -15,7 +15,8 @@ Rank 0 prints ONE JSON line.
 * value     = steps one after the other (each call returns before the next starts: the reference's synchronous call);
               ``value_concurrent2`` (``concurrent`` object) = the same K steps with TWO independent batches in flight
               (``basq_amd.recombination_many``: the reference's own pair, selection + quadrature, ``BASQ/_basq.py:82-88,
-              104-106``), results bit-identical to the sequential runs; multi-GPU lines add ``value_concurrent4``;
+              104-106``), results bit-identical to the sequential runs; ``value_concurrent3`` on one GPU, ``value_concurrent4`` on
+              multi-GPU lines;
 * roofline  = the dominant kernel (``blocksum_kernel``): algorithmic flops = pairs * (3d + 3)
               (SURVEY §8d) over its HIP-event time on the launch stream, against the fp64 vector peak;
 * cpu_baseline = the oracle (= the reference's CPU op sequence) on this host's cores, bounded sample.
@@ -138,7 +139,7 @@ def main():
     # ---- several batches in flight (outside the timed region of `value`): the same K steps through recombination_many ----
     concurrent = {}
     if not (args.no_concurrent or args.no_roofline_batch):
-        for k_fl in ([2] if world == 1 and not force_dist else [2, 4]):
+        for k_fl in ([2, 3] if world == 1 and not force_dist else [2, 4]):
             calls, seeds = [], [1] * args.steps
             for k in range(args.steps):
                 pts_nys, pts_local = pools_dev[k % len(pools_dev)]
@@ -264,6 +265,7 @@ def main():
                                    f"float64, pool sharded over {world} GPU(s); pool seeds {list(POOL_SEEDS)} cycled over steps",
                        "N": N, "d": d, "n": n, "m": m, "kernel": "rbf", "parallelism": f"pool-sharded x{world}"},
             "value_concurrent2": concurrent[2]["value"] if 2 in concurrent else None,
+            "value_concurrent3": concurrent[3]["value"] if 3 in concurrent else None,
             "value_concurrent4": concurrent[4]["value"] if 4 in concurrent else None,
             "concurrent": [concurrent[k] for k in sorted(concurrent)] or None,
             "roofline": {
