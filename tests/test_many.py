@@ -205,3 +205,38 @@ def test_recombination_many_gpu_goldens_structured_pair():
         assert idx.cpu().tolist() == fx["idx"], nm
         gw = torch.tensor(fx["w"], dtype=torch.float64)
         assert ((w.cpu() - gw).abs() / gw).max().item() <= 1e-6
+
+
+@pytest.mark.gpu
+def test_recombination_many_gpu_mixed_kinds():
+    """Batches of different kinds in flight together -- an opaque callable in the reference's block-by-block mode, WSABI-M
+    (round-by-round loop with its squared-covariance block sums), a SOBER-free structured posterior on the descriptor path --
+    each reproduces its golden: nothing is shared between batches in flight but the GPU."""
+    import basq_amd
+    from tests.cases import build_oracle_kernel
+
+    dev = torch.device("cuda", 0)
+    names = ["posterior_noise_ragged", "wsabim_1e4", "matern52_posterior", "rbf_ragged"]
+    calls, seeds = [], []
+    for i, nm in enumerate(names):
+        c = BY_NAME[nm]
+        pts, nys = build_pool(c)
+        if i == 0:                                                # a bare lambda over the oracle's predictive_covariance
+            ko, _ = build_oracle_kernel(c)
+            for obj in (ko, getattr(ko, "post", None)):
+                for attr in ("Xobs", "W", "mean_cache"):
+                    t = getattr(obj, attr, None) if obj is not None else None
+                    if torch.is_tensor(t):
+                        setattr(obj, attr, t.to(dev))
+            kern = lambda x, y, ko=ko: ko(x, y)                   # noqa: E731
+        else:
+            kern = build_product_kernel(c)
+        calls.append((pts.to(dev), nys.to(dev), c["n"], kern))
+        seeds.append(c["torch_seed"])
+    for in_flight in (2, 4):
+        res = basq_amd.recombination_many(calls, dev, in_flight=in_flight, seeds=seeds)
+        for nm, (idx, w) in zip(names, res):
+            fx = load_golden(nm)
+            assert idx.cpu().tolist() == fx["idx"], (nm, in_flight)
+            gw = torch.tensor(fx["w"], dtype=torch.float64)
+            assert ((w.cpu() - gw).abs() / gw).max().item() <= 1e-6
