@@ -90,7 +90,7 @@ def _slots(device, n):
     return out
 
 
-def _run_many(jobs, device, comm, in_flight):
+def _run_many(jobs, device, comm, in_flight, timings=None):
     jobs = list(jobs)
     if not jobs:
         return []
@@ -104,10 +104,12 @@ def _run_many(jobs, device, comm, in_flight):
     for idx, w in res:                               # allocated on a slot's stream, handed to the caller's
         idx.record_stream(cur)
         w.record_stream(cur)
+    if timings is not None:                          # host clock at each batch's first launch and at its result
+        timings.extend((j.times.get("start"), j.times.get("done")) for j in jobs)
     return res
 
 
-def recombination_many(calls, device, in_flight: int = 2, seeds=None, traces=None):
+def recombination_many(calls, device, in_flight: int = 2, seeds=None, traces=None, timings=None):
     """Several INDEPENDENT recombinations with ``in_flight`` of them on the GPU at a time -> ``[(idx, w), ...]``.
 
     ``calls``: ``(pts_rec, pts_nys, num_pts, kernel)`` per recombination -- e.g. the two calls every BASQ iteration makes,
@@ -117,16 +119,17 @@ def recombination_many(calls, device, in_flight: int = 2, seeds=None, traces=Non
 
     Results are bit-identical to sequential ``recombination`` calls in the same order: the CPU global generator is
     consumed in call order (one ``torch.randn(m, num_pts - 1)`` each, as in the reference), and ``seeds[k]`` (optional)
-    is what ``torch.manual_seed(seeds[k])`` right before call k would be.
+    is what ``torch.manual_seed(seeds[k])`` right before call k would be.  ``timings`` (a list) receives one
+    ``(start, done)`` pair of host clock readings per call: the per-batch latency with company on the GPU.
     """
     jobs = []
     for k, (pts_rec, pts_nys, num_pts, kernel) in enumerate(calls):
         jobs.append(Job(pts_rec, 0, pts_rec.shape[0], pts_nys, int(num_pts), _as_kernel_object(kernel),
                         trace=None if traces is None else traces[k], seed=None if seeds is None else seeds[k]))
-    return _run_many(jobs, device, LocalComm(), in_flight)
+    return _run_many(jobs, device, LocalComm(), in_flight, timings)
 
 
-def recombination_many_sharded(calls, device, group=None, in_flight: int = 4, seeds=None):
+def recombination_many_sharded(calls, device, group=None, in_flight: int = 4, seeds=None, timings=None):
     """``recombination_many`` with every pool sharded over the ranks of ``group``: ``calls`` holds
     ``(pts_local, gid0, n_total, pts_nys, num_pts, kernel)`` per recombination (see ``recombination_sharded``).
 
@@ -140,4 +143,4 @@ def recombination_many_sharded(calls, device, group=None, in_flight: int = 4, se
     for k, (pts_local, gid0, n_total, pts_nys, num_pts, kernel) in enumerate(calls):
         jobs.append(Job(pts_local, int(gid0), int(n_total), pts_nys, int(num_pts), _as_kernel_object(kernel),
                         seed=None if seeds is None else seeds[k]))
-    return _run_many(jobs, device, comm, in_flight)
+    return _run_many(jobs, device, comm, in_flight, timings)

@@ -146,10 +146,13 @@ def main():
                 calls.append((pts_local, pts_nys, n, kern) if (world == 1 and not force_dist)
                              else (pts_local, off, N, pts_nys, n, kern))
 
+            lat = []
+
             def many():
+                del lat[:]
                 if world == 1 and not force_dist:
-                    return basq_amd.recombination_many(calls, dev, in_flight=k_fl, seeds=seeds)
-                return basq_amd.recombination_many_sharded(calls, dev, in_flight=k_fl, seeds=seeds)
+                    return basq_amd.recombination_many(calls, dev, in_flight=k_fl, seeds=seeds, timings=lat)
+                return basq_amd.recombination_many_sharded(calls, dev, in_flight=k_fl, seeds=seeds, timings=lat)
 
             many()                                                   # warm-up: the slots' streams, buffers, workspaces
             barrier()
@@ -166,8 +169,10 @@ def main():
             for k in range(min(args.steps, len(pools_dev))):
                 i1, w1 = one_batch(k=k)
                 same = same and torch.equal(i1, res_c[k][0]) and torch.equal(w1, res_c[k][1])
+            lat_ms = sorted(1e3 * (b - a) for a, b in lat)           # first launch -> result, per batch (rank 0's host clock)
             concurrent[k_fl] = dict(in_flight=k_fl, value=args.steps / dtc, unit="batches/s", steps=args.steps,
-                                    ms_per_step=1e3 * dtc / args.steps, bit_identical_to_sequential=bool(same))
+                                    ms_per_step=1e3 * dtc / args.steps, latency_ms_median=lat_ms[len(lat_ms) // 2],
+                                    latency_ms_max=lat_ms[-1], bit_identical_to_sequential=bool(same))
 
     # ---- per-seed latencies (outside the timed region): one synchronised batch per pool seed, median reported ----
     per_seed_ms = []
