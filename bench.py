@@ -13,7 +13,7 @@ Rank 0 prints ONE JSON line.
 * N > 1     = the SAME batch with the pool sharded over the ranks (strong scaling; one small all-gather per round,
               stream-ordered: no host wait per round on any rank count);
 * value     = steps one after the other (each call returns before the next starts: the reference's synchronous call);
-              ``value_concurrent2`` (``concurrent`` object) = the same K steps with TWO independent batches in flight
+              ``value_concurrent2`` (``concurrent`` object) = max(K, 12) of the same steps with TWO independent batches in flight
               (``basq_amd.recombination_many``: the reference's own pair, selection + quadrature, ``BASQ/_basq.py:82-88,
               104-106``), results bit-identical to the sequential runs; ``value_concurrent3`` on one GPU, ``value_concurrent4`` on
               multi-GPU lines;
@@ -140,8 +140,9 @@ def main():
     concurrent = {}
     if not (args.no_concurrent or args.no_roofline_batch):
         for k_fl in ([2, 3] if world == 1 and not force_dist else [2, 4]):
-            calls, seeds = [], [1] * args.steps
-            for k in range(args.steps):
+            n_c = max(args.steps, 12)                                # enough steps for the pipeline's fill and drain not to dominate
+            calls, seeds = [], [1] * n_c
+            for k in range(n_c):
                 pts_nys, pts_local = pools_dev[k % len(pools_dev)]
                 calls.append((pts_local, pts_nys, n, kern) if (world == 1 and not force_dist)
                              else (pts_local, off, N, pts_nys, n, kern))
@@ -166,12 +167,12 @@ def main():
                 dtc = float(tt.item())
             # every pipelined result against the sequential run of the same step (same pool, same seed): bit for bit
             same = True
-            for k in range(min(args.steps, len(pools_dev))):
+            for k in range(min(n_c, len(pools_dev))):
                 i1, w1 = one_batch(k=k)
                 same = same and torch.equal(i1, res_c[k][0]) and torch.equal(w1, res_c[k][1])
             lat_ms = sorted(1e3 * (b - a) for a, b in lat)           # first launch -> result, per batch (rank 0's host clock)
-            concurrent[k_fl] = dict(in_flight=k_fl, value=args.steps / dtc, unit="batches/s", steps=args.steps,
-                                    ms_per_step=1e3 * dtc / args.steps, latency_ms_median=lat_ms[len(lat_ms) // 2],
+            concurrent[k_fl] = dict(in_flight=k_fl, value=n_c / dtc, unit="batches/s", steps=n_c,
+                                    ms_per_step=1e3 * dtc / n_c, latency_ms_median=lat_ms[len(lat_ms) // 2],
                                     latency_ms_max=lat_ms[-1], bit_identical_to_sequential=bool(same))
 
     # ---- per-seed latencies (outside the timed region): one synchronised batch per pool seed, median reported ----
