@@ -615,6 +615,10 @@ struct SqArgs {
     double outputscale, noise;
 };
 
+#ifndef BASQ_SQ_PF
+#define BASQ_SQ_PF 2            // prefetch depth (observation steps) of the squared-covariance block sums: 1 / 2 / 3 -> 78 / 66 / 78 ms per
+                                // config-5m batch (profiles/r03_z_wsabim_prefetch_depth_ab.txt; the one-step form of round 2: 74)
+#endif
 template <int KK, int FAM, int JT>
 __device__ __forceinline__ void sq_pair_accumulate(const double (&a)[JT][KK], const CandFrag<KK>& f0, const CandFrag<KK>& f1,
                                                    long long row0, long long row1, int kap0, int kap1, int jrow,
@@ -629,24 +633,41 @@ __device__ __forceinline__ void sq_pair_accumulate(const double (&a)[JT][KK], co
     const double* bp0 = Q.kobs + (long long)g * Q.ldk + row0;
     const double* bp1 = Q.kobs + (long long)g * Q.ldk + row1;
     const long long sa = 4 * Q.ldb, sb = 4 * Q.ldk;
-    double av[JT], b0 = bp0[0], b1 = bp1[0];
+    // Software pipeline, BASQ_SQ_PF observation steps deep: the fragments of step ko + PF are requested while step ko
+    // multiplies (JT + 2 loads feed 2 JT matrix instructions per step; the loads come from L2 -- B^T rows -- and, for the
+    // observation Gram block, from HBM).  Slots are indexed statically (the loop is unrolled PF-fold); steps past the end
+    // re-read the last step's fragments.
+    constexpr int PF = BASQ_SQ_PF;
+    double av[PF][JT], b0[PF], b1[PF];
+    const long long klast = Q.ko - 1;
 #pragma unroll
-    for (int jt = 0; jt < JT; ++jt) av[jt] = ap[jt * 16];
-    for (int ko = 0; ko < Q.ko; ++ko) {
-        const long long kn = (ko + 1 < Q.ko) ? (ko + 1) : ko;          // last trip re-reads its own fragments
-        double avn[JT];
+    for (int p = 0; p < PF; ++p) {
+        const long long kp_ = (p < Q.ko) ? p : klast;
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt) avn[jt] = ap[kn * sa + jt * 16];
-        const double b0n = bp0[kn * sb], b1n = bp1[kn * sb];
+        for (int jt = 0; jt < JT; ++jt) av[p][jt] = ap[kp_ * sa + jt * 16];
+        b0[p] = bp0[kp_ * sb];
+        b1[p] = bp1[kp_ * sb];
+    }
+    for (int ko = 0; ko < Q.ko; ko += PF) {
 #pragma unroll
-        for (int jt = 0; jt < JT; ++jt) {
-            E0[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[jt], b0, E0[jt], 0, 0, 0);
-            E1[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[jt], b1, E1[jt], 0, 0, 0);
+        for (int p = 0; p < PF; ++p) {
+            if (ko + p < Q.ko) {                                           // wave-uniform
+                double avc[JT];
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) avc[jt] = av[p][jt];
+                const double b0c = b0[p], b1c = b1[p];
+                const long long kn = (ko + p + PF < Q.ko) ? (ko + p + PF) : klast;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) av[p][jt] = ap[kn * sa + jt * 16];
+                b0[p] = bp0[kn * sb];
+                b1[p] = bp1[kn * sb];
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+                    E0[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(avc[jt], b0c, E0[jt], 0, 0, 0);
+                    E1[jt] = __builtin_amdgcn_mfma_f64_16x16x4f64(avc[jt], b1c, E1[jt], 0, 0, 0);
+                }
+            }
         }
-#pragma unroll
-        for (int jt = 0; jt < JT; ++jt) av[jt] = avn[jt];
-        b0 = b0n;
-        b1 = b1n;
     }
     const bool noisy = Q.noise != 0.0;
 #pragma unroll

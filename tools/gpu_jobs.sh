@@ -31,6 +31,7 @@ job_many_cfg5m()  { timeout -k 10 600 python tools/bench_many.py --case cfg5m_ws
 job_ab_lib()      { B=${AB_LIB:-basq_amd/csrc/libbasq_hip_jt2.so}; for i in 1 2 3; do for lib in basq_amd/csrc/libbasq_hip.so $B; do echo "== $lib" >> "$out/ab_lib.txt"; BASQ_HIP_LIB=$PWD/$lib timeout -k 10 120 python tools/bench_blocksum.py --reps 6 2>&1 | grep -v amdgpu.ids >> "$out/ab_lib.txt" || return 1; BASQ_HIP_LIB=$PWD/$lib timeout -k 10 120 python tools/bench_blocksum.py --family matern52 --d 32 --n 200 --reps 3 2>&1 | grep -v amdgpu.ids >> "$out/ab_lib.txt" || return 1; done; done; cat "$out/ab_lib.txt"; BASQ_HIP_LIB=$PWD/$B timeout -k 10 900 python -m pytest tests -x -q -m gpu -k "golden or fuzz or moment" > "$out/ab_lib_tests.log" 2>&1; rc=$?; tail -3 "$out/ab_lib_tests.log"; return $rc; }
 job_fuzz()        { ( timeout -k 10 500 python tools/fuzz_async.py 5 80 2>&1 | grep -v amdgpu.ids | tail -4; timeout -k 10 500 python tools/fuzz_structured.py 11 120 2>&1 | grep -v "amdgpu.ids\|Warning\|warn" | tail -8 ) > "$out/fuzz.txt" 2>&1; cat "$out/fuzz.txt"; }
 job_ab_lib_bench() { B=${AB_LIB:-basq_amd/csrc/libbasq_hip_jt2.so}; for i in 1 2; do for lib in basq_amd/csrc/libbasq_hip.so $B; do echo "== $lib" >> "$out/ab_lib_bench.txt"; BASQ_HIP_LIB=$PWD/$lib timeout -k 10 200 python bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-concurrent 2>/dev/null | cut -c1-260 >> "$out/ab_lib_bench.txt" || return 1; done; done; cat "$out/ab_lib_bench.txt"; }
+job_ab_sqpf()     { for i in 1 2; do for lib in libbasq_hip.so libbasq_hip_pf2.so libbasq_hip_pf3.so; do echo "== $lib" >> "$out/ab_sqpf.txt"; BASQ_HIP_LIB=$PWD/basq_amd/csrc/$lib timeout -k 10 200 python tools/bench_configs.py --only cfg5m_wsabim_5e5 --reps 4 2>&1 | grep -v amdgpu.ids | cut -c1-100 >> "$out/ab_sqpf.txt" || return 1; done; done; cat "$out/ab_sqpf.txt"; BASQ_HIP_LIB=$PWD/basq_amd/csrc/libbasq_hip_pf2.so timeout -k 10 600 python -m pytest tests -x -q -m gpu -k "wsabim or blocksum_sq" 2>&1 | tail -2; }
 job_ab_late()     { timeout -k 10 400 python tools/ab_engine.py LATE_CLASSES 2 3 0 4 5 --reps 8 --visits 3 2>&1 | grep -v amdgpu.ids > "$out/ab_late_classes.txt"; rc=$?; cat "$out/ab_late_classes.txt"; return $rc; }
 job_opaque_cfg4() { timeout -k 10 1100 python tools/bench_opaque_cfg4.py > "$out/opaque_cfg4.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/opaque_cfg4.txt" | cut -c1-250; return $rc; }
 
