@@ -385,8 +385,13 @@ __device__ __forceinline__ void tile_accumulate(const double (&a)[JT][KK], const
     }
 }
 
+#ifndef BASQ_BS_WAVES
+#define BASQ_BS_ATTR
+#else
+#define BASQ_BS_ATTR __attribute__((amdgpu_waves_per_eu(BASQ_BS_WAVES, BASQ_BS_WAVES)))
+#endif
 template <int KK, int FAM, int JT, int XS>
-__global__ void __launch_bounds__(256) blocksum_kernel(const BlocksumArgs A_in) {
+__global__ void __launch_bounds__(256) BASQ_BS_ATTR blocksum_kernel(const BlocksumArgs A_in) {
     constexpr int KP = KK * 4;
     BlocksumArgs A = A_in;
     if (A.geo) blocksum_apply_geo<KP>(A);
