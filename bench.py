@@ -199,6 +199,41 @@ def main():
     bytes_alg = sum(info["R"] * (8 * d + 16) + 8 * info["m"] * d for _, _, info in tr.kernel_events)
     achieved_tf = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
 
+    # ---- the same kernel in STEADY STATE: the round-1 class launch repeated back to back.  Inside a batch that launch opens on
+    #      a chip that clocked down during the previous batch's chain of single-work-group reductions (tools/idle_probe.py:
+    #      6.35 ms back to back, 7.5-7.8 ms after a chain or >= 10 ms of idle time); `achieved` above is the in-situ figure.
+    steady = None
+    if not args.no_roofline_batch and world == 1 and not force_dist:
+        from basq_amd._ops import HipOps
+        from basq_amd._partition import RoundGeometry
+
+        ops = HipOps(dev)
+        pts_nys, pts_local = pools_dev[0]
+        spec = kern.spec(d)
+        cen = ops.col_mean(pts_nys)
+        pa, pb = ops.pack(spec, pts_nys, cen, 0, pad_rows_to=64), ops.pack(spec, pts_local, cen, 1)
+        mu0, _ = ops.init_state(N, 0, N)
+        S2 = 2 * n
+        geo0 = RoundGeometry.of(N, S2)
+        C0 = 16
+        Rr = (geo0.nb // C0) * C0 * S2
+        if Rr > 0:
+            run = lambda: ops.blocksum(spec, pa, m, pb, mu0, None, Rr, 0, geo0.n_full, S2, C0, class_mod=C0)   # noqa: E731
+            run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 4
+            tf = float(Rr) * m * (3 * d + 3) / (ms * 1e-3) / 1e12
+            steady = dict(achieved=tf, frac=tf / PEAK_FP64_VECTOR_TFLOPS, ms_per_launch=ms, pairs_per_launch=float(Rr) * m,
+                          note="the 16-class round-1 launch repeated back to back (chip at its sustained clock); inside a batch "
+                               "the same launch starts on a chip that clocked down during the preceding chain of "
+                               "single-work-group reductions: profiles/r04_h_block_sums_after_idle_or_chain.txt")
+        del pa, pb, mu0
+
     # Hardware counters of the block-sum launches of one batch: rocprofv3 --pmc passes of THIS bench command (one counter
     # group per pass, tools/gpu_jobs.sh pmc -> tools/pmc_summary.py), committed with the commit they were taken on.
     # FETCH_SIZE / WRITE_SIZE in KiB; the kernel's loads are 8 B per lane (not the 16-B-per-lane streams whose gfx950
@@ -295,6 +330,7 @@ def main():
                 "fp64_pipe_busy_pmc": pmc_rec.get("fp64_pipe_busy") if pmc_rec else None,
                 "counters_source": (f"profiles/r03_pmc.json (commit {pmc_rec.get('commit')}, {pmc_rec.get('source')}); bytes per "
                                     "batch from the counters, time from this run's HIP events") if pmc_rec else None,
+                "steady_state": steady,
                 "launches_per_batch": k_launches, "kernel_ms_per_batch": k_ms, "pairs_per_batch": k_pairs,
                 "reference_pairs_per_batch": ref_pairs,
                 "whole_batch_TFLOPs_by_reference_count": ref_pairs * (3 * d + 3) / (dt / args.steps) / 1e12,
