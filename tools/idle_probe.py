@@ -6,6 +6,9 @@ The 14-class launch of a headline batch back to back, after 2 / 10 / 50 / 200 ms
 and right after 14 x (null space + elimination), the chain that ends every batch.  Finding (profiles/r04_h_*): 6.35 ms back to
 back, 7.5-7.8 ms after >= 10 ms of idle time OR after the 6-ms chain: the chip clocks down while one CU works and the block sums
 that follow pay ~1.2 ms for the ramp.  Batches in flight keep it loaded (part of what recombination_many gains).
+The last block looks at the shape of the effect with eight short launches (two classes, 1.2 ms each) after a chain: those
+are NOT slower than back to back -- the penalty belongs to the long, chip-filling launch, not to the first millisecond after
+the chain (no counter for the shader clock is readable from here; the mechanism is not pinned down).
 """
 import os, sys, time, torch
 sys.path.insert(0, '/root/repo')
@@ -61,3 +64,17 @@ for _ in range(4):
     torch.cuda.current_stream().wait_stream(side)
     ts.append(round(run(14), 3))
 print("chain with a filler launch beside it, then 14 classes:", ts)
+# the shape of the ramp: after a chain, eight launches of two classes each (~0.95 ms of work per launch at full speed)
+def run_events(nch, k):
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(k + 1)]
+    evs[0].record()
+    for i in range(k):
+        ops.blocksum(spec, A, m, B, mu, None, Rr, 0, geo.n_full, S, nch, class_mod=16)
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    return [round(evs[i].elapsed_time(evs[i + 1]), 3) for i in range(k)]
+torch.cuda.synchronize(); run_events(2, 8)
+print("back to back, 8 x 2 classes:", run_events(2, 8))
+for _ in range(3):
+    torch.cuda.synchronize(); chain()
+    print("after a chain,  8 x 2 classes:", run_events(2, 8))
