@@ -766,13 +766,21 @@ class FusedSums:
         """One block-sum launch over the local positions [p_lo, p_hi)."""
         b, ops = self.b, self.b.ops
         ev0 = ops.record_event() if self._timing() else None
+        clk = None
+        if ev0 is not None and b.trace.sample_clock is not None and class_mod > 0:
+            # one wave on a second stream, released by ev0: samples the clock every 250 us for the next 8 ms
+            side = b.trace.sample_clock
+            side.wait_event(ev0)
+            clk = side.shader_clock_mhz(32, 250)
         ops.blocksum(b.spec, b.nys_ext, b.m_ext, b.cand[p_lo:], b.mu[p_lo:], None if b.wx is None else b.wx[p_lo:],
                      p_hi - p_lo, b.off + p_lo, geo_.n_full, S_, n_ch, out=out, class_mod=class_mod, class0=class0)
         if ev0 is not None and p_hi > p_lo:
             # pairs this launch evaluates: one class launch covers n_ch of class_mod classes of its range
             frac = (n_ch / class_mod) if class_mod else 1.0
-            b.trace.kernel_events.append((ev0, ops.record_event(), dict(pairs=float(p_hi - p_lo) * b.m_ext * frac,
-                                                                       R=(p_hi - p_lo) * frac, m=b.m_ext, S=S_, chunks=n_ch)))
+            info = dict(pairs=float(p_hi - p_lo) * b.m_ext * frac, R=(p_hi - p_lo) * frac, m=b.m_ext, S=S_, chunks=n_ch)
+            b.trace.kernel_events.append((ev0, ops.record_event(), info))
+            if clk is not None:
+                info["clock_mhz"] = clk
 
     def timed_geo(self, r, mode, frac, launch):
         """A descriptor-driven launch; its pair count is filled in once the descriptor table has been read."""

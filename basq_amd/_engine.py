@@ -76,6 +76,7 @@ class EngineTrace:
     keep_tensors: bool = False
     time_kernels: bool = False                      # record HIP events around every block-sum launch
     kernel_events: list = field(default_factory=list)   # (start_evt, end_evt, dict(pairs=, R=, m=, S=))
+    sample_clock: object = None                     # time_kernels: a HipOps on a SECOND stream -> shader clock beside each class launch
     host_sync: bool = True                          # synchronise around phases to attribute host timers
 
     def add_time(self, key, dt):

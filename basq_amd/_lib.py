@@ -18,7 +18,7 @@ BASQ_OK = 0
 FAMILY = {"rbf": 0, "matern52": 1, "matern32": 2}
 ROLE_A, ROLE_B = 0, 1
 MAX_DIM = 38
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class KernelSpecC(C.Structure):
@@ -33,6 +33,7 @@ SIGNATURES = {
     "basq_strerror": (C.c_char_p, [C.c_int]),
     "basq_abi_version": (C.c_int, []),
     "basq_kp": (C.c_int, [C.c_int]),
+    "basq_shader_clock_mhz": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "basq_col_mean_f64": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp]),
     "basq_pack_points_f64": (C.c_int, [_specp, _vp, _i64, _vp, C.c_int, _vp, _vp]),
     "basq_gram_f64": (C.c_int, [_specp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),

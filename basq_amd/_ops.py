@@ -90,6 +90,13 @@ class HipOps:
         check(min(kp, 0), "basq_kp")
         return kp
 
+    def shader_clock_mhz(self, n=1, period_us=20):
+        """-> [n] device tensor: the shader clock over each of the next n periods on THIS stream (measurement aid: bench.py
+        runs it on a second stream beside the block sums)."""
+        out = self.empty(n)
+        check(self.lib.basq_shader_clock_mhz(_ptr(out), int(n), int(period_us), self._stream()), "basq_shader_clock_mhz")
+        return out
+
     # -- kernels -----------------------------------------------------------------------------
     def col_mean(self, X):
         self._chk(X)

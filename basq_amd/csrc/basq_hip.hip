@@ -385,6 +385,13 @@ __device__ __forceinline__ void tile_accumulate(const double (&a)[JT][KK], const
     }
 }
 
+// Blocks of prefetch distance for the candidate rows of the block sums: 2 while the third fragment keeps the kernel at
+// three waves per SIMD (<= 170 registers: KP <= 32), 1 for the wider rows (KK = 9, 10: 214-222 registers with a third
+// fragment).  Measured at the headline shape: 6.36 -> 6.20 ms per 14-class launch (profiles/r04_k_blocksum_prefetch2.txt).
+#ifndef BASQ_BS_PREFETCH
+#define BASQ_BS_PREFETCH 0      // 0 = by KK (A/B builds: -DBASQ_BS_PREFETCH=1 or 2)
+#endif
+#define BASQ_BS_PF_FOR(KK) (BASQ_BS_PREFETCH ? BASQ_BS_PREFETCH : ((KK) <= 8 ? 2 : 1))
 #ifndef BASQ_BS_WAVES
 #define BASQ_BS_ATTR
 #else
@@ -469,30 +476,55 @@ __global__ void __launch_bounds__(256) BASQ_BS_ATTR blocksum_kernel(const Blocks
             const double* mp = A.mu + p0;
             const double* xp = A.wx ? (A.wx + p0) : nullptr;
             const long long rstep = bstep * (long long)A.S * KP, mstep = bstep * (long long)A.S;
-            CandFrag<KK> cur, nxt;
+            if constexpr (BASQ_BS_PF_FOR(KK) == 2) {
+                // candidate rows requested TWO blocks ahead: every row is read once, from HBM or the far L2, and a block of work
+                // (~1 us with three waves per SIMD) does not always cover that; a third fragment costs 10 registers
+                CandFrag<KK> cur, nxt, nx2;
+                auto fetch = [&](CandFrag<KK>& f, const double* r, const double* mq, const double* xq) {
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk) cur.b[kk] = rp[kk * 4];
-            cur.wm = mp[0];
-            cur.w = xp ? cur.wm * xp[0] : cur.wm;
-            for (; i < bF1; i += bstep) {
-                const bool more = (i + bstep < bF1);
-                const double* rn = more ? (rp + rstep) : rp;                     // last trip re-reads its own row
-                const double* mn = more ? (mp + mstep) : mp;
-#pragma unroll
-                for (int kk = 0; kk < KK; ++kk) nxt.b[kk] = rn[kk * 4];
-                nxt.wm = mn[0];
-                if (xp) {
-                    const double* xn = more ? (xp + mstep) : xp;
-                    nxt.w = nxt.wm * xn[0];
-                    xp = xn;
-                } else {
-                    nxt.w = nxt.wm;
+                    for (int kk = 0; kk < KK; ++kk) f.b[kk] = r[kk * 4];
+                    f.wm = mq[0];
+                    f.w = xq ? f.wm * xq[0] : f.wm;
+                };
+                const long long nblk = (bF1 - i + bstep - 1) / bstep;               // blocks of the fast range
+                fetch(cur, rp, mp, xp);
+                const long long o1 = (nblk > 1) ? 1 : 0;
+                fetch(nxt, rp + o1 * rstep, mp + o1 * mstep, xp ? xp + o1 * mstep : nullptr);
+                for (long long t = 0; t < nblk; ++t) {
+                    const long long o2 = (t + 2 < nblk) ? (t + 2) : (nblk - 1);     // the last trips re-read the last row
+                    fetch(nx2, rp + o2 * rstep, mp + o2 * mstep, xp ? xp + o2 * mstep : nullptr);
+                    tile_accumulate<KK, FAM, JT, XS>(a, cur, acc, ek, exp_tab);
+                    tot += cur.wm;
+                    cur = nxt;
+                    nxt = nx2;
                 }
-                tile_accumulate<KK, FAM, JT, XS>(a, cur, acc, ek, exp_tab);
-                tot += cur.wm;
-                cur = nxt;
-                rp = rn;
-                mp = mn;
+                i += nblk * bstep;
+            } else {
+                CandFrag<KK> cur, nxt;
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) cur.b[kk] = rp[kk * 4];
+                cur.wm = mp[0];
+                cur.w = xp ? cur.wm * xp[0] : cur.wm;
+                for (; i < bF1; i += bstep) {
+                    const bool more = (i + bstep < bF1);
+                    const double* rn = more ? (rp + rstep) : rp;                     // last trip re-reads its own row
+                    const double* mn = more ? (mp + mstep) : mp;
+#pragma unroll
+                    for (int kk = 0; kk < KK; ++kk) nxt.b[kk] = rn[kk * 4];
+                    nxt.wm = mn[0];
+                    if (xp) {
+                        const double* xn = more ? (xp + mstep) : xp;
+                        nxt.w = nxt.wm * xn[0];
+                        xp = xn;
+                    } else {
+                        nxt.w = nxt.wm;
+                    }
+                    tile_accumulate<KK, FAM, JT, XS>(a, cur, acc, ek, exp_tab);
+                    tot += cur.wm;
+                    cur = nxt;
+                    rp = rn;
+                    mp = mn;
+                }
             }
         }
         // masked epilogue blocks
@@ -3440,6 +3472,33 @@ int basq_abi_version(void) { return BASQ_ABI_VERSION; }
 int basq_kp(int d) {
     if (d < 1 || d > BASQ_MAX_DIM) return BASQ_EINVAL;
     return ((d + 2 + 3) / 4) * 4;
+}
+
+// Measurement aid (bench.py's roofline): the shader clock over the next n * period_us microseconds, one wave counting
+// s_memtime cycles per period of the constant 100-MHz s_memrealtime.  Launched on a SECOND stream beside the kernel of
+// interest (one 64-thread work-group fits next to anything), it sees the clock that kernel runs at: under a full fp64 load
+// that follows >= 5 ms without one (a single-work-group reduction chain counts as without) the power manager holds the chip
+// at ~2.05 GHz and raises it by only ~20 MHz per ms (tools/clock_probe.hip) -- an otherwise idle chip reads 2.43 GHz.
+__global__ void shader_clock_kernel(double* out, int n, unsigned long long period_ticks) {
+    unsigned long long r0 = wall_clock64(), c0 = clock64();
+    for (int k = 0; k < n; ++k) {
+        unsigned long long r1 = r0;
+        while (r1 - r0 < period_ticks) {
+            __builtin_amdgcn_s_sleep(8);
+            r1 = wall_clock64();
+        }
+        const unsigned long long c1 = clock64();
+        if (threadIdx.x == 0) out[k] = 100.0 * (double)(c1 - c0) / (double)(r1 - r0);
+        r0 = r1;
+        c0 = c1;
+    }
+}
+
+int basq_shader_clock_mhz(double* out, int n, int period_us, void* stream) {
+    if (!out || n < 1 || period_us < 1 || (long long)n * period_us > 1000000) return BASQ_EINVAL;   // at most 1 s of sampling
+    hipLaunchKernelGGL(shader_clock_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, out, n, 100ull * period_us);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
 }
 
 int basq_col_mean_f64(const double* X, int64_t n, int d, double* mean, void* stream) {

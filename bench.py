@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--no-roofline-batch", action="store_true", help="skip the traced batch, the per-seed latencies and the "
                     "pipelined runs (counter passes: tools/gpu_jobs.sh pmc)")
     ap.add_argument("--no-concurrent", action="store_true", help="skip the runs with several batches in flight")
+    ap.add_argument("--plain", action="store_true", help="for kernel statistics under rocprofv3: the timed loop, the per-seed "
+                    "batches and the traced batch only -- no batches in flight, no back-to-back repetition of the round-1 "
+                    "launch, no clock sampler (every block-sum launch in the profile then belongs to a batch)")
     return ap.parse_args()
 
 
@@ -138,7 +141,7 @@ def main():
 
     # ---- several batches in flight (outside the timed region of `value`): the same K steps through recombination_many ----
     concurrent = {}
-    if not (args.no_concurrent or args.no_roofline_batch):
+    if not (args.no_concurrent or args.no_roofline_batch or args.plain):
         for k_fl in ([2, 3] if world == 1 and not force_dist else [2, 4]):
             n_c = max(args.steps, 12)                                # enough steps for the pipeline's fill and drain not to dominate
             calls, seeds = [], [1] * n_c
@@ -186,9 +189,27 @@ def main():
 
     # ---- kernel-level roofline: one extra traced batch (HIP events on the launch stream, no host syncs: the batch stays on
     #      the code path the timed steps take -- descriptor-driven rounds -- and reports its launches after the fact) ----
-    tr = basq_amd.EngineTrace(time_kernels=not args.no_roofline_batch, host_sync=False)
+    from basq_amd._ops import HipOps
+
+    clock_ops = HipOps(dev, stream=torch.cuda.Stream(device=dev))
+    tr = basq_amd.EngineTrace(time_kernels=not args.no_roofline_batch, sample_clock=None if args.plain else clock_ops,
+                              host_sync=False)
     one_batch(tr)
     torch.cuda.synchronize()
+    # the shader clock the class launches ran at: one wave on a second stream samples it every 250 us while the launch runs.
+    # A full fp64 load that follows the previous batch's chain of single-work-group reductions opens at ~2.05 GHz and gains
+    # only ~20 MHz per ms (tools/clock_probe.hip, profiles/r04_l_shader_clock_after_idle.txt)
+    clk, clk_w = [], 0.0
+    for a, b, info in tr.kernel_events:
+        if "clock_mhz" in info:
+            w_ms = a.elapsed_time(b)
+            series = info.pop("clock_mhz").tolist()[: max(1, min(32, int(w_ms / 0.25)))]      # the samples inside the launch
+            mean = sum(series) / len(series)
+            clk.append(dict(classes=info["chunks"], ms=round(w_ms, 3), mhz_mean=round(mean), mhz_first=round(series[0]),
+                            mhz_last=round(series[-1])))
+            clk_w += mean * w_ms
+    clk_ms = sum(c["ms"] for c in clk)
+    clock_in_situ = clk_w / clk_ms if clk_ms > 0 else None              # MHz, time-weighted over the class launches
     k_ms = sum(a.elapsed_time(b) for a, b, _ in tr.kernel_events)
     k_pairs = sum(info["pairs"] for _, _, info in tr.kernel_events)
     k_launches = len(tr.kernel_events)
@@ -203,8 +224,7 @@ def main():
     #      a chip that clocked down during the previous batch's chain of single-work-group reductions (tools/idle_probe.py:
     #      6.35 ms back to back, 7.5-7.8 ms after a chain or >= 10 ms of idle time); `achieved` above is the in-situ figure.
     steady = None
-    if not args.no_roofline_batch and world == 1 and not force_dist:
-        from basq_amd._ops import HipOps
+    if not (args.no_roofline_batch or args.plain) and world == 1 and not force_dist:
         from basq_amd._partition import RoundGeometry
 
         ops = HipOps(dev)
@@ -226,12 +246,20 @@ def main():
                 run()
             e1.record()
             torch.cuda.synchronize()
+            # one more launch with the clock sampled beside it
+            ev = ops.record_event()
+            clock_ops.wait_event(ev)
+            clk_s = clock_ops.shader_clock_mhz(max(1, int(e0.elapsed_time(e1) / 4 / 0.25)), 250)
+            run()
+            torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / 4
             tf = float(Rr) * m * (3 * d + 3) / (ms * 1e-3) / 1e12
             steady = dict(achieved=tf, frac=tf / PEAK_FP64_VECTOR_TFLOPS, ms_per_launch=ms, pairs_per_launch=float(Rr) * m,
+                          shader_clock_MHz=float(clk_s.mean().item()),
                           note="the 16-class round-1 launch repeated back to back (chip at its sustained clock); inside a batch "
                                "the same launch starts on a chip that clocked down during the preceding chain of "
-                               "single-work-group reductions: profiles/r04_h_block_sums_after_idle_or_chain.txt")
+                               "single-work-group reductions: profiles/r04_h_block_sums_after_idle_or_chain.txt, "
+                               "profiles/r04_l_shader_clock_after_idle.txt")
         del pa, pb, mu0
 
     # Hardware counters of the block-sum launches of one batch: rocprofv3 --pmc passes of THIS bench command (one counter
@@ -331,6 +359,10 @@ def main():
                 "counters_source": (f"profiles/r03_pmc.json (commit {pmc_rec.get('commit')}, {pmc_rec.get('source')}); bytes per "
                                     "batch from the counters, time from this run's HIP events") if pmc_rec else None,
                 "steady_state": steady,
+                # the clock the class launches (most of kernel_ms_per_batch) actually had, and the fraction against the fp64
+                # peak AT that clock: what the kernel leaves on the table, as opposed to what the power manager withholds
+                "shader_clock_MHz_in_situ": clock_in_situ, "shader_clock_samples": clk or None,
+                "frac_at_in_situ_clock": (achieved_tf / (PEAK_FP64_VECTOR_TFLOPS * clock_in_situ / 2400.0)) if clock_in_situ else None,
                 "launches_per_batch": k_launches, "kernel_ms_per_batch": k_ms, "pairs_per_batch": k_pairs,
                 "reference_pairs_per_batch": ref_pairs,
                 "whole_batch_TFLOPs_by_reference_count": ref_pairs * (3 * d + 3) / (dt / args.steps) / 1e12,

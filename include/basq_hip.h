@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BASQ_ABI_VERSION 10
+#define BASQ_ABI_VERSION 11
 
 /* error codes */
 #define BASQ_OK            0
@@ -59,6 +59,11 @@ typedef struct basq_kernel_spec {
 
 const char* basq_strerror(int code);
 int         basq_abi_version(void);
+
+/* Measurement aid, no counterpart in the reference: the shader clock in MHz over each of the next n periods of period_us
+ * microseconds -> out[n] (device).  bench.py launches it on a second stream beside the dominant kernel: the clock a launch
+ * runs at inside a batch is what its roofline is set by.  n * period_us <= 1e6. */
+int basq_shader_clock_mhz(double* out, int n, int period_us, void* stream);
 
 /* KP: packed row length (multiple of 4, >= d + 2). */
 int basq_kp(int d);

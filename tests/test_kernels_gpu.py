@@ -828,3 +828,13 @@ def test_pack_points_vs_standin(hip_ops, d, n):
             got = hip_ops.pack(spec, hip_ops.to_device(X), None if center is None else hip_ops.to_device(center), role).cpu()
             assert got.shape == want.shape
             assert (got - want).abs().max().item() <= 1e-14 * max(1.0, want.abs().max().item())
+
+
+def test_shader_clock_sampler(hip_ops):
+    """The measurement aid behind ``roofline.shader_clock_MHz_in_situ``: plausible MHz, one value per period."""
+    clk = hip_ops.shader_clock_mhz(4, 50)
+    torch.cuda.synchronize()
+    assert clk.shape == (4,)
+    assert bool(((clk > 500.0) & (clk < 3500.0)).all()), clk.tolist()
+    with pytest.raises(Exception):
+        hip_ops.shader_clock_mhz(0, 50)

@@ -32,6 +32,7 @@ job_ab_lib()      { B=${AB_LIB:-basq_amd/csrc/libbasq_hip_jt2.so}; for i in 1 2 
 job_fuzz()        { ( timeout -k 10 500 python tools/fuzz_async.py 5 80 2>&1 | grep -v amdgpu.ids | tail -4; timeout -k 10 500 python tools/fuzz_structured.py 11 120 2>&1 | grep -v "amdgpu.ids\|Warning\|warn" | tail -8 ) > "$out/fuzz.txt" 2>&1; cat "$out/fuzz.txt"; }
 job_ab_lib_bench() { B=${AB_LIB:-basq_amd/csrc/libbasq_hip_jt2.so}; for i in 1 2; do for lib in basq_amd/csrc/libbasq_hip.so $B; do echo "== $lib" >> "$out/ab_lib_bench.txt"; BASQ_HIP_LIB=$PWD/$lib timeout -k 10 200 python bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-concurrent 2>/dev/null | cut -c1-260 >> "$out/ab_lib_bench.txt" || return 1; done; done; cat "$out/ab_lib_bench.txt"; }
 job_ab_sqpf()     { for i in 1 2; do for lib in libbasq_hip.so libbasq_hip_pf2.so libbasq_hip_pf3.so; do echo "== $lib" >> "$out/ab_sqpf.txt"; BASQ_HIP_LIB=$PWD/basq_amd/csrc/$lib timeout -k 10 200 python tools/bench_configs.py --only cfg5m_wsabim_5e5 --reps 4 2>&1 | grep -v amdgpu.ids | cut -c1-100 >> "$out/ab_sqpf.txt" || return 1; done; done; cat "$out/ab_sqpf.txt"; BASQ_HIP_LIB=$PWD/basq_amd/csrc/libbasq_hip_pf2.so timeout -k 10 600 python -m pytest tests -x -q -m gpu -k "wsabim or blocksum_sq" 2>&1 | tail -2; }
+job_ab_idle()     { B=${AB_LIB:-basq_amd/csrc/libbasq_hip_bpf2.so}; for i in 1 2; do for lib in basq_amd/csrc/libbasq_hip.so $B; do echo "== $lib" >> "$out/ab_idle.txt"; BASQ_HIP_LIB=$PWD/$lib timeout -k 10 200 python tools/idle_probe.py 2>&1 | grep -v amdgpu.ids | cut -c1-200 >> "$out/ab_idle.txt" || return 1; done; done; cat "$out/ab_idle.txt"; }
 job_ab_late()     { timeout -k 10 400 python tools/ab_engine.py LATE_CLASSES 2 3 0 4 5 --reps 8 --visits 3 2>&1 | grep -v amdgpu.ids > "$out/ab_late_classes.txt"; rc=$?; cat "$out/ab_late_classes.txt"; return $rc; }
 job_opaque_cfg4() { timeout -k 10 1100 python tools/bench_opaque_cfg4.py > "$out/opaque_cfg4.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/opaque_cfg4.txt" | cut -c1-250; return $rc; }
 
@@ -43,7 +44,7 @@ prof() {
     head -16 "$out/prof_$name/${name}_kernel_stats.csv" 2>/dev/null | cut -c1-160
     return $rc
 }
-job_prof_bench()  { prof bench bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-concurrent && python tools/trace_gaps.py "$(ls $out/prof_bench/*kernel_trace.csv | head -1)" > "$out/trace_gaps_bench.txt" 2>&1; rc=$?; head -6 "$out/trace_gaps_bench.txt" | cut -c1-200; return $rc; }
+job_prof_bench()  { prof bench bench.py --steps 10 --warmup 2 --no-cpu-baseline --plain && python tools/trace_gaps.py "$(ls $out/prof_bench/*kernel_trace.csv | head -1)" > "$out/trace_gaps_bench.txt" 2>&1; rc=$?; head -6 "$out/trace_gaps_bench.txt" | cut -c1-200; return $rc; }
 job_trace_round() { prof round bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-concurrent --no-roofline-batch && python tools/trace_round.py "$(ls $out/prof_round/*kernel_trace.csv | head -1)" --first 2 --count 2 > "$out/trace_round.txt" 2>&1; rc=$?; cat "$out/trace_round.txt" | cut -c1-140; return $rc; }
 job_prof_many()   { prof many tools/bench_many.py --batches 12 --inflight 2 --pipelined-only && python tools/trace_overlap.py --tail-fraction 0.7 "$(ls $out/prof_many/*kernel_trace.csv | head -1)" > "$out/trace_overlap_many.txt" 2>&1; rc=$?; head -30 "$out/trace_overlap_many.txt" | cut -c1-200; return $rc; }
 job_prof_concurrent() { prof conc tools/exp_concurrent.py --threads 2 --batches 6 && python tools/trace_overlap.py "$(ls $out/prof_conc/*kernel_trace.csv | head -1)" > "$out/trace_overlap_conc.txt" 2>&1; rc=$?; head -30 "$out/trace_overlap_conc.txt" | cut -c1-200; return $rc; }
