@@ -1682,6 +1682,51 @@ __device__ __forceinline__ double agent_load_f64(const double* p) {
     return __longlong_as_double((long long)__hip_atomic_load((basq_gu64*)p, BASQ_RLX_AGENT));
 }
 
+// Tagged granules: a double handed to another work-group as ONE 16-byte write-through store {tag, low word, tag, high word}.
+// Each 8-byte half carries the tag, so a reader that finds both tags equal to the epoch it waits for holds the value -- the
+// data is its own flag: no drain, no flag store, no second round trip (MI355X_MICROARCH.md, visibility: data-tagged
+// granules; 8-byte halves are the unit observed untorn).  Words are zeroed by the launcher before every launch; epochs
+// count steps within the launch and are never 0.
+typedef unsigned basq_v4u __attribute__((ext_vector_type(4)));
+// Same-XCD clusters: a PLAIN store leaves the granule in the XCD's L2, where a sibling's L1-bypassing load finds it in a
+// fraction of the time a write-through line takes to come back from the fabric (guide, "stores of each flavour").  Which
+// XCD a work-group runs on is not ours to choose, so the cluster checks it (cluster_shares_xcd) and falls back to
+// write-through stores when its members are spread; `local` is work-group uniform.
+__device__ __forceinline__ void granule_store(__amdgpu_buffer_rsrc_t rs, unsigned idx, unsigned tag, double v, bool local) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const basq_v4u g = {tag, (unsigned)b, tag, (unsigned)(b >> 32)};
+    if (local) __builtin_amdgcn_raw_buffer_store_b128(g, rs, (int)(idx * 16u), 0, 0);
+    else __builtin_amdgcn_raw_buffer_store_b128(g, rs, (int)(idx * 16u), 0, 16);
+}
+__device__ __forceinline__ basq_v4u granule_load(__amdgpu_buffer_rsrc_t rs, unsigned idx) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(idx * 16u), 0, 16);     // sc1: served by L2 / the fabric, never L1
+}
+__device__ __forceinline__ bool granule_ok(const basq_v4u g, unsigned tag) { return g.x == tag && g.z == tag; }
+__device__ __forceinline__ double granule_value(const basq_v4u g) {
+    return __longlong_as_double((long long)(((unsigned long long)g.w << 32) | (unsigned long long)g.y));
+}
+// One handshake per launch: every member publishes the XCD it runs on (agent-scope word, zeroed by the launcher) and reads
+// the others'.  -> true iff all NCU members share one XCD (a member that never answers counts as elsewhere).
+template <int NCU>
+__device__ __forceinline__ bool cluster_shares_xcd(unsigned* words, int cu, int* verdict_l) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        const unsigned mine = 0x100u | (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xfu);   // HW_REG_XCC_ID[3:0]
+        if (lane == 0) __hip_atomic_store((basq_gu32*)(words + cu), mine, BASQ_RLX_AGENT);
+        unsigned f = mine, spins = 0;
+        for (;;) {
+            f = (lane < NCU) ? __hip_atomic_load((basq_gu32*)(words + lane), BASQ_RLX_AGENT) : mine;
+            if (__all(f != 0u) || ++spins > (1u << 16)) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const bool same = __all(f == mine);
+        if (lane == 0) *verdict_l = same ? 1 : 0;
+    }
+    __syncthreads();
+    return *verdict_l != 0;
+}
+#define BASQ_GRANULE_SPIN_LIMIT (1u << 19)   // sweeps (~1 us each, with s_sleep after the first few) before a cluster gives up
+
 __device__ __forceinline__ int wave_min_i32(int v) {
     const int BIG = 0x7fffffff;
     v = min(v, __builtin_amdgcn_update_dpp(BIG, v, 0x111, 0xf, 0xf, false));
@@ -1769,8 +1814,14 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) car_eliminate_cluster_kernel(co
     const double INF = __builtin_huge_val();
     __shared__ __attribute__((aligned(16))) double ring_l[GLOBAL ? 2 : D * SLOT];
     __shared__ int count_l;
-    double* ring = GLOBAL ? (ws + 16) : ring_l;
-    int* count = GLOBAL ? (int*)ws : &count_l;     // NCU > 1: zeroed by the launcher (memset node ahead of the launch)
+    double* ring = ring_l;                          // one work-group: ring + counter word in LDS
+    int* count = &count_l;
+    // clusters: the ring holds tagged granules (tag = step + 1; every word zeroed by the launcher) -- a consumer sweeps the
+    // slot until all its tags match: no counter, no drain on the publishing side, one fabric trip per step
+    __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)(ws + 16), 0, GLOBAL ? (int)(D * SLOT * 16) : 0, 0x00020000);
+    __shared__ int local_l;
+    bool local = false;
+    if (GLOBAL) local = cluster_shares_xcd<NCU>((unsigned*)ws, cu, &local_l);
     if (!GLOBAL) {
         if (threadIdx.x == 0) count_l = 0;
         __syncthreads();
@@ -1808,31 +1859,66 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) car_eliminate_cluster_kernel(co
         const int lane_j = (j & 127) >> 1;
         const double rphij = (j == 0x7fffffff) ? 0.0 : readlane_f64(brphi, lane_j);
         const double phij = (j == 0x7fffffff) ? 0.0 : readlane_f64(bphi, lane_j);
-        double* slot = ring + (size_t)(kp % D) * SLOT;
+        const double hv = (lane == 0) ? wmin : (lane == 1) ? rphij : (lane == 2) ? phij : __longlong_as_double((long long)j);
+        if (GLOBAL) {
+            const unsigned gbase = (unsigned)(kp % D) * SLOT, tag = (unsigned)(kp + 1);
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            if (GLOBAL) agent_store_f64(slot + BASQ_PAIRCOL(k), r[k]);
-            else slot[BASQ_PAIRCOL(k)] = r[k];
+            for (int k = 0; k < NV; ++k) granule_store(grs, gbase + BASQ_PAIRCOL(k), tag, r[k], local);
+            if (lane < 4) granule_store(grs, gbase + NC + lane, tag, hv, local);
+        } else {
+            double* slot = ring + (size_t)(kp % D) * SLOT;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) slot[BASQ_PAIRCOL(k)] = r[k];
+            if (lane < 4) slot[NC + lane] = hv;
+            counter_publish<false>(count, kp + 1, lane);
         }
-        if (lane < 4) {
-            const double v = (lane == 0) ? wmin : (lane == 1) ? rphij : (lane == 2) ? phij : __longlong_as_double((long long)j);
-            if (GLOBAL) agent_store_f64(slot + NC + lane, v);
-            else slot[NC + lane] = v;
-        }
-        counter_publish<GLOBAL>(count, kp + 1, lane);
     };
     if (nrows > 0 && gw == 0) test_and_publish(a[0], 0);
     int status = 0;
     for (int k = 0; k < nrows; ++k) {
-        const int seen = counter_wait_gt<GLOBAL>(count, k);
-        if (seen >= BASQ_ABORT_COUNT) { status = 2; break; }
-        const double* slot = ring + (size_t)(k % D) * SLOT;
-        double phi[NV];
+        double phi[NV], hdr[4];
+        if (GLOBAL) {
+            const unsigned gbase = (unsigned)(k % D) * SLOT, tag = (unsigned)(k + 1);
+            basq_v4u g[NV], gh;
+            unsigned spins = 0;
+            bool bad = false;
+            // Only the owner of row k+1 is on the critical path: it sweeps the whole slot at once.  Thirty-one waves doing
+            // the same (9 KB per sweep each) slow the very store they wait for (1.05 vs 0.59 ms at 200 x 400); they watch the
+            // four header granules -- one 64-byte request per sweep -- and fetch the row once those carry the tag.
+            if (!(k + 1 < nrows && gw == (k + 1) % W)) {
+                for (;;) {
+                    gh = granule_load(grs, gbase + NC + (lane & 3));
+                    if (__all(granule_ok(gh, tag))) break;
+                    if (++spins > BASQ_GRANULE_SPIN_LIMIT) { bad = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            for (; !bad;) {
 #pragma unroll
-        for (int kk = 0; kk < NV; ++kk) phi[kk] = GLOBAL ? agent_load_f64(slot + BASQ_PAIRCOL(kk)) : slot[BASQ_PAIRCOL(kk)];
-        double hdr[4];
+                for (int kk = 0; kk < NV; ++kk) g[kk] = granule_load(grs, gbase + BASQ_PAIRCOL(kk));
+                gh = granule_load(grs, gbase + NC + (lane & 3));
+                bool ok = granule_ok(gh, tag);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) hdr[u] = GLOBAL ? agent_load_f64(slot + NC + u) : slot[NC + u];
+                for (int kk = 0; kk < NV; ++kk) ok = ok && granule_ok(g[kk], tag);
+                if (__all(ok)) break;
+                if (++spins > BASQ_GRANULE_SPIN_LIMIT) { bad = true; break; }   // never in a healthy run (wave-uniform)
+                if (spins > 16) __builtin_amdgcn_s_sleep(2);
+            }
+            if (bad) { status = 2; break; }       // this wave publishes nothing more: its siblings run into the same limit
+#pragma unroll
+            for (int kk = 0; kk < NV; ++kk) phi[kk] = granule_value(g[kk]);
+            const double hv = granule_value(gh);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) hdr[u] = readlane_f64(hv, u);
+        } else {
+            const int seen = counter_wait_gt<false>(count, k);
+            if (seen >= BASQ_ABORT_COUNT) { status = 2; break; }
+            const double* slot = ring + (size_t)(k % D) * SLOT;
+#pragma unroll
+            for (int kk = 0; kk < NV; ++kk) phi[kk] = slot[BASQ_PAIRCOL(kk)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) hdr[u] = slot[NC + u];
+        }
         const double aj = hdr[0], rphij = hdr[1], phij = hdr[2];
         const int j = __builtin_amdgcn_readfirstlane((int)__double_as_longlong(hdr[3]));
         if (j == 0x7fffffff) { status = 1; break; }               // uniform: no positive entry (the reference raises)
@@ -2421,10 +2507,15 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const dou
     __shared__ __attribute__((aligned(16))) double wpart_l[2 * WPG * MSG];   // [parity][local wave]: partial row | ssp
     __shared__ __attribute__((aligned(16))) double r1_l[2 * MSG];          // [parity]: row t+1 after G_t | its column-t entry
     __shared__ int abort_l;
-    // global (clusters): ws = [flags: NCU words in the first 128 B][2][NCU][MSG] work-group sums [2][MSG] row t+1
-    unsigned* flags = (unsigned*)ws;
-    double* gsum = GLOBAL ? (ws + 16) : nullptr;
-    double* gr1 = GLOBAL ? (gsum + 2 * NCU * MSG) : nullptr;
+    // global (clusters): ws = [16 unused doubles][2][NCU][MSG] granules of work-group sums [2][MSG] granules of row t+1
+    static_assert(!GLOBAL || NC == WPG * 64, "the exchange gives every thread of a work-group one column");
+    constexpr unsigned R1BASE = 2u * NCU * MSG;                      // granule index of the row t+1 messages
+    __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)(ws + 16), 0,
+                                                                   GLOBAL ? (int)((R1BASE + 2u * MSG) * 16u) : 0, 0x00020000);
+    if (threadIdx.x == 0) abort_l = 0;
+    __shared__ int local_l;
+    bool local = false;
+    if (GLOBAL) local = cluster_shares_xcd<NCU>((unsigned*)ws, cu, &local_l);
 
     double a[NG * 4][NV], cprev[NG * 4];
 #pragma unroll
@@ -2445,7 +2536,8 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const dou
     for (int t = -1; t + 1 < m; ++t) {
         const int par = (t + 1) & 1;
         double* my_msg = wpart_l + (size_t)(par * WPG + wv) * MSG;
-        double* r1buf = GLOBAL ? (gr1 + (size_t)par * MSG) : (r1_l + (size_t)par * MSG);
+        double* r1buf = r1_l + (size_t)par * MSG;                   // (one work-group; clusters publish granules instead)
+        const unsigned epoch = (unsigned)(t + 2), r1g = R1BASE + (unsigned)par * MSG;
         double pw[NV];
 #pragma unroll
         for (int k = 0; k < NV; ++k) pw[k] = 0.0;
@@ -2483,13 +2575,10 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const dou
                         if (r == t + 1) {
 #pragma unroll
                             for (int k = 0; k < NV; ++k) {
-                                if (GLOBAL) agent_store_f64(r1buf + BASQ_PAIRCOL(k), a[jr][k]);
+                                if (GLOBAL) granule_store(grs, r1g + BASQ_PAIRCOL(k), epoch, (BASQ_PAIRCOL(k) == NC - 1) ? cr : a[jr][k], local);
                                 else r1buf[BASQ_PAIRCOL(k)] = a[jr][k];
                             }
-                            if (lane == 0) {
-                                if (GLOBAL) agent_store_f64(r1buf + NC, cr);
-                                else r1buf[NC] = cr;
-                            }
+                            if (!GLOBAL && lane == 0) r1buf[NC] = cr;
                         } else {
 #pragma unroll
                             for (int k = 0; k < NV; ++k) pw[k] += cr * a[jr][k];
@@ -2501,7 +2590,7 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const dou
         } else if (gw == 0) {   // prologue: row 0 as it stands is "row t+1"
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
-                if (GLOBAL) agent_store_f64(r1buf + BASQ_PAIRCOL(k), a[0][k]);
+                if (GLOBAL) granule_store(grs, r1g + BASQ_PAIRCOL(k), epoch, a[0][k], local);
                 else r1buf[BASQ_PAIRCOL(k)] = a[0][k];
             }
         }
@@ -2510,14 +2599,13 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const dou
             *reinterpret_cast<d2_t*>(my_msg + 2 * lane + 128 * h) = (d2_t){pw[2 * h], pw[2 * h + 1]};
         if (lane == 0) my_msg[NC] = ssp;
         BASQ_NS_STAMP(t + 1, 1);
-        if (GLOBAL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the owner's row stores have left the CU
         __syncthreads();
         BASQ_NS_STAMP(t + 1, 2);
         // ---- chain (every wave) ----
         double accs[NV], ss2 = 0.0, r1[NV], rn[NV], alphaH = 0.0;
 #pragma unroll
         for (int k = 0; k < NV; ++k) accs[k] = 0.0;
-        if (!GLOBAL || wv == 0) {
+        if (!GLOBAL) {
             if (t >= 0) {
 #pragma unroll
                 for (int w = 0; w < WPG; ++w) {                     // local partials, wave order
@@ -2533,55 +2621,47 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const dou
             }
         }
         if (GLOBAL) {
-            // ONE wave per work-group talks to the other CUs: it publishes this work-group's sum (write-through), waits
-            // for every work-group's flag, gathers the sums in cluster order and the published row t+1, and hands the
-            // result to its seven sibling waves through LDS -- 20 KB of fabric traffic per CU and step instead of 160 KB.
-            const unsigned epoch = (unsigned)(t + 2);
-            double* mine = gsum + (size_t)(par * NCU + cu) * MSG;
-            double* tot_l = wpart_l + (size_t)(par * WPG) * MSG;    // this parity's first partial slot: free after the sum above
-            if (wv == 0) {
+            // Every thread of the work-group owns ONE column of the exchange: it adds the eight local partials (wave order),
+            // publishes the work-group's sum as a tagged granule and sweeps the NCU granules of that column and the granule
+            // of the published row t+1 until every tag carries this step's epoch -- one fabric trip, no drain, no flag.
+            // The cluster-order sum and the row go to the sibling waves through LDS (one barrier).  The two scalars of a
+            // step (|column|^2 partials, the pivot entry) ride in the last column slot, NC - 1, which the matrix never
+            // uses (the launcher admits n <= NC - 2 only).
+            const unsigned col = (unsigned)(wv * 64 + lane);
+            double* tot_l = wpart_l + (size_t)(par * WPG) * MSG;    // this parity's first partial slot: a thread overwrites
+            double s_own = 0.0;                                     // only the entry it has just read
+            if (t >= 0) {
+                const unsigned lcol = (col == NC - 1) ? NC : col;   // the scalar's slot in the local messages
 #pragma unroll
-                for (int k = 0; k < NV; ++k) agent_store_f64(mine + BASQ_PAIRCOL(k), accs[k]);
-                if (lane == 0) agent_store_f64(mine + NC, ss2);
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) __hip_atomic_store((basq_gu32*)(flags + cu), epoch, BASQ_RLX_AGENT);
-                unsigned spins = 0;
-                bool bad = false;
-                for (;;) {
-                    const unsigned f = (lane < NCU) ? __hip_atomic_load((basq_gu32*)(flags + lane), BASQ_RLX_AGENT) : epoch;
-                    if (__all(f >= epoch)) { bad = __any(f >= (unsigned)BASQ_ABORT_COUNT); break; }
-                    if (++spins > BASQ_SPIN_LIMIT) {                // never in a healthy run: abort the whole cluster
-                        if (lane == 0) __hip_atomic_store((basq_gu32*)(flags + cu), (unsigned)BASQ_ABORT_COUNT, BASQ_RLX_AGENT);
-                        bad = true;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // no instruction: the gathers stay below the poll
-                double tot[NV], sst = 0.0;
-#pragma unroll
-                for (int k = 0; k < NV; ++k) tot[k] = 0.0;
-                if (!bad) {
-#pragma unroll
-                    for (int c2 = 0; c2 < NCU; ++c2) {              // cluster order: every work-group forms the same sum
-                        const double* src = gsum + (size_t)(par * NCU + c2) * MSG;
-#pragma unroll
-                        for (int k = 0; k < NV; ++k) tot[k] += agent_load_f64(src + BASQ_PAIRCOL(k));
-                        sst += agent_load_f64(src + NC);
-                    }
-#pragma unroll
-                    for (int k = 0; k < NV; ++k) {
-                        tot_l[BASQ_PAIRCOL(k)] = tot[k];
-                        r1_l[(size_t)par * MSG + BASQ_PAIRCOL(k)] = agent_load_f64(r1buf + BASQ_PAIRCOL(k));
-                    }
-                    if (lane == 0) {
-                        tot_l[NC] = sst;
-                        r1_l[(size_t)par * MSG + NC] = agent_load_f64(r1buf + NC);
-                    }
-                }
-                if (lane == 0) abort_l = bad ? 1 : 0;
+                for (int w = 0; w < WPG; ++w) s_own += wpart_l[(size_t)(par * WPG + w) * MSG + lcol];   // wave order
+                granule_store(grs, (unsigned)(par * NCU + cu) * MSG + col, epoch, s_own, local);
             }
-            __syncthreads();                                        // wave 0's verdict and gathered data: work-group uniform
+            basq_v4u gq[NCU], g1;
+            unsigned spins = 0;
+            bool bad = false;
+            for (;;) {
+                bool ok = true;
+                if (t >= 0) {
+#pragma unroll
+                    for (int c2 = 0; c2 < NCU; ++c2) gq[c2] = granule_load(grs, (unsigned)(par * NCU + c2) * MSG + col);
+#pragma unroll
+                    for (int c2 = 0; c2 < NCU; ++c2) ok = ok && granule_ok(gq[c2], epoch);
+                }
+                g1 = granule_load(grs, r1g + col);
+                ok = ok && granule_ok(g1, epoch);
+                if (__all(ok)) break;
+                if (++spins > BASQ_GRANULE_SPIN_LIMIT) { bad = true; break; }   // never in a healthy run (wave-uniform)
+                if (spins > 16) __builtin_amdgcn_s_sleep(2);
+            }
+            double tot = 0.0;
+            if (t >= 0) {
+#pragma unroll
+                for (int c2 = 0; c2 < NCU; ++c2) tot += granule_value(gq[c2]);   // cluster order: the same sum everywhere
+            }
+            tot_l[col] = tot;
+            r1_l[(size_t)par * MSG + col] = granule_value(g1);
+            if (bad && lane == 0) abort_l = 1;
+            __syncthreads();                                        // sums, row and verdict: work-group uniform from here
             aborted = abort_l != 0;
             if (aborted) break;                                     // no wave is left behind at a barrier
 #pragma unroll
@@ -2590,7 +2670,8 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const dou
                 accs[2 * h] = v.x;
                 accs[2 * h + 1] = v.y;
             }
-            ss2 = tot_l[NC];
+            ss2 = tot_l[NC - 1];
+            if (lane == 63) accs[NV - 1] = 0.0;                     // (slot NC - 1 carried the scalar)
         }
         {
             const double* r1src = r1_l + (size_t)par * MSG;          // clusters: wave 0's copy of the published row
@@ -2600,7 +2681,8 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const dou
                 r1[2 * h] = v.x;
                 r1[2 * h + 1] = v.y;
             }
-            alphaH = r1src[NC];
+            alphaH = r1src[GLOBAL ? NC - 1 : NC];
+            if (GLOBAL && lane == 63) r1[NV - 1] = 0.0;
         }
         BASQ_NS_STAMP(t + 1, 4);
         if (t >= 0) {
@@ -3835,7 +3917,8 @@ int basq_tail_weights_geo_f64(const double* mu, const double* wx, const int64_t*
 }
 
 // workspace (doubles) of the cluster kernels for an [s, M] reduction: 16 counter/flag words + the message ring
-static inline size_t cluster_ws_doubles(int nv, int ncu) { return 16 + (size_t)(2 * BASQ_WPG * ncu) * (nv * 64 + 8); }
+// (ring of 2 W slots of tagged 16-byte granules; the bidiagonalisation's 2 x (NCU + 1) messages are the smaller user)
+static inline size_t cluster_ws_doubles(int nv, int ncu) { return 16 + 2 * (size_t)(2 * BASQ_WPG * ncu) * (nv * 64 + 8); }
 
 #ifndef BASQ_CAR_CLUSTER
 #define BASQ_CAR_CLUSTER 1      // 1: cluster kernels where the null vectors do not fit one CU's LDS; 2: also where they do
@@ -3869,7 +3952,8 @@ int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32
         return BASQ_OK;
     }
     if (nrows >= 1 && !fits_lds && M <= 512 && nrows <= 4 * BASQ_WPG * 8 && ws) {   // 4-CU cluster (n = 200: M = 400)
-        if (hipMemsetAsync(ws, 0, 16 * sizeof(double), st) != hipSuccess) return BASQ_ELAUNCH;
+        // every granule word zeroed: tags are the step numbers of THIS launch
+        if (hipMemsetAsync(ws, 0, cluster_ws_doubles(8, 4) * sizeof(double), st) != hipSuccess) return BASQ_ELAUNCH;
         hipLaunchKernelGGL((car_eliminate_cluster_kernel<8, 8, 4>), dim3(4 * 8), dim3(T), 0, st, PhiT, mu, M, s,
                            keep_rank, kept, w_star, info, ws, 8);
         BASQ_CHECK_LAUNCH();
@@ -3909,8 +3993,9 @@ int basq_nullspace_f64(const double* X, int32_t s, int32_t M, double* V, double*
         if (s <= BASQ_WPG * 4) hipLaunchKernelGGL((bidiag_cluster_kernel<4, 4, 1>), dim3(1), dim3(T), 0, st, X, s, M, V, tau, (double*)nullptr, 1, info);
         else hipLaunchKernelGGL((bidiag_cluster_kernel<4, 14, 1>), dim3(1), dim3(T), 0, st, X, s, M, V, tau, (double*)nullptr, 1, info);
         rc = (hipGetLastError() == hipSuccess) ? BASQ_OK : BASQ_ELAUNCH;
-    } else if (BASQ_NS_CLUSTER && !(M <= 256 && s <= 112) && M <= 512 && s <= 4 * BASQ_WPG * 8 && ws) {   // 4-CU cluster
-        if (hipMemsetAsync(ws, 0, 16 * sizeof(double), st) != hipSuccess) return BASQ_ELAUNCH;
+    } else if (BASQ_NS_CLUSTER && !(M <= 256 && s <= 112) && M <= 510 && s <= 4 * BASQ_WPG * 8 && ws) {   // 4-CU cluster
+        // every granule word zeroed: tags are the step numbers of THIS launch (16 + 2 x (4 + 1) messages of 520 granules)
+        if (hipMemsetAsync(ws, 0, (16 + 2 * (4 + 1) * (8 * 64 + 8) * 2) * sizeof(double), st) != hipSuccess) return BASQ_ELAUNCH;
         hipLaunchKernelGGL((bidiag_cluster_kernel<8, 8, 4>), dim3(4 * 8), dim3(T), 0, st, X, s, M, V, tau, ws, 8, info);
         rc = (hipGetLastError() == hipSuccess) ? BASQ_OK : BASQ_ELAUNCH;
     } else if (M <= 256 && s <= 112) {                          // whole matrix in registers (16 waves)
