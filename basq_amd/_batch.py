@@ -608,7 +608,7 @@ class Batch:
                 n_keep, status = hl[0], hl[1]
                 kept_list = hl[2:2 + n_keep]
             if status == 2:
-                # a 4-work-group cluster kernel gave up waiting for its siblings (they must be co-resident; a GPU shared
+                # an 8-work-group cluster kernel gave up waiting for its siblings (they must be co-resident; a GPU shared
                 # with other work may not grant that within the spin limit): nothing of this round has been applied yet --
                 # redo its reduction, and every later one of the batch, on the single-work-group kernels
                 if not cluster:

@@ -232,7 +232,7 @@ class HipOps:
     def nullspace(self, XcarT, s, M, cluster=True):
         """Rows s..M-1 of the full ``Vh`` of ``svd(XcarT [s, M])`` (``_rchq.py:140-143``) -> PhiT [M-s, M].
 
-        Shapes that need the 4-work-group cluster kernels (M > 256) attach ``PhiT.ns_info`` (device int32[1]: 2 = a
+        Shapes that need the 8-work-group cluster kernels (M > 256) attach ``PhiT.ns_info`` (device int32[1]: 2 = a
         cluster spin timed out), which ``car_eliminate`` folds into its status word; ``cluster=False`` selects the
         single-work-group kernels (the retry path after such a time-out)."""
         self._chk(XcarT)

@@ -3918,6 +3918,12 @@ int basq_tail_weights_geo_f64(const double* mu, const double* wx, const int64_t*
 
 // workspace (doubles) of the cluster kernels for an [s, M] reduction: 16 counter/flag words + the message ring
 // (ring of 2 W slots of tagged 16-byte granules; the bidiagonalisation's 2 x (NCU + 1) messages are the smaller user)
+#ifndef BASQ_CLUSTER_NCU
+#define BASQ_CLUSTER_NCU 8       // work-groups of a cluster (8 waves each), all dealt to ONE XCD; rows per wave = 256 / (8 NCU).
+                                 // 8 vs 4 at 200 x 400: null space 779 vs 845 us, elimination 521 vs 564 (profiles/r04_u_*)
+#endif
+#define BASQ_CLUSTER_NR (32 / BASQ_CLUSTER_NCU)
+static inline size_t bidiag_ws_doubles(int nv, int ncu) { return 16 + 2 * (size_t)(2 * (ncu + 1)) * (nv * 64 + 8); }
 static inline size_t cluster_ws_doubles(int nv, int ncu) { return 16 + 2 * (size_t)(2 * BASQ_WPG * ncu) * (nv * 64 + 8); }
 
 #ifndef BASQ_CAR_CLUSTER
@@ -3927,8 +3933,8 @@ static inline size_t cluster_ws_doubles(int nv, int ncu) { return 16 + 2 * (size
 int64_t basq_reduction_ws_doubles(int32_t s, int32_t M) {
     if (s < 1 || M <= s || M > 1024) return 0;
     size_t need = 0;
-    // 4-CU clusters (elimination ring: 2 W slots; bidiagonalisation: 2 x (NCU + 1) messages -- the ring is the larger)
-    if (M > 256 && M <= 512 && (s <= 256 || (M - s) <= 256)) need = cluster_ws_doubles(8, 4);
+    // clusters of BASQ_CLUSTER_NCU work-groups (elimination ring: 2 W slots; bidiagonalisation: 2 x (NCU + 1) messages -- the ring is the larger)
+    if (M > 256 && M <= 512 && (s <= 256 || (M - s) <= 256)) need = cluster_ws_doubles(8, BASQ_CLUSTER_NCU);
     return (int64_t)need;
 }
 
@@ -3951,10 +3957,10 @@ int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32
         BASQ_CHECK_LAUNCH();
         return BASQ_OK;
     }
-    if (nrows >= 1 && !fits_lds && M <= 512 && nrows <= 4 * BASQ_WPG * 8 && ws) {   // 4-CU cluster (n = 200: M = 400)
+    if (nrows >= 1 && !fits_lds && M <= 512 && nrows <= 4 * BASQ_WPG * 8 && ws) {   // cluster of BASQ_CLUSTER_NCU CUs (n = 200: M = 400)
         // every granule word zeroed: tags are the step numbers of THIS launch
-        if (hipMemsetAsync(ws, 0, cluster_ws_doubles(8, 4) * sizeof(double), st) != hipSuccess) return BASQ_ELAUNCH;
-        hipLaunchKernelGGL((car_eliminate_cluster_kernel<8, 8, 4>), dim3(4 * 8), dim3(T), 0, st, PhiT, mu, M, s,
+        if (hipMemsetAsync(ws, 0, cluster_ws_doubles(8, BASQ_CLUSTER_NCU) * sizeof(double), st) != hipSuccess) return BASQ_ELAUNCH;
+        hipLaunchKernelGGL((car_eliminate_cluster_kernel<8, BASQ_CLUSTER_NR, BASQ_CLUSTER_NCU>), dim3(BASQ_CLUSTER_NCU * 8), dim3(T), 0, st, PhiT, mu, M, s,
                            keep_rank, kept, w_star, info, ws, 8);
         BASQ_CHECK_LAUNCH();
         return BASQ_OK;
@@ -3993,10 +3999,10 @@ int basq_nullspace_f64(const double* X, int32_t s, int32_t M, double* V, double*
         if (s <= BASQ_WPG * 4) hipLaunchKernelGGL((bidiag_cluster_kernel<4, 4, 1>), dim3(1), dim3(T), 0, st, X, s, M, V, tau, (double*)nullptr, 1, info);
         else hipLaunchKernelGGL((bidiag_cluster_kernel<4, 14, 1>), dim3(1), dim3(T), 0, st, X, s, M, V, tau, (double*)nullptr, 1, info);
         rc = (hipGetLastError() == hipSuccess) ? BASQ_OK : BASQ_ELAUNCH;
-    } else if (BASQ_NS_CLUSTER && !(M <= 256 && s <= 112) && M <= 510 && s <= 4 * BASQ_WPG * 8 && ws) {   // 4-CU cluster
+    } else if (BASQ_NS_CLUSTER && !(M <= 256 && s <= 112) && M <= 510 && s <= 4 * BASQ_WPG * 8 && ws) {   // cluster of BASQ_CLUSTER_NCU CUs
         // every granule word zeroed: tags are the step numbers of THIS launch (16 + 2 x (4 + 1) messages of 520 granules)
-        if (hipMemsetAsync(ws, 0, (16 + 2 * (4 + 1) * (8 * 64 + 8) * 2) * sizeof(double), st) != hipSuccess) return BASQ_ELAUNCH;
-        hipLaunchKernelGGL((bidiag_cluster_kernel<8, 8, 4>), dim3(4 * 8), dim3(T), 0, st, X, s, M, V, tau, ws, 8, info);
+        if (hipMemsetAsync(ws, 0, bidiag_ws_doubles(8, BASQ_CLUSTER_NCU) * sizeof(double), st) != hipSuccess) return BASQ_ELAUNCH;
+        hipLaunchKernelGGL((bidiag_cluster_kernel<8, BASQ_CLUSTER_NR, BASQ_CLUSTER_NCU>), dim3(BASQ_CLUSTER_NCU * 8), dim3(T), 0, st, X, s, M, V, tau, ws, 8, info);
         rc = (hipGetLastError() == hipSuccess) ? BASQ_OK : BASQ_ELAUNCH;
     } else if (M <= 256 && s <= 112) {                          // whole matrix in registers (16 waves)
         if (s <= 32) hipLaunchKernelGGL((bidiag_reflectors_reg_kernel<4, 2>), dim3(1), dim3(1024), 0, st, X, s, M, V, tau);

@@ -188,7 +188,7 @@ int basq_finalize_f64(const double* parts, int32_t n_parts, int32_t msg_rows, in
  * Scratch: V [s, M] (reflector vectors; also row storage when s*M exceeds the LDS), tau [s].
  * Agreement with the host LAPACK rows is at rounding level (~1e-13); 1 <= s < M <= 1024.
  * info (optional, device int32[1]): 0, or 2 = a cluster work-group gave up waiting for its siblings (bounded spins:
- * the four work-groups of a cluster must be co-resident, which a GPU shared with other work may not grant within the
+ * the eight work-groups of a cluster must be co-resident, which a GPU shared with other work may not grant within the
  * limit); PhiT is then poisoned with NaNs.  Passing ws = NULL selects the single-work-group kernels for every shape
  * (slower for M > 256, no co-residency requirement): the caller's retry path.
  */
@@ -197,9 +197,10 @@ int basq_nullspace_f64(const double* XcarT, int32_t s, int32_t M, double* V, dou
 
 /*
  * Workspace (in doubles) that basq_nullspace_f64 / basq_car_eliminate_f64 need in `ws` for an [s, M] reduction:
- * 0 when the shape runs on one compute unit (M <= 256: ws may be NULL), otherwise the message ring + flag words of the
- * 4-work-group cluster kernels (M = 2n = 400 at n = 200: the 200 x 400 matrix does not fit one CU's registers).  The
- * caller owns the buffer (the library allocates nothing); the entries zero its flag words themselves.  Without a
+ * 0 when the shape runs on one compute unit (M <= 256: ws may be NULL), otherwise the message ring of the
+ * 8-work-group cluster kernels (M = 2n = 400 at n = 200: the 200 x 400 matrix does not fit one CU's registers): tagged
+ * 16-byte granules {tag, low word, tag, high word} -- the data is its own flag.  The caller owns the buffer (the library
+ * allocates nothing); the entries zero its words themselves before every launch (tags count the steps of ONE launch).  Without a
  * workspace (ws == NULL) such shapes fall back to slower single-work-group kernels.
  */
 int64_t basq_reduction_ws_doubles(int32_t s, int32_t M);
@@ -213,7 +214,7 @@ int64_t basq_reduction_ws_doubles(int32_t s, int32_t M);
  * or -1), kept[<=s] ascending survivor ids, w_star[<=s], info[0] = n_keep, info[1] = status
  * (0 ok, 1 = a null vector had no positive entry: the reference would raise at :152; 2 = a cluster kernel's
  * bounded spin timed out -- never in a healthy run).  Null vectors live in registers (one work-group for M <= 256,
- * a 4-work-group cluster through `ws` for M <= 512, see basq_reduction_ws_doubles; ws may be NULL otherwise); M <= 1024.
+ * an 8-work-group cluster through `ws` for M <= 512, see basq_reduction_ws_doubles; ws may be NULL otherwise); M <= 1024.
  */
 int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32_t* keep_rank, int32_t* kept,
                            double* w_star, int32_t* info, double* ws, void* stream);
