@@ -3923,6 +3923,13 @@ int basq_tail_weights_geo_f64(const double* mu, const double* wx, const int64_t*
                                  // 8 vs 4 at 200 x 400: null space 779 vs 845 us, elimination 521 vs 564 (profiles/r04_u_*)
 #endif
 #define BASQ_CLUSTER_NR (32 / BASQ_CLUSTER_NCU)
+// Work-groups b, b + 8, b + 16, ... of a launch are dealt to one XCD (observed, not promised): a cluster uses every 8th
+// work-group of its grid.  BASQ_CLUSTER_SPREAD=1 (tests) uses consecutive work-groups instead -- eight different XCDs -- so
+// that the write-through path the kernels fall back to when their members do NOT share an XCD is exercised on purpose.
+static int cluster_stride() {
+    static const int spread = [] { const char* e = getenv("BASQ_CLUSTER_SPREAD"); return (e && atoi(e) > 0) ? 1 : 0; }();
+    return spread ? 1 : 8;
+}
 static inline size_t bidiag_ws_doubles(int nv, int ncu) { return 16 + 2 * (size_t)(2 * (ncu + 1)) * (nv * 64 + 8); }
 static inline size_t cluster_ws_doubles(int nv, int ncu) { return 16 + 2 * (size_t)(2 * BASQ_WPG * ncu) * (nv * 64 + 8); }
 
@@ -3960,8 +3967,8 @@ int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32
     if (nrows >= 1 && !fits_lds && M <= 512 && nrows <= 4 * BASQ_WPG * 8 && ws) {   // cluster of BASQ_CLUSTER_NCU CUs (n = 200: M = 400)
         // every granule word zeroed: tags are the step numbers of THIS launch
         if (hipMemsetAsync(ws, 0, cluster_ws_doubles(8, BASQ_CLUSTER_NCU) * sizeof(double), st) != hipSuccess) return BASQ_ELAUNCH;
-        hipLaunchKernelGGL((car_eliminate_cluster_kernel<8, BASQ_CLUSTER_NR, BASQ_CLUSTER_NCU>), dim3(BASQ_CLUSTER_NCU * 8), dim3(T), 0, st, PhiT, mu, M, s,
-                           keep_rank, kept, w_star, info, ws, 8);
+        hipLaunchKernelGGL((car_eliminate_cluster_kernel<8, BASQ_CLUSTER_NR, BASQ_CLUSTER_NCU>), dim3(BASQ_CLUSTER_NCU * cluster_stride()), dim3(T), 0, st, PhiT, mu, M, s,
+                           keep_rank, kept, w_star, info, ws, cluster_stride());
         BASQ_CHECK_LAUNCH();
         return BASQ_OK;
     }
@@ -4002,7 +4009,7 @@ int basq_nullspace_f64(const double* X, int32_t s, int32_t M, double* V, double*
     } else if (BASQ_NS_CLUSTER && !(M <= 256 && s <= 112) && M <= 510 && s <= 4 * BASQ_WPG * 8 && ws) {   // cluster of BASQ_CLUSTER_NCU CUs
         // every granule word zeroed: tags are the step numbers of THIS launch (16 + 2 x (4 + 1) messages of 520 granules)
         if (hipMemsetAsync(ws, 0, bidiag_ws_doubles(8, BASQ_CLUSTER_NCU) * sizeof(double), st) != hipSuccess) return BASQ_ELAUNCH;
-        hipLaunchKernelGGL((bidiag_cluster_kernel<8, BASQ_CLUSTER_NR, BASQ_CLUSTER_NCU>), dim3(BASQ_CLUSTER_NCU * 8), dim3(T), 0, st, X, s, M, V, tau, ws, 8, info);
+        hipLaunchKernelGGL((bidiag_cluster_kernel<8, BASQ_CLUSTER_NR, BASQ_CLUSTER_NCU>), dim3(BASQ_CLUSTER_NCU * cluster_stride()), dim3(T), 0, st, X, s, M, V, tau, ws, cluster_stride(), info);
         rc = (hipGetLastError() == hipSuccess) ? BASQ_OK : BASQ_ELAUNCH;
     } else if (M <= 256 && s <= 112) {                          // whole matrix in registers (16 waves)
         if (s <= 32) hipLaunchKernelGGL((bidiag_reflectors_reg_kernel<4, 2>), dim3(1), dim3(1024), 0, st, X, s, M, V, tau);

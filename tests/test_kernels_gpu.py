@@ -4,6 +4,8 @@ The CPU side is ``tests/cpu_stand_in.py`` (contract restatement) and ``oracle/ke
 (gpytorch-style kernel values).  Integer/index outputs and the elimination (same op order as the
 reference) must match bit for bit; floating-point sums within 1e-12 relative.
 """
+import os
+import sys
 import pytest
 import torch
 
@@ -838,3 +840,43 @@ def test_shader_clock_sampler(hip_ops):
     assert bool(((clk > 500.0) & (clk < 3500.0)).all()), clk.tolist()
     with pytest.raises(Exception):
         hip_ops.shader_clock_mhz(0, 50)
+
+
+_SPREAD_CHILD = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from basq_amd._ops import HipOps
+ops = HipOps(torch.device("cuda:0"))
+out = {}
+for s, M in ((200, 400), (150, 400)):
+    g = torch.Generator().manual_seed(s + 7 * M)
+    X = torch.randn(s, M, generator=g, dtype=torch.float64); X[0] = 1.0
+    mu = torch.rand(M, generator=g, dtype=torch.float64) + 0.05; mu = mu / mu.sum()
+    for rep in range(3):
+        P = ops.nullspace(ops.to_device(X), s, M)
+        kr, kept, w, info = ops.car_eliminate(P.clone(), ops.to_device(mu), M, s)
+        out[(s, M, rep)] = (P.cpu(), kr.cpu(), w.cpu(), info.cpu())
+torch.save(out, sys.argv[2])
+"""
+
+
+def test_cluster_reductions_members_on_different_xcds(tmp_path):
+    """The clusters write their granules with plain stores when all members share an XCD and write-through otherwise
+    (``cluster_shares_xcd``).  ``BASQ_CLUSTER_SPREAD=1`` deals the members to eight DIFFERENT XCDs: the fall-back path must
+    return the same bits as the same-XCD path (both sum in cluster order), three times in a row."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for spread in ("0", "1"):
+        out = tmp_path / f"spread{spread}.pt"
+        env = dict(os.environ, BASQ_CLUSTER_SPREAD=spread)
+        r = subprocess.run([sys.executable, "-c", _SPREAD_CHILD, root, str(out)], env=env, capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[spread] = torch.load(out)
+    for key, a in res["0"].items():
+        b = res["1"][key]
+        assert a[3].tolist()[1] == 0 and b[3].tolist()[1] == 0, (key, a[3].tolist(), b[3].tolist())
+        assert torch.equal(a[0], b[0]), f"{key}: null space differs between the same-XCD and the spread cluster"
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
