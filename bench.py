@@ -192,8 +192,10 @@ def main():
     from basq_amd._ops import HipOps
 
     clock_ops = HipOps(dev, stream=torch.cuda.Stream(device=dev))
-    tr = basq_amd.EngineTrace(time_kernels=not args.no_roofline_batch, sample_clock=None if args.plain else clock_ops,
-                              host_sync=False)
+    # (one rank only: with RCCL's streams in the process the sampler's stream can land on the hardware queue of the launch
+    #  stream, and the 8-ms sampler then runs IN FRONT of the block sums instead of beside them)
+    sample = None if (args.plain or world > 1 or force_dist) else clock_ops
+    tr = basq_amd.EngineTrace(time_kernels=not args.no_roofline_batch, sample_clock=sample, host_sync=False)
     one_batch(tr)
     torch.cuda.synchronize()
     # the shader clock the class launches ran at: one wave on a second stream samples it every 250 us while the launch runs.
