@@ -1660,10 +1660,15 @@ __global__ void __launch_bounds__(1024) car_eliminate_lds_kernel(const double* _
 // BASQ_WPG = 8 waves (two per SIMD) and a cluster is NCU work-groups (W = 8 NCU waves) that exchange ONE message
 // per step:
 //   NCU = 1: through LDS (ring buffer + one counter word, no s_barrier in the elimination);
-//   NCU > 1: through a ring in global memory, written with agent-scope (sc1, write-through) 8-byte stores, each
-//            storing wave draining vmcnt before ITS OWN counter/flag store, read with agent-scope (sc1) loads by the
-//            wave that polled (MI355X_MICROARCH.md, visibility: "8-B agent atomics both sides", every wave signals
-//            and polls for itself).  Spins are bounded: a timeout aborts every wave of the cluster with status 2.
+//   NCU > 1: as TAGGED GRANULES in global memory -- every double travels as one 16-byte store {tag, low word, tag, high
+//            word}, tag = the step it belongs to, and a reader sweeps its granules (L1-bypassing sc1 loads) until both
+//            tags of each match: the data is its own flag, so there is no drain, no flag store and no acquire, ONE trip
+//            per step (round 2's flag + drain + gather form took three: 2.24 -> 0.71 ms per 200 x 400 null space).
+//            The members sit on every 8th work-group of the grid, which the dispatcher deals to ONE XCD; they check
+//            that at launch (cluster_shares_xcd) and then use PLAIN stores, which stay in that XCD's L2 -- otherwise
+//            write-through (sc1) stores.  Placement changes speed, never results.  The granule words are zeroed before
+//            every launch; spins are bounded: a member that is not resident -> status 2 -> the caller's retry on the
+//            single-work-group kernels.
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) unsigned long long basq_gu64;
 typedef __attribute__((address_space(1))) unsigned int basq_gu32;
@@ -1674,13 +1679,6 @@ typedef __attribute__((address_space(1))) unsigned int basq_gu32;
                                           // (4 waves of 512 registers would park half of it in AGPRs: two moves per use)
 #define BASQ_SPIN_LIMIT (1u << 22)       // polls (with s_sleep) before a cluster kernel gives up: ~0.3 s
 #define BASQ_ABORT_COUNT 0x40000000
-
-__device__ __forceinline__ void agent_store_f64(double* p, double v) {
-    __hip_atomic_store((basq_gu64*)p, (unsigned long long)__double_as_longlong(v), BASQ_RLX_AGENT);
-}
-__device__ __forceinline__ double agent_load_f64(const double* p) {
-    return __longlong_as_double((long long)__hip_atomic_load((basq_gu64*)p, BASQ_RLX_AGENT));
-}
 
 // Tagged granules: a double handed to another work-group as ONE 16-byte write-through store {tag, low word, tag, high word}.
 // Each 8-byte half carries the tag, so a reader that finds both tags equal to the epoch it waits for holds the value -- the
@@ -1754,29 +1752,21 @@ __device__ __forceinline__ double pick_slot(const double (&r)[NV], int kj) {
     return v;
 }
 
-// Monotone counter shared by the waves of a cluster (LDS word for one work-group, global word otherwise).
-template <bool GLOBAL>
+// Monotone counter in LDS shared by the waves of a ONE-work-group cluster (clusters of several work-groups hand over tagged
+// granules instead and need no counter).
 __device__ __forceinline__ void counter_publish(int* cnt, int value, int lane) {
-    if (GLOBAL) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's payload stores have left the CU
-        if (lane == 0) __hip_atomic_store((basq_gu32*)cnt, (unsigned)value, BASQ_RLX_AGENT);
-    } else {
-        if (lane == 0) __hip_atomic_store(cnt, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    if (lane == 0) __hip_atomic_store(cnt, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // wait until *cnt > k; returns the value seen (>= BASQ_ABORT_COUNT: another wave gave up)
-template <bool GLOBAL>
 __device__ __forceinline__ int counter_wait_gt(int* cnt, int k) {
     unsigned spins = 0;
     int c;
     for (;;) {
-        if (GLOBAL) c = (int)__hip_atomic_load((basq_gu32*)cnt, BASQ_RLX_AGENT);
-        else c = __hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        c = __hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
         c = __builtin_amdgcn_readfirstlane(c);
         if (c > k) break;
-        if (++spins > BASQ_SPIN_LIMIT) {                           // never in a healthy run: abort the whole cluster
-            if (GLOBAL) __hip_atomic_store((basq_gu32*)cnt, (unsigned)BASQ_ABORT_COUNT, BASQ_RLX_AGENT);
-            else __hip_atomic_store(cnt, BASQ_ABORT_COUNT, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (++spins > BASQ_SPIN_LIMIT) {                           // never in a healthy run: abort the whole work-group
+            __hip_atomic_store(cnt, BASQ_ABORT_COUNT, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             c = BASQ_ABORT_COUNT;
             break;
         }
@@ -1870,7 +1860,7 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) car_eliminate_cluster_kernel(co
 #pragma unroll
             for (int k = 0; k < NV; ++k) slot[BASQ_PAIRCOL(k)] = r[k];
             if (lane < 4) slot[NC + lane] = hv;
-            counter_publish<false>(count, kp + 1, lane);
+            counter_publish(count, kp + 1, lane);
         }
     };
     if (nrows > 0 && gw == 0) test_and_publish(a[0], 0);
@@ -1911,7 +1901,7 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) car_eliminate_cluster_kernel(co
 #pragma unroll
             for (int u = 0; u < 4; ++u) hdr[u] = readlane_f64(hv, u);
         } else {
-            const int seen = counter_wait_gt<false>(count, k);
+            const int seen = counter_wait_gt(count, k);
             if (seen >= BASQ_ABORT_COUNT) { status = 2; break; }
             const double* slot = ring + (size_t)(k % D) * SLOT;
 #pragma unroll
