@@ -2718,7 +2718,7 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const dou
         }
         BASQ_NS_STAMP(t + 1, 3);
     }
-    if (aborted && gw == 0 && lane == 0) {
+    if (aborted && threadIdx.x == 0) {   // ANY member that gave up reports (its siblings run into the same limit, or are done)
         tau_g[0] = __builtin_nan("");   // poisons the null space: an elimination that ignores `info` still fails loudly
         if (info_g) info_g[0] = 2;      // status 2: a bounded spin expired (sibling work-groups not co-resident)
     }
