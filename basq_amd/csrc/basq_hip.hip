@@ -212,7 +212,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 __device__ long long* g_ns_prof;
 #define BASQ_NS_STAMP(t, slot)                                                                     \
     do {                                                                                           \
-        if ((threadIdx.x & 63) == 0) g_ns_prof[((t) * 8 + (slot)) * 16 + (threadIdx.x >> 6)] = clock64(); \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x == 0) g_ns_prof[((t) * 8 + (slot)) * 16 + (threadIdx.x >> 6)] = clock64(); \
     } while (0)
 #else
 #define BASQ_NS_STAMP(t, slot) do { } while (0)

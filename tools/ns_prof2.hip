@@ -30,7 +30,7 @@ int main(int argc, char** argv) {
     hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        int rc = basq_nullspace_f64(dX, m, n, dV, dtau, dP, wsn > 0 ? dws : nullptr, nullptr);
+        int rc = basq_nullspace_f64(dX, m, n, dV, dtau, dP, wsn > 0 ? dws : nullptr, nullptr, nullptr);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
