@@ -126,7 +126,10 @@ def _cholqr(ops, X, flags, passes=2):
     k = X.shape[1]
     for _ in range(passes):
         G = _mm_splitk(ops, X.t(), X, 32)
-        if k <= getattr(ops, "CHOL_FACTOR_MAX_Q", 0):
+        if cfg.FUSED_CHOLQR and k <= getattr(ops, "CHOLQR_FUSED_MAX_Q", 0):
+            X, info = ops.cholqr(G, X)                         # factor and solve in one launch, pipelined by panels
+            flags.append(info)
+        elif k <= getattr(ops, "CHOL_FACTOR_MAX_Q", 0):
             flags.append(ops.chol_factor(G))
             X = ops.trsm_rows(X, G)
         else:
@@ -263,7 +266,11 @@ def nystrom_basis_steps(ops, A, q_req: int, trace=None, overlap=None, notes=None
             Y = prod.at(Q)
             k = Y.shape[1]
             G1 = _mm_splitk(ops, Y.t(), Y, 32)                 # = B B^T
-            if k <= getattr(ops, "CHOL_FACTOR_MAX_Q", 0):
+            if cfg.FUSED_CHOLQR and k <= getattr(ops, "CHOLQR_FUSED_MAX_Q", 0):
+                Yq, i1 = ops.cholqr(G1, Y)                      # = (L1^-1 B)^T, G1 -> L1 in place
+                G2 = _mm_splitk(ops, Yq.t(), Yq, 32)
+                i2 = ops.chol_factor(G2)
+            elif k <= getattr(ops, "CHOL_FACTOR_MAX_Q", 0):
                 i1 = ops.chol_factor(G1)
                 Yq = ops.trsm_rows(Y, G1)                       # = (L1^-1 B)^T
                 G2 = _mm_splitk(ops, Yq.t(), Yq, 32)

@@ -12,6 +12,9 @@ HOST_SVD_THREADS = 1             # 100x200 / 99x99 SVDs: fastest single-threaded
 
 # The range finder's products on basq_skinny_gemm_f64 (False: library GEMMs through torch, for A/B comparisons).
 OWN_RANGE_GEMM = True
+# CholeskyQR's factor + triangular solve in ONE launch whose solvers start on a column panel as soon as the factor has
+# published it (basq_cholqr_f64; same bits as the two separate launches).  False: the two launches of round 2.
+FUSED_CHOLQR = True
 # The GPU range finder may be switched off (tests compare both paths).
 GPU_RANGE_FINDER = True
 # Per-round null space (:140-143) from the bidiagonalisation's right reflectors on the GPU (basq_nullspace_f64)

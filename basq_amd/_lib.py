@@ -18,7 +18,7 @@ BASQ_OK = 0
 FAMILY = {"rbf": 0, "matern52": 1, "matern32": 2}
 ROLE_A, ROLE_B = 0, 1
 MAX_DIM = 38
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class KernelSpecC(C.Structure):
@@ -64,6 +64,7 @@ SIGNATURES = {
     "basq_chol_inv_f64": (C.c_int, [_vp, _i32, _vp, _vp, _f64, _vp]),
     "basq_chol_factor_f64": (C.c_int, [_vp, _i32, _vp, _f64, _vp]),
     "basq_trsm_rows_f64": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp]),
+    "basq_cholqr_f64": (C.c_int, [_vp, _i32, _vp, _f64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "basq_skinny_gemm_f64": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _i64, _i32, _i32, _vp, _vp, _vp]),
     "basq_gemm_f64": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _f64, _vp]),
 }

@@ -468,6 +468,20 @@ class HipOps:
         check(self.lib.basq_trsm_rows_f64(_ptr(X), q, rows, q, _ptr(L), _ptr(out), q, self._stream()), "basq_trsm_rows_f64")
         return out
 
+    CHOLQR_FUSED_MAX_Q = 112
+
+    def cholqr(self, G, X, rel_tol=1e-12):
+        """``chol_factor`` + ``trsm_rows`` in ONE launch (q <= CHOLQR_FUSED_MAX_Q): G -> L in place, returns
+        ``(X @ L^-T, info[1])`` -- the solve of a column panel starts as soon as the factor has produced it."""
+        self._chk(G)
+        self._chk(X)
+        rows, q = X.shape
+        out = self.empty(rows, q)
+        info = self.empty(2, dtype=torch.int32)
+        check(self.lib.basq_cholqr_f64(_ptr(G), q, _ptr(info), float(rel_tol), _ptr(X), q, rows, _ptr(out), q, self._stream()),
+              "basq_cholqr_f64")
+        return out, info[:1]
+
     def gemm(self, A, B, alpha=1.0):
         """C = alpha * A @ B on the f64 matrix cores (own kernel)."""
         self._chk(A)

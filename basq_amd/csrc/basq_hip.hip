@@ -3427,6 +3427,228 @@ __global__ void __launch_bounds__(512) trsm_rows_kernel(const double* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// CholeskyQR in ONE launch: work-group 0 factors G = X^T X panel by panel (chol_factor_panel_kernel's steps), the others
+// solve Q = X L^-T for 64 rows each (trsm_rows_kernel's steps) and start on panel p as soon as column panel p of L exists,
+// instead of after the whole factor: 68 + 46 us (+ a launch) -> ~80 us at q = 99.
+// Hand-over (MI355X_MICROARCH.md, visibility, "sc1 payload + drained flag"): the LAST wave of the factor work-group stores
+// column panel p (rows j0.., 8 columns: final after F1/F2) write-through into G -- which is the kernel's output anyway --,
+// drains its own stores and raises info[1] to p + 1; meanwhile the other seven waves run the trailing update.  A solving
+// work-group polls that word with ONE lane (bounded), then copies the panel into its LDS image of L with L1-bypassing loads.
+// Same arithmetic, same order as the two separate kernels: identical bits.
+// ------------------------------------------------------------------------------------------------
+#define BASQ_CHOLQR_ABORT 0x40000000u
+__global__ void __launch_bounds__(512) cholqr_fused_kernel(double* __restrict__ G, int q, int* __restrict__ info, double rel_tol,
+                                                           const double* __restrict__ X, long long ldx, long long rows,
+                                                           double* __restrict__ Qo, long long ldq) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    constexpr int NB = BASQ_CHOL_NB, NTHR = 512, NF3 = NTHR - 64;   // the last wave publishes while the others update
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    basq_gu32* progress = (basq_gu32*)(info + 1);
+    if (blockIdx.x == 0) {
+        // ---------------- factor ----------------
+        double* Lp = sm;                                     // [q (q + 1) / 2] packed rows
+        __shared__ double red[16];
+        __shared__ double s_dmax;
+#define BASQ_TRI(i, j) Lp[(size_t)(i) * ((i) + 1) / 2 + (j)]
+        for (int i = tid >> 7; i < q; i += NTHR / 128)
+            for (int k = tid & 127; k <= i; k += 128) BASQ_TRI(i, k) = G[(size_t)i * q + k];
+        __syncthreads();
+        double dm = 0.0;
+        for (int i = tid; i < q; i += NTHR) dm = fmax(dm, BASQ_TRI(i, i));
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) dm = fmax(dm, __shfl_xor(dm, o, 64));
+        if (lane == 0) red[wv] = dm;
+        __syncthreads();
+        if (tid == 0) {
+            double v = red[0];
+            for (int w = 1; w < NTHR / 64; ++w) v = fmax(v, red[w]);
+            s_dmax = v;
+        }
+        __syncthreads();
+        const double floor_ = rel_tol * s_dmax;
+        int bad = 0, panel = 0;
+        for (int j0 = 0; j0 < q; j0 += NB, ++panel) {
+            const int nb = (q - j0 < NB) ? (q - j0) : NB;
+            double D[NB][NB], rd[NB];
+#pragma unroll
+            for (int r = 0; r < NB; ++r)
+#pragma unroll
+                for (int c = 0; c <= r; ++c) D[r][c] = (r < nb) ? BASQ_TRI(j0 + r, j0 + c) : ((r == c) ? 1.0 : 0.0);
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                const double d = D[c][c];
+                if (c < nb && !(d > floor_) && bad == 0) bad = j0 + c + 1;       // uniform: every thread holds the same block
+                const double r = rsqrt_nr(bad ? 1.0 : d);
+                rd[c] = r;
+                D[c][c] = d * r;
+#pragma unroll
+                for (int i = c + 1; i < NB; ++i) D[i][c] *= r;
+#pragma unroll
+                for (int i = c + 1; i < NB; ++i)
+#pragma unroll
+                    for (int k = c + 1; k <= i; ++k) D[i][k] -= D[i][c] * D[k][c];
+            }
+            if (bad) break;                                                     // uniform
+            const int R = q - j0 - nb;
+            if (tid < R) {
+                const int i = j0 + nb + tid;
+                double y[NB];
+#pragma unroll
+                for (int c = 0; c < NB; ++c) y[c] = (c < nb) ? BASQ_TRI(i, j0 + c) : 0.0;
+#pragma unroll
+                for (int c = 0; c < NB; ++c) {
+                    double v = y[c];
+#pragma unroll
+                    for (int k = 0; k < c; ++k) v -= y[k] * D[c][k];
+                    y[c] = v * rd[c];
+                }
+#pragma unroll
+                for (int c = 0; c < NB; ++c)
+                    if (c < nb) BASQ_TRI(i, j0 + c) = y[c];
+            }
+            __syncthreads();
+            if (wv == NTHR / 64 - 1) {
+                // the factored block goes back (its last lane), then this wave publishes column panel `panel`
+                if (tid == NTHR - 1) {
+#pragma unroll
+                    for (int r = 0; r < NB; ++r)
+#pragma unroll
+                        for (int c = 0; c <= r; ++c)
+                            if (r < nb) BASQ_TRI(j0 + r, j0 + c) = D[r][c];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (no instruction) the LDS writes stay above the reads
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int e = lane; e < (q - j0) * NB; e += 64) {
+                    const int i = j0 + e / NB, c = e % NB;
+                    if (c < nb && j0 + c <= i)
+                        __hip_atomic_store((basq_gu64*)(G + (size_t)i * q + j0 + c),
+                                           (unsigned long long)__double_as_longlong(BASQ_TRI(i, j0 + c)), BASQ_RLX_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's stores have left the CU
+                if (lane == 0) __hip_atomic_store(progress, (unsigned)(panel + 1), BASQ_RLX_AGENT);
+            } else {
+                // trailing triangle, 4 x 4 tiles, on the other seven waves
+                const int nt = (R + 3) >> 2, ntiles = nt * (nt + 1) / 2;
+                for (int tile = tid; tile < ntiles; tile += NF3) {
+                    int ti = (int)((__builtin_sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+                    while (ti * (ti + 1) / 2 > tile) --ti;
+                    while ((ti + 1) * (ti + 2) / 2 <= tile) ++ti;
+                    const int tk = tile - ti * (ti + 1) / 2;
+                    const int i0 = j0 + nb + 4 * ti, k0 = j0 + nb + 4 * tk;
+                    double acc[4][4];
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+#pragma unroll
+                        for (int y2 = 0; y2 < 4; ++y2) acc[x][y2] = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) {
+                        double li[4], lk[4];
+#pragma unroll
+                        for (int x = 0; x < 4; ++x) {
+                            const int ii = (i0 + x < q) ? (i0 + x) : (q - 1), kk2 = (k0 + x < q) ? (k0 + x) : (q - 1);
+                            li[x] = (c < nb) ? BASQ_TRI(ii, j0 + c) : 0.0;
+                            lk[x] = (c < nb) ? BASQ_TRI(kk2, j0 + c) : 0.0;
+                        }
+#pragma unroll
+                        for (int x = 0; x < 4; ++x)
+#pragma unroll
+                            for (int y2 = 0; y2 < 4; ++y2) acc[x][y2] = __builtin_fma(li[x], lk[y2], acc[x][y2]);
+                    }
+#pragma unroll
+                    for (int x = 0; x < 4; ++x)
+#pragma unroll
+                        for (int y2 = 0; y2 < 4; ++y2)
+                            if (i0 + x < q && k0 + y2 <= i0 + x) BASQ_TRI(i0 + x, k0 + y2) -= acc[x][y2];
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            info[0] = bad;
+            if (bad) __hip_atomic_store(progress, BASQ_CHOLQR_ABORT, BASQ_RLX_AGENT);   // the solvers stop waiting
+        }
+#undef BASQ_TRI
+        return;
+    }
+    // ---------------- solve: 64 rows of X per work-group ----------------
+    const int ld = q | 1;
+    double* Y = sm;                                       // [64][ld]
+    double* Lsh = sm + 64 * ld;                           // [q][q]
+    __shared__ unsigned s_seen;
+    const long long r0 = (long long)(blockIdx.x - 1) * 64;
+    const int nr = (rows - r0 < 64) ? (int)(rows - r0) : 64;
+    for (int e = tid; e < 64 * q; e += 512) {
+        const int r = e / q, c = e - r * q;
+        Y[r * ld + c] = (r < nr) ? X[(r0 + r) * ldx + c] : 0.0;
+    }
+    const int r = tid & 63, c = tid >> 6;                 // wave = panel column c (uniform), lane = row
+    int panel = 0;
+    for (int j0 = 0; j0 < q; j0 += NB, ++panel) {
+        const int nb = (q - j0 < NB) ? (q - j0) : NB;
+        if (tid == 0) {                                   // ONE lane polls the progress word
+            unsigned seen, spins = 0;
+            for (;;) {
+                seen = __hip_atomic_load(progress, BASQ_RLX_AGENT);
+                if (seen >= (unsigned)(panel + 1)) break;
+                if (++spins > BASQ_SPIN_LIMIT) { seen = BASQ_CHOLQR_ABORT; break; }     // never in a healthy run
+                __builtin_amdgcn_s_sleep(1);
+            }
+            s_seen = seen;
+        }
+        __syncthreads();                                  // (also: Y is loaded, the previous panel's block is solved)
+        if (s_seen >= BASQ_CHOLQR_ABORT) {                // uniform: failed pivot (info[0] says so) or a time-out
+            if (s_seen == BASQ_CHOLQR_ABORT && tid == 0 && blockIdx.x == 1 && info[0] == 0) atomicMax(info, q + 1000);
+            return;
+        }
+        for (int e = tid; e < (q - j0) * NB; e += 512) {   // column panel `panel` of L -> LDS (L1-bypassing loads)
+            const int i = j0 + e / NB, cc = e % NB;
+            if (cc < nb && j0 + cc <= i)
+                Lsh[(size_t)i * q + j0 + cc] = __longlong_as_double((long long)__hip_atomic_load(
+                    (basq_gu64*)(G + (size_t)i * q + j0 + cc), BASQ_RLX_AGENT));
+        }
+        __syncthreads();
+        if (c < nb) {
+            const double* lrow = Lsh + (size_t)(j0 + c) * q;
+            const double* yrow = Y + r * ld;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int k = 0;
+            for (; k + 3 < j0; k += 4) {
+                s0 = __builtin_fma(yrow[k], lrow[k], s0);
+                s1 = __builtin_fma(yrow[k + 1], lrow[k + 1], s1);
+                s2 = __builtin_fma(yrow[k + 2], lrow[k + 2], s2);
+                s3 = __builtin_fma(yrow[k + 3], lrow[k + 3], s3);
+            }
+            for (; k < j0; ++k) s0 = __builtin_fma(yrow[k], lrow[k], s0);
+            Y[r * ld + j0 + c] -= (s0 + s1) + (s2 + s3);
+        }
+        __syncthreads();
+        if (tid < 64) {                                   // one thread per row: the 8 x 8 block by forward substitution
+            double y[NB];
+#pragma unroll
+            for (int cc = 0; cc < NB; ++cc) y[cc] = (cc < nb) ? Y[tid * ld + j0 + cc] : 0.0;
+#pragma unroll
+            for (int cc = 0; cc < NB; ++cc) {
+                if (cc < nb) {
+                    const double* lrow = Lsh + (size_t)(j0 + cc) * q + j0;
+                    double v = y[cc];
+#pragma unroll
+                    for (int k = 0; k < cc; ++k) v -= y[k] * lrow[k];
+                    y[cc] = v / lrow[cc];
+                }
+            }
+#pragma unroll
+            for (int cc = 0; cc < NB; ++cc)
+                if (cc < nb) Y[tid * ld + j0 + cc] = y[cc];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < 64 * q; e += 512) {
+        const int rr = e / q, cc = e - rr * q;
+        if (rr < nr) Qo[(r0 + rr) * ldq + cc] = Y[rr * ld + cc];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Block sums of a dense per-pair matrix handed over by the caller:
 //     E[j][s] += scale * sum_{p in chunk, set(p) = s} mu_p * C[j][p]        (SQ = false)
 //     E[j][s] += scale * sum_{p in chunk, set(p) = s} mu_p * C[j][p]^2      (SQ = true)
@@ -4198,6 +4420,21 @@ int basq_trsm_rows_f64(const double* X, int64_t ldx, int64_t rows, int32_t q, co
         hipLaunchKernelGGL(trsm_rows_kernel<false>, grid, dim3(512), lds, (hipStream_t)stream, X, (long long)ldx,
                            (long long)rows, q, L, Q, (long long)ldq);
     }
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_cholqr_f64(double* G, int32_t q, int32_t* info, double rel_tol, const double* X, int64_t ldx, int64_t rows,
+                    double* Q, int64_t ldq, void* stream) {
+    if (!G || !info || !X || !Q || q < 1 || rows < 0 || ldx < q || ldq < q || !(rel_tol >= 0.0)) return BASQ_EINVAL;
+    const size_t lds = ((size_t)64 * (q | 1) + (size_t)q * q) * sizeof(double);       // a solver's rows + its image of L
+    if (lds > 163840 - 512 || rows > 64LL * 4096) return BASQ_EUNSUPPORTED;           // q <= 112; every work-group resident
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(info, 0, 2 * sizeof(int32_t), st) != hipSuccess) return BASQ_ELAUNCH;   // pivot flag | progress word
+    if (hipFuncSetAttribute((const void*)cholqr_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return BASQ_ELAUNCH;
+    hipLaunchKernelGGL(cholqr_fused_kernel, dim3((unsigned)(1 + (rows + 63) / 64)), dim3(512), lds, st, G, q, info, rel_tol, X,
+                       (long long)ldx, (long long)rows, Q, (long long)ldq);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }

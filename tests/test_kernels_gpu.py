@@ -880,3 +880,44 @@ def test_cluster_reductions_members_on_different_xcds(tmp_path):
         assert a[3].tolist()[1] == 0 and b[3].tolist()[1] == 0, (key, a[3].tolist(), b[3].tolist())
         assert torch.equal(a[0], b[0]), f"{key}: null space differs between the same-XCD and the spread cluster"
         assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+
+
+@pytest.mark.parametrize("rows,q", [(10048, 99), (10000, 100), (1000, 30), (130, 7), (5000, 112), (64, 40)])
+def test_fused_cholqr_equals_factor_plus_solve(hip_ops, rows, q):
+    """``basq_cholqr_f64`` (factor and solve in one launch, the solvers following the factor panel by panel through a
+    progress word) against ``basq_chol_factor_f64`` + ``basq_trsm_rows_f64``: same arithmetic, same bits -- repeated, with a
+    second stream keeping the chip busy, so that a solver reading a panel too early would show."""
+    g = torch.Generator().manual_seed(rows + q)
+    X = torch.randn(rows, q, generator=g, dtype=torch.float64)
+    Xd = hip_ops.to_device(X)
+    G = (X.t() @ X)
+    G1 = hip_ops.to_device(G.clone())
+    info1 = hip_ops.chol_factor(G1)
+    Q1 = hip_ops.trsm_rows(Xd, G1)
+    side = torch.cuda.Stream()
+    A = torch.randn(2048, 2048, device=hip_ops.device, dtype=torch.float32)
+    for rep in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(1 + rep % 3):
+                A = torch.tanh(A @ A * 1e-3)
+        G2 = hip_ops.to_device(G.clone())
+        Q2, info2 = hip_ops.cholqr(G2, Xd)
+        assert int(info2.item()) == 0 and int(info1.item()) == 0
+        assert torch.equal(torch.tril(G2), torch.tril(G1)), f"repetition {rep}: factor differs"
+        assert torch.equal(Q2, Q1), f"repetition {rep}: Q differs bitwise"
+    torch.cuda.synchronize()
+    QtQ = (Q1.t() @ Q1).cpu()
+    assert (QtQ - torch.eye(q, dtype=torch.float64)).abs().max().item() < 1e-9
+
+
+def test_fused_cholqr_reports_a_failed_pivot(hip_ops):
+    """A rank-deficient Gram: the factor flags the pivot, raises the abort word, and every solver returns (no hang)."""
+    g = torch.Generator().manual_seed(3)
+    X = torch.randn(4000, 40, generator=g, dtype=torch.float64)
+    X[:, 17] = X[:, 3] + X[:, 5]                               # exact linear dependence
+    Xd = hip_ops.to_device(X)
+    G = hip_ops.to_device(X.t() @ X)
+    info_ref = hip_ops.chol_factor(G.clone())
+    Q, info = hip_ops.cholqr(G.clone(), Xd)
+    torch.cuda.synchronize()
+    assert int(info_ref.item()) > 0 and int(info.item()) == int(info_ref.item())
