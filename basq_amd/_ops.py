@@ -468,7 +468,7 @@ class HipOps:
         check(self.lib.basq_trsm_rows_f64(_ptr(X), q, rows, q, _ptr(L), _ptr(out), q, self._stream()), "basq_trsm_rows_f64")
         return out
 
-    CHOLQR_FUSED_MAX_Q = 112
+    CHOLQR_FUSED_MAX_Q = 200
 
     def cholqr(self, G, X, rel_tol=1e-12):
         """``chol_factor`` + ``trsm_rows`` in ONE launch (q <= CHOLQR_FUSED_MAX_Q): G -> L in place, returns

@@ -3437,6 +3437,7 @@ __global__ void __launch_bounds__(512) trsm_rows_kernel(const double* __restrict
 // Same arithmetic, same order as the two separate kernels: identical bits.
 // ------------------------------------------------------------------------------------------------
 #define BASQ_CHOLQR_ABORT 0x40000000u
+template <bool FULL>   // FULL: a solver keeps an image of all of L in LDS (q <= 112); otherwise the 8 rows of the current panel
 __global__ void __launch_bounds__(512) cholqr_fused_kernel(double* __restrict__ G, int q, int* __restrict__ info, double rel_tol,
                                                            const double* __restrict__ X, long long ldx, long long rows,
                                                            double* __restrict__ Qo, long long ldq) {
@@ -3573,7 +3574,7 @@ __global__ void __launch_bounds__(512) cholqr_fused_kernel(double* __restrict__ 
     // ---------------- solve: 64 rows of X per work-group ----------------
     const int ld = q | 1;
     double* Y = sm;                                       // [64][ld]
-    double* Lsh = sm + 64 * ld;                           // [q][q]
+    double* Lsh = sm + 64 * ld;                           // FULL: [q][q]; else [NB][q] = rows j0.. of the current panel
     __shared__ unsigned s_seen;
     const long long r0 = (long long)(blockIdx.x - 1) * 64;
     const int nr = (rows - r0 < 64) ? (int)(rows - r0) : 64;
@@ -3600,15 +3601,28 @@ __global__ void __launch_bounds__(512) cholqr_fused_kernel(double* __restrict__ 
             if (s_seen == BASQ_CHOLQR_ABORT && tid == 0 && blockIdx.x == 1 && info[0] == 0) atomicMax(info, q + 1000);
             return;
         }
-        for (int e = tid; e < (q - j0) * NB; e += 512) {   // column panel `panel` of L -> LDS (L1-bypassing loads)
-            const int i = j0 + e / NB, cc = e % NB;
-            if (cc < nb && j0 + cc <= i)
-                Lsh[(size_t)i * q + j0 + cc] = __longlong_as_double((long long)__hip_atomic_load(
-                    (basq_gu64*)(G + (size_t)i * q + j0 + cc), BASQ_RLX_AGENT));
+        if (FULL) {
+            for (int e = tid; e < (q - j0) * NB; e += 512) {   // column panel `panel` of L -> LDS (L1-bypassing loads)
+                const int i = j0 + e / NB, cc = e % NB;
+                if (cc < nb && j0 + cc <= i)
+                    Lsh[(size_t)i * q + j0 + cc] = __longlong_as_double((long long)__hip_atomic_load(
+                        (basq_gu64*)(G + (size_t)i * q + j0 + cc), BASQ_RLX_AGENT));
+            }
+        } else {
+            // rows j0 .. j0 + nb - 1 of L, whole (their left parts were published with the earlier panels, whose drains
+            // precede this panel's in the publishing wave's program order)
+            const int w = j0 + nb;
+            for (int e = tid; e < nb * w; e += 512) {
+                const int cc = e / w, k = e - cc * w;
+                if (k <= j0 + cc)
+                    Lsh[(size_t)cc * q + k] = __longlong_as_double((long long)__hip_atomic_load(
+                        (basq_gu64*)(G + (size_t)(j0 + cc) * q + k), BASQ_RLX_AGENT));
+            }
         }
+        const int lbase = FULL ? j0 : 0;                   // LDS row of L's row j0
         __syncthreads();
         if (c < nb) {
-            const double* lrow = Lsh + (size_t)(j0 + c) * q;
+            const double* lrow = Lsh + (size_t)(lbase + c) * q;
             const double* yrow = Y + r * ld;
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
             int k = 0;
@@ -3629,7 +3643,7 @@ __global__ void __launch_bounds__(512) cholqr_fused_kernel(double* __restrict__ 
 #pragma unroll
             for (int cc = 0; cc < NB; ++cc) {
                 if (cc < nb) {
-                    const double* lrow = Lsh + (size_t)(j0 + cc) * q + j0;
+                    const double* lrow = Lsh + (size_t)(lbase + cc) * q + j0;
                     double v = y[cc];
 #pragma unroll
                     for (int k = 0; k < cc; ++k) v -= y[k] * lrow[k];
@@ -4427,14 +4441,26 @@ int basq_trsm_rows_f64(const double* X, int64_t ldx, int64_t rows, int32_t q, co
 int basq_cholqr_f64(double* G, int32_t q, int32_t* info, double rel_tol, const double* X, int64_t ldx, int64_t rows,
                     double* Q, int64_t ldq, void* stream) {
     if (!G || !info || !X || !Q || q < 1 || rows < 0 || ldx < q || ldq < q || !(rel_tol >= 0.0)) return BASQ_EINVAL;
-    const size_t lds = ((size_t)64 * (q | 1) + (size_t)q * q) * sizeof(double);       // a solver's rows + its image of L
-    if (lds > 163840 - 512 || rows > 64LL * 4096) return BASQ_EUNSUPPORTED;           // q <= 112; every work-group resident
+    const size_t tri = (size_t)q * (q + 1) / 2 * sizeof(double);                        // the factor's packed triangle
+    const size_t lds_full = ((size_t)64 * (q | 1) + (size_t)q * q) * sizeof(double);    // a solver's rows + its image of L
+    const size_t lds_rows = ((size_t)64 * (q | 1) + (size_t)BASQ_CHOL_NB * q) * sizeof(double);   // ... + one row panel of L
+    const bool full = lds_full <= 163840 - 512;                                       // q <= 112
+    const size_t lds = full ? lds_full : (lds_rows > tri ? lds_rows : tri);
+    if (lds > 163840 - 512 || rows > 64LL * 4096) return BASQ_EUNSUPPORTED;           // q <= 200; every work-group resident
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(info, 0, 2 * sizeof(int32_t), st) != hipSuccess) return BASQ_ELAUNCH;   // pivot flag | progress word
-    if (hipFuncSetAttribute((const void*)cholqr_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return BASQ_ELAUNCH;
-    hipLaunchKernelGGL(cholqr_fused_kernel, dim3((unsigned)(1 + (rows + 63) / 64)), dim3(512), lds, st, G, q, info, rel_tol, X,
-                       (long long)ldx, (long long)rows, Q, (long long)ldq);
+    const dim3 grid((unsigned)(1 + (rows + 63) / 64));
+    if (full) {
+        if (hipFuncSetAttribute((const void*)cholqr_fused_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return BASQ_ELAUNCH;
+        hipLaunchKernelGGL(cholqr_fused_kernel<true>, grid, dim3(512), lds, st, G, q, info, rel_tol, X, (long long)ldx,
+                           (long long)rows, Q, (long long)ldq);
+    } else {
+        if (hipFuncSetAttribute((const void*)cholqr_fused_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return BASQ_ELAUNCH;
+        hipLaunchKernelGGL(cholqr_fused_kernel<false>, grid, dim3(512), lds, st, G, q, info, rel_tol, X, (long long)ldx,
+                           (long long)rows, Q, (long long)ldq);
+    }
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }

@@ -350,7 +350,7 @@ int basq_chol_inv_f64(double* G, int32_t q, double* W, int32_t* info, double rel
  *       basq_chol_factor_f64: the orthonormal factor of CholeskyQR straight from X, 64 rows per work-group.  q <= 318.
  */
 int basq_chol_factor_f64(double* G, int32_t q, int32_t* info, double rel_tol, void* stream);
-/*   basq_cholqr_f64: the two above in ONE launch (q <= 112, rows <= 262144): G -> L in place and Q = X L^-T, the solve of
+/*   basq_cholqr_f64: the two above in ONE launch (q <= 200, rows <= 262144): G -> L in place and Q = X L^-T, the solve of
  *       column panel p starting as soon as the factor has produced it (work-group 0 factors and publishes, the others
  *       solve 64 rows each).  Same arithmetic and bits as basq_chol_factor_f64 + basq_trsm_rows_f64.  info: device
  *       int32[2] -- info[0] the pivot flag as above (or q + 1000: a solver gave up waiting for the factor), info[1] the

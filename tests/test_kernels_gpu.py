@@ -882,7 +882,7 @@ def test_cluster_reductions_members_on_different_xcds(tmp_path):
         assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
 
 
-@pytest.mark.parametrize("rows,q", [(10048, 99), (10000, 100), (1000, 30), (130, 7), (5000, 112), (64, 40)])
+@pytest.mark.parametrize("rows,q", [(10048, 99), (10000, 100), (1000, 30), (130, 7), (5000, 112), (64, 40), (10048, 199), (3000, 113), (700, 200)])
 def test_fused_cholqr_equals_factor_plus_solve(hip_ops, rows, q):
     """``basq_cholqr_f64`` (factor and solve in one launch, the solvers following the factor panel by panel through a
     progress word) against ``basq_chol_factor_f64`` + ``basq_trsm_rows_f64``: same arithmetic, same bits -- repeated, with a
