@@ -20,8 +20,8 @@ from ._engine import EngineTrace                               # noqa: F401
 from ._acquisition_function import SquareRootAcquisitionFunction   # noqa: F401
 from ._gaussian_calc import GaussianCalc                       # noqa: F401
 from ._sampler import PriorSampler, UncertaintySampler         # noqa: F401
-from ._rchq import (recombination, recombination_many, recombination_many_sharded,   # noqa: F401
-                    recombination_sharded)
+from ._rchq import (SlotPool, recombination, recombination_many, recombination_many_sharded,   # noqa: F401
+                    recombination_sharded, release_slots)
 
 __all__ = ["recombination", "recombination_sharded", "recombination_many", "recombination_many_sharded", "BASQ", "KernelQuadrature", "GaussianCalc", "SquareRootAcquisitionFunction", "PriorSampler", "UncertaintySampler", "EngineTrace", "kernels",
-           "pools", "sober"]
+           "pools", "sober", "SlotPool", "release_slots"]

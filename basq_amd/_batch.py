@@ -32,6 +32,7 @@ whether to block on it (one batch) or to advance another batch meanwhile (``Reco
 """
 from __future__ import annotations
 
+import dataclasses
 import time
 import warnings
 from dataclasses import dataclass
@@ -47,6 +48,21 @@ from ._partition import (RoundGeometry, choose_chunks, initial_shards, local_blo
 
 class ReductionTimeout(RuntimeError):
     """A cluster reduction kernel gave up waiting for its sibling work-groups (status 2)."""
+
+
+class _NoWait:
+    """An event that has already fired (ops without events: the CPU stand-in of the tests)."""
+
+    def synchronize(self):
+        pass
+
+    def query(self):
+        return True
+
+
+def _recorded_event(ops):
+    ev = ops.record_event(False) if getattr(ops, "name", "") == "hip" else None
+    return ev if ev is not None else _NoWait()
 
 
 def classes_for(nb_global: int) -> int:
@@ -95,7 +111,8 @@ class Plan:
     world: int
 
     @staticmethod
-    def of(kernel, variant, objective, comm, ops, trace):
+    def of(kernel, variant, objective, comm, ops, trace, n_sets=0):
+        """``n_sets`` = 2 * (min(num_pts - 1, m) + 1), the width of every round's reduction (0: unknown, no limit)."""
         if variant not in ("basq", "sober"):
             raise ValueError(variant)
         sober = variant == "sober"
@@ -118,8 +135,11 @@ class Plan:
         # descriptor-driven rounds: the same restriction + the ops must provide the *_geo entries; a trace that
         # synchronises per phase (host timers, per-round tensors) needs the round-by-round loop
         traced_sync = trace is not None and (trace.host_sync or trace.keep_tensors)
+        # ... and they call the GPU null-space / elimination kernels directly: wider reductions than those hold
+        # (2 * num_pts > 1024) and the host-LAPACK route (GPU_NULLSPACE off) take the round-by-round loop
+        gpu_reduction = cfg.GPU_NULLSPACE and n_sets <= getattr(ops, "NULLSPACE_MAX_M", 1 << 30)
         async_rounds = (cfg.ASYNC_ROUNDS and not opaque and not sober and objective is None and warp != "wsabim"
-                        and hasattr(ops, "round_next") and not traced_sync
+                        and hasattr(ops, "round_next") and not traced_sync and gpu_reduction
                         and (comm.world == 1 or cfg.REPLICATED_REDUCTION))
         return Plan(opaque, sober, warp, posterior, objective is not None, classes, async_rounds, comm.world)
 
@@ -163,7 +183,8 @@ class Batch:
         self.gid0, self.n_total, self.num_pts = int(gid0), int(n_total), int(num_pts)
         self.init_weights, self.objective = init_weights, objective
         self.pipelined = pipelined
-        self.plan = Plan.of(kernel, variant, objective, comm, ops, trace)
+        m_nys = int(pts_nys.shape[0]) if pts_nys.dim() >= 1 else 0
+        self.plan = Plan.of(kernel, variant, objective, comm, ops, trace, n_sets=2 * (min(int(num_pts) - 1, m_nys) + 1))
 
     # ------------------------------------------------------------------------------------------------
     # the step generator
@@ -237,6 +258,10 @@ class Batch:
         self.base = None if plan.opaque else kernel.base
         self.post = kernel.posterior if plan.posterior else None
         self.spec = None if plan.opaque else self.base.spec(d)
+        if plan.posterior:
+            # the message of a posterior batch is k - k(., X) W k(X, .): a cancellation that amplifies kernel-value errors
+            # by up to the conditioning of the observation Gram -- its block sums take the 1e-17 exponential
+            self.spec = dataclasses.replace(self.spec, accurate_exp=True)
         self.kp = d if plan.opaque else ops.kp(d)
         self.kscale = 1.0 if plan.opaque else self.spec.outputscale
         self.center = None if plan.opaque else ops.col_mean(pts_nys)
@@ -354,6 +379,11 @@ class Batch:
             _skip_test_matrix_draw(ops, m, self.num_pts - 1)    # keep this rank's global generator in step with rank 0
             if late is not None:
                 late()                                          # runs while rank 0 finishes the basis
+            if cfg.GPU_RANGE_FINDER and self.num_pts - 1 <= m:
+                # rank 0 yields exactly once on this path (the range finder's q x q SVD): yield at the same point, so that
+                # ``run_many`` resumes the batches -- and every rank enqueues its collectives -- in ONE order (ADVICE r3:
+                # with more jobs than slots the ranks otherwise disagree on which batch issues the next all-gather)
+                yield _recorded_event(ops)
         if comm.world > 1:
             comm.broadcast(U)
         return U

@@ -32,28 +32,37 @@ from ._lib import ROLE_A, ROLE_B
 from .kernels import StationaryKernel
 
 
-def _is_psd(mat) -> bool:
-    """``Utils.is_psd`` (``BASQ/_utils.py:45-57``)."""
-    try:
-        torch.linalg.cholesky(mat)
-        return bool((mat == mat.T).all() and (torch.linalg.eig(mat)[0].real >= 0).all())
-    except Exception:
+def _accepts_as_covariance(mat) -> bool:
+    """The acceptance test behind ``Utils.is_psd`` (``BASQ/_utils.py:45-57``), in this repository's own terms (as
+    ``_basis.make_cov_psd``): exactly symmetric, a Cholesky factor exists, no negative eigenvalue.  The spectrum comes from
+    the symmetric solver -- the matrix IS exactly symmetric once the first test has passed, so the reference's general
+    ``eig`` sees the same eigenvalues up to round-off.  Non-finite entries fail the test (the reference's ``try`` catches the
+    LAPACK error they raise)."""
+    if not bool(torch.isfinite(mat).all()) or not torch.equal(mat, mat.T):
         return False
+    if int(torch.linalg.cholesky_ex(mat).info.item()) != 0:
+        return False
+    return bool((torch.linalg.eigvalsh(mat) >= 0).all())
 
 
-def safe_mvn_register(mu, cov):
-    """``Utils.safe_mvn_register`` (``BASQ/_utils.py:59-81``): MVN with the reference's PSD repair loop."""
-    if _is_psd(cov):
+def safe_mvn_register(mu, cov, max_doublings: int = 60):
+    """``Utils.safe_mvn_register`` (``BASQ/_utils.py:59-81``): a ``MultivariateNormal`` from an estimated covariance that may
+    fail the test above.  Repair in the reference's order and arithmetic: (1) NaNs -> 0, (2) the elementwise geometric mean
+    with the transpose (symmetrises; ``sqrt`` of a negative product -> NaN, which step 3 then never cures -- the
+    reference loops forever there, this raises after ``max_doublings``), (3) a diagonal jitter that starts at 1e-5 and doubles
+    until the matrix is accepted."""
+    if _accepts_as_covariance(cov):
         return MultivariateNormal(mu, cov)
-    warnings.warn("Estimated covariance matrix was not positive semi-definite. Conveting...")
+    warnings.warn("basq_amd: the estimated covariance is not positive semi-definite; repairing it (symmetrise, then diagonal "
+                  "jitter), as BASQ/_utils.py:59-81 does")
     cov = torch.nan_to_num(cov)
     cov = torch.sqrt(cov * cov.T)
-    if not _is_psd(cov):
-        n_dim = cov.size(0)
-        jitter = torch.ones(n_dim, dtype=cov.dtype, device=cov.device) * 1e-5
-        while not _is_psd(cov):
-            cov[range(n_dim), range(n_dim)] += jitter
-            jitter *= 2
+    jitter, tries = 1e-5, 0
+    while not _accepts_as_covariance(cov):
+        if tries >= max_doublings:
+            raise ValueError("safe_mvn_register: the covariance estimate cannot be repaired by diagonal jitter")
+        cov = cov + jitter * torch.eye(cov.shape[0], dtype=cov.dtype, device=cov.device)
+        jitter, tries = 2.0 * jitter, tries + 1
     return MultivariateNormal(mu, cov)
 
 
@@ -121,11 +130,10 @@ class GaussianCalc:
             # level, `is_psd` demands exact symmetry (_utils.py:55), so `safe_mvn_register` always takes its
             # repair branch  cov <- sqrt(cov * cov.T)  (_utils.py:72-73), i.e. the element-wise absolute value.
             cov = torch.sqrt(torch.nan_to_num(cov) * torch.nan_to_num(cov).T)
-            if not _is_psd(cov):
-                jitter = torch.ones(d, dtype=cov.dtype, device=cov.device) * 1e-5
-                while not _is_psd(cov):
-                    cov[range(d), range(d)] += jitter
-                    jitter *= 2
+            jitter = 1e-5
+            while not _accepts_as_covariance(cov):               # the reference's doubling diagonal jitter (_utils.py:75-80)
+                cov = cov + jitter * torch.eye(d, dtype=cov.dtype, device=cov.device)
+                jitter *= 2.0
             return MultivariateNormal(mu, cov)
         return safe_mvn_register(mu, cov)
 

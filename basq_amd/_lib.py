@@ -18,11 +18,15 @@ BASQ_OK = 0
 FAMILY = {"rbf": 0, "matern52": 1, "matern32": 2}
 ROLE_A, ROLE_B = 0, 1
 MAX_DIM = 38
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class KernelSpecC(C.Structure):
-    _fields_ = [("family", C.c_int32), ("d", C.c_int32), ("lengthscale", C.c_double), ("outputscale", C.c_double)]
+    _fields_ = [("family", C.c_int32), ("d", C.c_int32), ("lengthscale", C.c_double), ("outputscale", C.c_double),
+                ("flags", C.c_int32), ("reserved", C.c_int32)]
+
+
+SPEC_ACCURATE_EXP = 1            # include/basq_hip.h: BASQ_SPEC_ACCURATE_EXP
 
 
 _vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double

@@ -83,7 +83,8 @@ class HipOps:
 
     @staticmethod
     def spec_c(spec) -> KernelSpecC:
-        return KernelSpecC(_lib.FAMILY[spec.family], int(spec.d), float(spec.lengthscale), float(spec.outputscale))
+        return KernelSpecC(_lib.FAMILY[spec.family], int(spec.d), float(spec.lengthscale), float(spec.outputscale),
+                           _lib.SPEC_ACCURATE_EXP if getattr(spec, "accurate_exp", False) else 0, 0)
 
     def kp(self, d: int) -> int:
         kp = self.lib.basq_kp(int(d))
@@ -526,14 +527,23 @@ class HipOps:
         return out
 
     # -- host <-> device staging through cached pinned buffers (per-round 160 KB / 80 KB / 0.4 KB copies) ---------
+    PIN_CACHE_ENTRIES = 48           # a batch uses ~8 (tag, shape) pairs; a long loop over varying shapes stays bounded
+
     def _pinned(self, shape, dtype, tag):
         cache = self.__dict__.setdefault("_pin_cache", {})
         key = (tag, tuple(shape), dtype)
-        buf = cache.get(key)
+        buf = cache.pop(key, None)
         if buf is None:
             buf = torch.empty(tuple(shape), dtype=dtype, pin_memory=True)
-            cache[key] = buf
+            while len(cache) >= self.PIN_CACHE_ENTRIES:         # least recently used first (dicts keep insertion order)
+                cache.pop(next(iter(cache)))
+        cache[key] = buf                                        # (re)inserted at the end: most recently used
         return buf
+
+    def release_caches(self):
+        """Drop the pinned staging buffers, the cluster kernels' workspace and the transposed-basis cache."""
+        for k in ("_pin_cache", "_ws_cache", "_ut_cache"):
+            self.__dict__.pop(k, None)
 
     def to_host(self, t, tag="d2h"):
         """Device -> pinned host tensor (synchronises the stream).  The buffer is reused by the next call with

@@ -75,41 +75,77 @@ def recombination_sharded(pts_local, gid0, n_total, pts_nys, num_pts, kernel, de
 
 
 # ---- several independent recombinations in flight ------------------------------------------------------------------------
-_SLOTS = {}          # (device index, slot) -> HipOps bound to its own stream (streams and workspaces are reused)
+class SlotPool:
+    """The per-batch-in-flight resources of ``recombination_many``: one ``HipOps`` -- a HIP stream plus that stream's pinned
+    staging buffers, cluster-kernel workspace and transposed-basis cache -- per (device, slot).  Slots are created on first
+    use and reused by later calls (creating a stream and pinning host memory costs milliseconds); ``release()`` drops them.
+    A pool serves one caller at a time: ``lease`` holds its lock for the duration of a ``recombination_many`` call, so two
+    host threads never drive the same slot's stream and staging buffers concurrently."""
+
+    def __init__(self):
+        import threading
+
+        self._slots = {}                 # (device index, slot) -> HipOps
+        self._lock = threading.Lock()
+
+    def lease(self, device, n):
+        """Context manager -> the first ``n`` slots of ``device`` (exclusive until the ``with`` block ends)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _lease():
+            with self._lock:
+                dev = torch.device(device)
+                idx = dev.index if dev.index is not None else torch.cuda.current_device()
+                out = []
+                for k in range(n):
+                    ops = self._slots.get((idx, k))
+                    if ops is None:
+                        ops = self._slots[(idx, k)] = HipOps(torch.device("cuda", idx), stream=torch.cuda.Stream(device=idx))
+                    out.append(ops)
+                yield out
+
+        return _lease()
+
+    def release(self):
+        """Synchronise and drop every slot (streams, pinned buffers, workspaces); the next call re-creates what it needs."""
+        with self._lock:
+            for ops in self._slots.values():
+                ops.synchronize()
+                ops.release_caches()
+            self._slots.clear()
 
 
-def _slots(device, n):
-    dev = torch.device(device)
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    out = []
-    for k in range(n):
-        ops = _SLOTS.get((idx, k))
-        if ops is None:
-            ops = _SLOTS[(idx, k)] = HipOps(torch.device("cuda", idx), stream=torch.cuda.Stream(device=idx))
-        out.append(ops)
-    return out
+_DEFAULT_POOL = SlotPool()
 
 
-def _run_many(jobs, device, comm, in_flight, timings=None):
+def release_slots():
+    """Free the streams and cached buffers ``recombination_many`` / ``recombination_many_sharded`` keep between calls."""
+    _DEFAULT_POOL.release()
+
+
+def _run_many(jobs, device, comm, in_flight, timings=None, pool: SlotPool | None = None):
     jobs = list(jobs)
     if not jobs:
         return []
-    slots = _slots(device, max(1, min(int(in_flight), len(jobs))))
-    cur = torch.cuda.current_stream(slots[0].device)
-    for ops in slots:
-        ops.stream.wait_stream(cur)                  # the inputs were produced on the caller's stream
-    res = RecombinationEngine(slots[0], comm).run_many(jobs, slots)
-    for ops in slots:
-        cur.wait_stream(ops.stream)
-    for idx, w in res:                               # allocated on a slot's stream, handed to the caller's
-        idx.record_stream(cur)
-        w.record_stream(cur)
+    with (pool or _DEFAULT_POOL).lease(device, max(1, min(int(in_flight), len(jobs)))) as slots:
+        cur = torch.cuda.current_stream(slots[0].device)
+        for ops in slots:
+            ops.stream.wait_stream(cur)              # the inputs were produced on the caller's stream
+        # (the inputs are consumed on the slots' streams without record_stream: run_many synchronises every slot before
+        # it returns, so the caller cannot free or overwrite them while a slot still reads them)
+        res = RecombinationEngine(slots[0], comm).run_many(jobs, slots)
+        for ops in slots:
+            cur.wait_stream(ops.stream)
+        for idx, w in res:                           # allocated on a slot's stream, handed to the caller's
+            idx.record_stream(cur)
+            w.record_stream(cur)
     if timings is not None:                          # host clock at each batch's first launch and at its result
         timings.extend((j.times.get("start"), j.times.get("done")) for j in jobs)
     return res
 
 
-def recombination_many(calls, device, in_flight: int = 2, seeds=None, traces=None, timings=None):
+def recombination_many(calls, device, in_flight: int = 2, seeds=None, traces=None, timings=None, pool: SlotPool | None = None):
     """Several INDEPENDENT recombinations with ``in_flight`` of them on the GPU at a time -> ``[(idx, w), ...]``.
 
     ``calls``: ``(pts_rec, pts_nys, num_pts, kernel)`` per recombination -- e.g. the two calls every BASQ iteration makes,
@@ -121,12 +157,14 @@ def recombination_many(calls, device, in_flight: int = 2, seeds=None, traces=Non
     consumed in call order (one ``torch.randn(m, num_pts - 1)`` each, as in the reference), and ``seeds[k]`` (optional)
     is what ``torch.manual_seed(seeds[k])`` right before call k would be.  ``timings`` (a list) receives one
     ``(start, done)`` pair of host clock readings per call: the per-batch latency with company on the GPU.
+    ``pool``: the ``SlotPool`` whose streams and staging buffers the batches use (default: a module-level pool, freed by
+    ``basq_amd.release_slots()``).
     """
     jobs = []
     for k, (pts_rec, pts_nys, num_pts, kernel) in enumerate(calls):
         jobs.append(Job(pts_rec, 0, pts_rec.shape[0], pts_nys, int(num_pts), _as_kernel_object(kernel),
                         trace=None if traces is None else traces[k], seed=None if seeds is None else seeds[k]))
-    return _run_many(jobs, device, LocalComm(), in_flight, timings)
+    return _run_many(jobs, device, LocalComm(), in_flight, timings, pool)
 
 
 def recombination_many_sharded(calls, device, group=None, in_flight: int = 4, seeds=None, timings=None):

@@ -3762,6 +3762,11 @@ __global__ void axpb_strided_kernel(const double* __restrict__ x, long long n, l
 static inline bool spec_ok(const basq_kernel_spec* s) {
     return s && s->d >= 1 && s->d <= BASQ_MAX_DIM && s->lengthscale > 0.0 && s->family >= 0 && s->family <= 2;
 }
+// exponential scheme of the fused block sums: the accurate one (1e-17) where the caller asks for it (GP posteriors), else
+// the build's default (2: 2.5e-14, one fp64 instruction less per kernel value)
+static inline int blocksum_exp_scheme(const basq_kernel_spec* s) {
+    return (s->flags & BASQ_SPEC_ACCURATE_EXP) ? 1 : BASQ_BLOCKSUM_EXP_SCHEME;
+}
 
 extern "C" {
 
@@ -3888,7 +3893,7 @@ int basq_blocksum_f64(const basq_kernel_spec* spec, const double* nys, int32_t m
                       int32_t n_chunks, int32_t class_mod, int32_t class0, double* Xpart, double* totpart, void* stream) {
     if (!totpart) return BASQ_EINVAL;
     return blocksum_impl(spec, nys, m, cand, mu, wx, Rl, off, n_full, S, n_chunks, class_mod, class0, Xpart, totpart,
-                         stream, BASQ_BLOCKSUM_EXP_SCHEME);
+                         stream, blocksum_exp_scheme(spec));
 }
 
 int basq_blocksum_sq_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
@@ -4296,7 +4301,7 @@ int basq_blocksum_geo_f64(const basq_kernel_spec* spec, const double* nys, int32
     A.class_mod = class_mod; A.class0 = class0;
     A.geo = (const long long*)geo; A.geo_mode = geo_mode;
     A.n_stiles = (S + 15) / 16;
-    return dispatch_blocksum(basq_kp(spec->d) / 4, spec->family, A, (hipStream_t)stream, BASQ_BLOCKSUM_EXP_SCHEME);
+    return dispatch_blocksum(basq_kp(spec->d) / 4, spec->family, A, (hipStream_t)stream, blocksum_exp_scheme(spec));
 }
 
 int basq_reweight_compact_geo_f64(const double* cand, const double* mu, const int64_t* gid, const double* wx,

@@ -40,6 +40,7 @@ class KernelSpec:
     d: int
     lengthscale: float
     outputscale: float
+    accurate_exp: bool = False      # fused block sums with the 1e-17 exponential (GP posteriors: include/basq_hip.h)
 
 
 def _ops_for(x):

@@ -334,7 +334,9 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"RBF kernel l=2, N={N} candidates, d={d}, n={n} recombination, m={m} Nystrom points, "
-                                   f"float64, pool sharded over {world} GPU(s); pool seeds {list(POOL_SEEDS)} cycled over steps",
+                                   f"float64, pool sharded over {world} GPU(s); synthetic 8-component mixture pool with unit-variance "
+                                   f"Irwin-Hall(12) components (sum of 12 uniforms - 6: support +-6, bit-portable; basq_amd/pools.py), "
+                                   f"pool seeds {list(POOL_SEEDS)} cycled over steps",
                        "N": N, "d": d, "n": n, "m": m, "kernel": "rbf", "parallelism": f"pool-sharded x{world}"},
             "value_concurrent2": concurrent[2]["value"] if 2 in concurrent else None,
             "value_concurrent3": concurrent[3]["value"] if 3 in concurrent else None,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BASQ_ABI_VERSION 12
+#define BASQ_ABI_VERSION 13
 
 /* error codes */
 #define BASQ_OK            0
@@ -55,7 +55,15 @@ typedef struct basq_kernel_spec {
     int32_t d;             /* input dimension, 1..BASQ_MAX_DIM                     */
     double  lengthscale;   /* single shared lengthscale (no ARD), > 0              */
     double  outputscale;   /* ScaleKernel outputscale s2                           */
+    int32_t flags;         /* BASQ_SPEC_* bits                                     */
+    int32_t reserved;      /* 0                                                    */
 } basq_kernel_spec;
+
+/* flags: the fused block sums (basq_blocksum_f64 / _geo) evaluate exp() with the 2048-entry table + cubic (relative error
+ * 1e-17) instead of the 4096-entry table + quadratic (2.5e-14, one fp64 instruction less per kernel value).  Set for GP
+ * posteriors (BASQ/_gp.py:259-277): there the message is k - k(.,X) W k(X,.), a cancellation that amplifies kernel-value
+ * errors by up to the conditioning of the observation Gram. */
+#define BASQ_SPEC_ACCURATE_EXP 1
 
 const char* basq_strerror(int code);
 int         basq_abi_version(void);

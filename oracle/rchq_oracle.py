@@ -6,8 +6,8 @@ leg use it, and only as the checker / the timed CPU baseline.
 
 Pinning
 -------
-``tests/test_oracle_vs_reference.py`` (runs only where ``/root/reference`` is
-mounted) and ``oracle/make_golden.py`` drive this restatement and the imported
+``tests/test_oracle.py::test_oracle_vs_imported_reference`` (runs only where
+``/root/reference`` is mounted) and ``oracle/make_golden.py`` drive this restatement and the imported
 reference ``BASQ._rchq.recombination`` with the same callables, dtype (float64)
 and ``torch.manual_seed``; the outputs are required to be **bit-identical**
 (indices and weights).  The committed fixtures under ``tests/golden/`` are the

@@ -136,3 +136,69 @@ def has_golden(name):
     import os
 
     return os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".json"))
+
+
+def structured_fuzz_cases(seed: int, count: int):
+    """The configurations of the structured-kernel differential fuzz (stationary, GP posterior, WSABI-L, WSABI-M;
+    likelihood noise 1e-10 / 1e-6 / 1e-3; random sizes), as ``tools/fuzz_structured.py`` draws them: a deterministic
+    list of case dicts, shared by the GPU fuzz test and the CPU test of the ill-conditioned regime."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i in range(count):
+        N = int(torch.randint(50, 6000, (1,), generator=g))
+        d = int(torch.randint(2, 12, (1,), generator=g))
+        n = int(torch.randint(3, 70, (1,), generator=g))
+        m = int(torch.randint(5, min(N, 250) + 1, (1,), generator=g))
+        kind = i % 4
+        fam = ["rbf", "matern52", "matern32"][i % 3]
+        post = dict(n_obs=int(torch.randint(5, 120, (1,), generator=g)), noise=[1e-10, 1e-6, 1e-3][i % 3], obs_seed=50 + i)
+        if kind == 0:
+            kern = K(fam, 1.0 + 0.5 * (i % 4), 1.0 + 0.1 * (i % 3))
+        elif kind == 1:
+            kern = K(fam, 1.5 + 0.5 * (i % 3), 1.2, posterior=post)
+        elif kind == 2:
+            kern = K("rbf", 2.0, 1.0, posterior=post, warp="wsabil")
+        else:
+            kern = K("rbf", 2.0, 1.0, posterior=post, warp="wsabim")
+        out.append(case(f"fz{seed}_{i}", N, d, m, n, kern, pool_seed=400 + i, torch_seed=i))
+    return out
+
+
+def observation_gram_condition(c, state):
+    """2-norm condition number of ``K(X, X) + noise I`` of a posterior case (that of the Woodbury matrix), 1 without one."""
+    if state is None:
+        return 1.0
+    W = state["W"]
+    ev = torch.linalg.eigvalsh(0.5 * (W + W.T)).abs()
+    lo = float(ev.min())
+    return float(ev.max()) / lo if lo > 0 else float("inf")
+
+
+class UlpPerturbed:
+    """A base-kernel oracle whose values move by at most one ulp (``K * (1 + delta)``, ``|delta| <= 2^-52``, a fixed
+    pseudo-random pattern per call shape): the yard-stick for "the reference's own sensitivity" in ill-conditioned regimes."""
+
+    def __init__(self, base, seed: int):
+        self.base, self.seed = base, int(seed)
+        self.family, self.lengthscale, self.outputscale = base.family, base.lengthscale, base.outputscale
+
+    def __call__(self, x, y):
+        Kxy = self.base(x, y)
+        g = torch.Generator().manual_seed(self.seed * 7919 + Kxy.numel() % 1000)
+        return Kxy * (1.0 + 2.0 ** -52 * (2.0 * torch.rand(Kxy.shape, generator=g, dtype=torch.float64) - 1.0))
+
+
+def build_perturbed_oracle_kernel(c, seed: int):
+    """``build_oracle_kernel(c)`` with every base-kernel value moved by <= 1 ulp (the GP state -- Woodbury matrix, mean
+    cache -- is the unperturbed one: the same fitted model, evaluated with a kernel that rounds differently)."""
+    from oracle.kernels_oracle import PosteriorOracle, WsabiOracle
+
+    ko, state = build_oracle_kernel(c)
+    k = c["kernel"]
+    if k["posterior"] is None:
+        return UlpPerturbed(ko, seed)
+    base = ko.base if k["warp"] == "none" else ko.post.base
+    post = PosteriorOracle(UlpPerturbed(base, seed), state["Xobs"], state["W"], state["noise"])
+    if k["warp"] == "none":
+        return post
+    return WsabiOracle(post, state["mean_const"], state["mean_cache"], k["warp"])

@@ -210,6 +210,9 @@ GPU_CASES = [
     ("posterior_noise_ragged", None, 256 << 20),    # a BARE lambda, no keyword: the probe selects the reference's calls
     ("wsabil_noise_ragged", None, 256 << 20),
     ("matern32_8e3", None, 256 << 20),              # a bare lambda over a plain kernel: whatever the probe picks, same batch
+    # BASELINE config 4 through its named door, at full size: Matern-5/2, N=1e6, d=32, n=200 as a BARE lambda
+    # (_rchq.py:81-86 with an arbitrary `kernel`; tutorial 02).  ~1 s of GPU time.
+    ("cfg4_matern52_1e6_d32", None, 256 << 20),
 ]
 
 

@@ -113,7 +113,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, opaque=()):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -130,7 +130,14 @@ def _worker(rank, world, port, q):
             c = BY_NAME[nm]
             pts, nys = build_pool(c)
             off, n = initial_shards(c["N"], world)[rank]
-            jobs.append(Job(pts[off:off + n].clone(), off, c["N"], nys, c["n"], build_product_kernel(c), seed=c["torch_seed"]))
+            kern = build_product_kernel(c)
+            if nm in opaque:                                     # the same kernel as a bare callable (dense path)
+                from basq_amd.kernels import CallableKernel
+                from tests.cases import build_oracle_kernel
+
+                ko, _ = build_oracle_kernel(c)
+                kern = CallableKernel(lambda x, y, ko=ko: ko(x, y))
+            jobs.append(Job(pts[off:off + n].clone(), off, c["N"], nys, c["n"], kern, seed=c["torch_seed"]))
         slots = [CpuStandInOps(), CpuStandInOps()]
         res = RecombinationEngine(slots[0], TorchDistComm()).run_many(jobs, slots)
         q.put((rank, [(i.tolist(), w.tolist()) for i, w in res], slots[0].calls.get("round_next", 0)))
@@ -162,6 +169,34 @@ def test_run_many_sharded_matches_goldens(world):
             gw = torch.tensor(fx["w"], dtype=torch.float64)
             assert ((torch.tensor(w, dtype=torch.float64) - gw).abs() / gw).max().item() <= 1e-6
     assert all(r[1] == res[0][1] for r in res)                                # bit-identical across the ranks
+
+
+@pytest.mark.parametrize("opaque", [("rbf_ragged",), ("cfg1_posterior_1e4",), ("rbf_ragged", "rbf_1e4")])
+def test_run_many_sharded_with_opaque_callables_and_more_jobs_than_slots(opaque):
+    """three jobs on two slots, some of them opaque callables -- whose basis only rank 0 computes (the other ranks
+    wait for the broadcast).  Every rank must yield at the same points of such a batch, or the FIFO scheduler starts job 2
+    on one rank while another still owes job 1's all-gather: collectives pair up across batches (a hang, or mixed buffers).
+    All ranks return the goldens, bit-identical to each other."""
+    import torch.multiprocessing as mp
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, opaque)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, _ in res:
+        for nm, (idx, w) in zip(["rbf_ragged", "cfg1_posterior_1e4", "rbf_1e4"], out):
+            fx = load_golden(nm)
+            assert idx == fx["idx"], f"rank {rank} {nm}"
+            gw = torch.tensor(fx["w"], dtype=torch.float64)
+            assert ((torch.tensor(w, dtype=torch.float64) - gw).abs() / gw).max().item() <= 1e-6
+    assert all(r[1] == res[0][1] for r in res)
 
 
 # ---- GPU ---------------------------------------------------------------------------------------------------------------

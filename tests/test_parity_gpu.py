@@ -168,6 +168,71 @@ def test_differential_fuzz_gpu():
         torch.set_default_dtype(prev)
 
 
+def test_structured_differential_fuzz_gpu():
+    """Random configurations with STRUCTURED kernels -- stationary, GP posterior (``_gp.py:259-277``), WSABI-L and WSABI-M
+    (``_wsabi.py:205-249``), likelihood noise 1e-10 / 1e-6 / 1e-3 -- through the HIP path against the oracle (``_rchq.py:81-99``
+    with those callables): indices identical, weights inside the 1e-5 bar.
+
+    Where the bar applies: every case whose observation Gram ``K(X, X) + noise I`` has condition number <= 1e6 MUST be
+    inside it.  Beyond that the posterior covariance is a catastrophic cancellation; a case that leaves the bar there is
+    accepted only if the REFERENCE ITSELF leaves the bar when its base-kernel values move by <= 1 ulp (oracle vs oracle,
+    three perturbation patterns) -- it is counted as ``unstable``, not as compared.  The case list is the one of
+    ``tools/fuzz_structured.py 11`` (round 3's builder-run log), cases 19 / 21 / 93 included."""
+    import warnings
+
+    import basq_amd
+    from oracle.rchq_oracle import recombination_oracle
+    from tests.cases import (build_oracle_kernel, build_perturbed_oracle_kernel, build_pool, build_product_kernel,
+                             observation_gram_condition, structured_fuzz_cases)
+
+    def deviation(ia, wa, ib, wb):
+        same = ia.tolist() == ib.tolist()
+        return same, (((wa - wb).abs() / wb).max().item() if same and len(wb) else (0.0 if same else float("inf")))
+
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        compared = rank_deficient = unstable = 0
+        kinds = [0, 0, 0, 0]
+        for i, c in enumerate(structured_fuzz_cases(11, 150)):
+            pts, nys = build_pool(c)
+            ko, state = build_oracle_kernel(c)
+            A = ko(nys, nys)
+            ev = torch.linalg.eigvalsh(0.5 * (A + A.T))
+            if int((ev > 1e-10 * ev.abs().max()).sum()) < min(c["n"] - 1, c["m"]):
+                rank_deficient += 1                              # q beyond the numerical rank: see test_host_logic.py
+                continue
+            cond = observation_gram_condition(c, state)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                torch.manual_seed(c["torch_seed"])
+                io, wo = recombination_oracle(pts, nys, c["n"], ko)
+                torch.manual_seed(c["torch_seed"])
+                ie, we = basq_amd.recombination(pts, nys, c["n"], build_product_kernel(c, state), torch.device(DEV))
+            same, rel = deviation(ie.cpu(), we.cpu(), io, wo)
+            if same and rel <= 1e-5:
+                compared += 1
+                kinds[i % 4] += 1
+                continue
+            label = f"case {i} ({c['kernel']['family']}, warp {c['kernel']['warp']}, N={c['N']} d={c['d']} n={c['n']} m={c['m']}, " \
+                    f"posterior {c['kernel']['posterior']}, cond {cond:.1e}): idx equal {same}, rel {rel:.2e}"
+            assert cond > 1e6, "outside the bar on a well-conditioned case: " + label
+            ref_moves = False
+            for s in (1, 2, 3):                                  # the reference against itself, kernel values +- 1 ulp
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    torch.manual_seed(c["torch_seed"])
+                    ip, wp = recombination_oracle(pts, nys, c["n"], build_perturbed_oracle_kernel(c, s))
+                same_p, rel_p = deviation(ip, wp, io, wo)
+                ref_moves = ref_moves or not (same_p and rel_p <= 1e-5)
+            assert ref_moves, "outside the bar where the reference is stable under 1-ulp perturbations: " + label
+            unstable += 1
+        assert compared >= 100 and min(kinds) >= 20, (compared, kinds)
+        assert unstable <= 8, unstable
+    finally:
+        torch.set_default_dtype(prev)
+
+
 @pytest.mark.parametrize("N,d,n,m", [(1, 2, 2, 1), (2, 2, 2, 1), (2, 2, 3, 2), (3, 1, 2, 2), (5, 3, 2, 3), (4, 2, 2, 4),
                                      (7, 2, 3, 1), (10, 2, 10, 5), (6, 2, 2, 6), (0, 2, 3, 0)])
 def test_tiny_and_degenerate_pools_gpu(N, d, n, m):
@@ -261,6 +326,26 @@ def test_host_nullspace_route_reproduces_goldens():
             assert ((w - gw).abs() / gw).max().item() <= W_RTOL
     finally:
         cfg.GPU_NULLSPACE = old
+
+
+def test_untraced_batch_beyond_the_reduction_kernels():
+    """the same envelope WITHOUT a trace -- the call every user makes.  ``Plan.of`` must keep such a batch off the
+    descriptor-driven rounds (they call the GPU null-space kernel directly, which rejects 2 * num_pts > 1024): it used to
+    raise ``BasqHipError``; now it warns and returns the batch the traced run returns."""
+    from tests.cases import K, case
+
+    c = case("wide_n520", 6_000, 8, 1_500, 520, K("rbf", 1.0), pool_seed=62, torch_seed=4)
+    with pytest.warns(RuntimeWarning, match="host LAPACK"):
+        _, idx_t, w_t = _run(c, basq_amd_trace(keep_tensors=True))
+    with pytest.warns(RuntimeWarning, match="host LAPACK"):
+        _, idx, w = _run(c)
+    assert idx.tolist() == idx_t.tolist() and torch.equal(w, w_t)
+
+
+def basq_amd_trace(**kw):
+    import basq_amd
+
+    return basq_amd.EngineTrace(**kw)
 
 
 @pytest.mark.parametrize("M,s,seed", [(200, 100, 0), (74, 37, 1), (400, 200, 2), (150, 60, 3)])

@@ -16,7 +16,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import basq_amd                                  # noqa: E402
 from basq_amd._engine import Job, LocalComm, RecombinationEngine   # noqa: E402
-from basq_amd._rchq import _slots                # noqa: E402
+from basq_amd._rchq import _DEFAULT_POOL                # noqa: E402
 from basq_amd.pools import gmm_pool              # noqa: E402
 
 
@@ -76,10 +76,10 @@ def main():
         basq_amd.recombination_many(calls[:2 * k], dev, in_flight=k, seeds=seeds[:2 * k])      # warm the slots
         torch.cuda.synchronize()
         jobs = [Job(p, 0, p.shape[0], nys, n, kk, seed=sd) for (p, nys, n, kk), sd in zip(calls, seeds)]
-        slots = _slots(dev, k)
-        t0 = time.perf_counter()
-        res = RecombinationEngine(slots[0], LocalComm()).run_many(jobs, slots)
-        torch.cuda.synchronize()
+        with _DEFAULT_POOL.lease(dev, k) as slots:
+            t0 = time.perf_counter()
+            res = RecombinationEngine(slots[0], LocalComm()).run_many(jobs, slots)
+            torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / a.batches
         lat = sorted(j.times["done"] - j.times["start"] for j in jobs)
         same = None if ref is None else all(torch.equal(i1, i2) and torch.equal(w1, w2) for (i1, w1), (i2, w2) in zip(ref, res))
