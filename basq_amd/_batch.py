@@ -997,6 +997,8 @@ class OpaqueSums:
         if Rl == 0:
             return E.unsqueeze(0), T
         nc_max = max(S, min(Rl, kernel.chunk_bytes // (8 * m)))
+        nc_max = (nc_max // S) * S                              # whole blocks: every chunk starts at the same set, and at an
+                                                                # even position when the shard does (16-byte loads, see the kernel)
         ones = ops.zeros(1, min(nc_max, Rl)) + 1.0
         for p0 in range(0, Rl, nc_max):
             nc = min(nc_max, Rl - p0)

@@ -3727,6 +3727,128 @@ __global__ void __launch_bounds__(256) dense_blocksum_kernel(const double* __res
     }
 }
 
+// The same sums with 16 bytes per lane (round 4): a thread owns a PAIR of neighbouring sets (2t, 2t+1) -- two consecutive
+// candidates of a row = one 16-byte load -- in one of NS position slices (slice k takes the blocks k, k + NS, ... of the
+// chunk), JR = 8 rows per work-group and two blocks per trip: 16 independent 16-byte loads in flight per lane (the 8-byte
+// form had ~10 of 8 bytes and ran at 3.0 TB/s, latency-bound: profiles/r03_k_cfg4_opaque_kernel_stats.csv).  The slices
+// are added in slice order through LDS, the ragged tail (all of it belongs to set S-1) is spread over the work-group
+// and added wave by wave: every sum has a fixed order.  Needs S even and an even first position (the engine cuts its
+// chunks that way); everything else takes the kernel above.
+struct __attribute__((aligned(8))) DPair { double x, y; };
+
+template <int JR, bool SQ>
+__global__ void __launch_bounds__(1024) dense_blocksum_pairs_kernel(const double* __restrict__ C, int m, long long nc,
+                                                                    long long ldc, const double* __restrict__ mu,
+                                                                    long long pg0, long long n_full, int S, int NS,
+                                                                    double scale, double* __restrict__ E) {
+    extern __shared__ double dbs_red[];                          // [NS][JR][S] slice partials, then [waves][JR] tail partials
+    const int half = S >> 1;
+    const int t = threadIdx.x % half, k = threadIdx.x / half;   // set pair, position slice (blockDim.x = half * NS)
+    const int j0 = blockIdx.x * JR;
+    const double* rows[JR];
+#pragma unroll
+    for (int jr = 0; jr < JR; ++jr) rows[jr] = C + (long long)((j0 + jr < m) ? (j0 + jr) : (m - 1)) * ldc;
+    const long long blk_end = (pg0 + nc < n_full) ? (pg0 + nc) : n_full;
+    const long long oe = blk_end - pg0;                          // block positions of this chunk: offsets [0, oe)
+    const int ph = (int)(pg0 % S);                               // even
+    long long o = (long long)(((2 * t - ph) % S + S) % S) + (long long)k * S;   // first offset of set 2t in slice k
+    const long long step = (long long)NS * S;
+    double a0[JR], a1[JR];
+#pragma unroll
+    for (int jr = 0; jr < JR; ++jr) { a0[jr] = 0.0; a1[jr] = 0.0; }
+    for (; o + step + 1 < oe; o += 2 * step) {                   // two blocks per trip: 2 JR + 2 loads of 16 bytes in flight
+        const DPair w0 = *reinterpret_cast<const DPair*>(mu + o), w1 = *reinterpret_cast<const DPair*>(mu + o + step);
+        DPair c0[JR], c1[JR];
+#pragma unroll
+        for (int jr = 0; jr < JR; ++jr) {
+            c0[jr] = *reinterpret_cast<const DPair*>(rows[jr] + o);
+            c1[jr] = *reinterpret_cast<const DPair*>(rows[jr] + o + step);
+        }
+#pragma unroll
+        for (int jr = 0; jr < JR; ++jr) {
+            a0[jr] = __builtin_fma(SQ ? w0.x * c0[jr].x : w0.x, c0[jr].x, a0[jr]);
+            a1[jr] = __builtin_fma(SQ ? w0.y * c0[jr].y : w0.y, c0[jr].y, a1[jr]);
+            a0[jr] = __builtin_fma(SQ ? w1.x * c1[jr].x : w1.x, c1[jr].x, a0[jr]);
+            a1[jr] = __builtin_fma(SQ ? w1.y * c1[jr].y : w1.y, c1[jr].y, a1[jr]);
+        }
+    }
+    for (; o + 1 < oe; o += step) {
+        const DPair w0 = *reinterpret_cast<const DPair*>(mu + o);
+#pragma unroll
+        for (int jr = 0; jr < JR; ++jr) {
+            const DPair c = *reinterpret_cast<const DPair*>(rows[jr] + o);
+            a0[jr] = __builtin_fma(SQ ? w0.x * c.x : w0.x, c.x, a0[jr]);
+            a1[jr] = __builtin_fma(SQ ? w0.y * c.y : w0.y, c.y, a1[jr]);
+        }
+    }
+    if (o < oe) {                                                // the chunk's block positions end inside this pair
+        const double w0 = mu[o];
+#pragma unroll
+        for (int jr = 0; jr < JR; ++jr) {
+            const double c = rows[jr][o];
+            a0[jr] = __builtin_fma(SQ ? w0 * c : w0, c, a0[jr]);
+        }
+    }
+    // slices -> slice 0, in slice order
+    if (NS > 1) {
+        if (k > 0) {
+#pragma unroll
+            for (int jr = 0; jr < JR; ++jr) {
+                double* dst = dbs_red + ((long long)(k * JR + jr)) * S + 2 * t;
+                dst[0] = a0[jr];
+                dst[1] = a1[jr];
+            }
+        }
+        __syncthreads();
+        if (k == 0) {
+            for (int kk = 1; kk < NS; ++kk)
+#pragma unroll
+                for (int jr = 0; jr < JR; ++jr) {
+                    const double* src = dbs_red + ((long long)(kk * JR + jr)) * S + 2 * t;
+                    a0[jr] += src[0];
+                    a1[jr] += src[1];
+                }
+        }
+    }
+    // ragged tail: offsets [tl, nc) all belong to set S-1 (BASQ/_rchq.py:91-99)
+    const long long tl = ((n_full > pg0) ? n_full : pg0) - pg0;
+    if (tl < nc) {                                               // work-group uniform
+        double tt[JR];
+#pragma unroll
+        for (int jr = 0; jr < JR; ++jr) tt[jr] = 0.0;
+        for (long long q = tl + threadIdx.x; q < nc; q += blockDim.x) {
+            const double w0 = mu[q];
+#pragma unroll
+            for (int jr = 0; jr < JR; ++jr) {
+                const double c = rows[jr][q];
+                tt[jr] = __builtin_fma(SQ ? w0 * c : w0, c, tt[jr]);
+            }
+        }
+#pragma unroll
+        for (int jr = 0; jr < JR; ++jr)
+            for (int sh = 32; sh >= 1; sh >>= 1) tt[jr] += __shfl_xor(tt[jr], sh, 64);
+        __syncthreads();                                         // the slice partials have been consumed
+        const int wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
+        if ((threadIdx.x & 63) == 0)
+#pragma unroll
+            for (int jr = 0; jr < JR; ++jr) dbs_red[wave * JR + jr] = tt[jr];
+        __syncthreads();
+        if (k == 0 && t == half - 1)
+            for (int w = 0; w < nwaves; ++w)
+#pragma unroll
+                for (int jr = 0; jr < JR; ++jr) a1[jr] += dbs_red[w * JR + jr];
+    }
+    if (k == 0) {
+#pragma unroll
+        for (int jr = 0; jr < JR; ++jr)
+            if (j0 + jr < m) {
+                double* e = E + (long long)(j0 + jr) * S + 2 * t;
+                e[0] += scale * a0[jr];
+                e[1] += scale * a1[jr];
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Box-Muller transform of torch's CPU ``normal_fill`` (aten/native/cpu/DistributionTemplates.h): blocks of 16
 // uniforms -> 16 normals (u1 = 1 - u[j], u2 = u[j+8]; r = sqrt(-2 log u1), t = 2 pi u2; out[j] = r cos t,
@@ -4359,6 +4481,35 @@ int basq_dense_blocksum_f64(const double* C, int32_t m, int64_t nc, int64_t ldc,
     if (!C || !mu || !E || m < 1 || nc < 0 || ldc < nc || pg0 < 0 || n_full < 0 || S < 1 || n_full % S != 0)
         return BASQ_EINVAL;
     if (nc == 0) return BASQ_OK;
+    if (S % 2 == 0 && pg0 % 2 == 0 && S >= 4 && S <= 2048 && nc >= 4 * (int64_t)S) {
+        // 16 bytes per lane: set pairs x position slices (dense_blocksum_pairs_kernel)
+        constexpr int JR8 = 8;
+        const int half = S / 2;
+        int NS = 512 / half;
+        NS = NS < 1 ? 1 : (NS > 16 ? 16 : NS);
+        const long long nblocks = (nc + S - 1) / S;
+        while (NS > 1 && (long long)NS * 2 > nblocks) --NS;     // at least two blocks per slice
+        const int nthr = half * NS;
+        size_t lds = (size_t)NS * JR8 * S * sizeof(double);
+        const size_t lds_tail = (size_t)((nthr + 63) / 64) * JR8 * sizeof(double);
+        if (lds < lds_tail) lds = lds_tail;
+        if (lds <= 160 * 1024 - 512) {
+            const dim3 grid8((unsigned)((m + JR8 - 1) / JR8)), block8((unsigned)nthr);
+            const void* fn = square ? (const void*)dense_blocksum_pairs_kernel<JR8, true>
+                                    : (const void*)dense_blocksum_pairs_kernel<JR8, false>;
+            if (lds > 64 * 1024 &&
+                hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return BASQ_ELAUNCH;
+            if (square)
+                hipLaunchKernelGGL((dense_blocksum_pairs_kernel<JR8, true>), grid8, block8, lds, (hipStream_t)stream, C, m,
+                                   (long long)nc, (long long)ldc, mu, (long long)pg0, (long long)n_full, S, NS, scale, E);
+            else
+                hipLaunchKernelGGL((dense_blocksum_pairs_kernel<JR8, false>), grid8, block8, lds, (hipStream_t)stream, C, m,
+                                   (long long)nc, (long long)ldc, mu, (long long)pg0, (long long)n_full, S, NS, scale, E);
+            BASQ_CHECK_LAUNCH();
+            return BASQ_OK;
+        }
+    }
     constexpr int JR = 4;
     const dim3 grid((unsigned)((m + JR - 1) / JR)), block(256);
     if (square)

@@ -274,7 +274,9 @@ class CallableKernel:
       whose value depends on the block they are asked for, like the reference's DEFAULT kernel ``predictive_covariance``,
       which adds the likelihood noise to entries ``[k][k]`` of EVERY block (``BASQ/_gp.py:275-276``);
     * ``block_exact=False``: ``fn(pts_nys, chunk)`` for chunks of up to ``chunk_bytes / (8 m)`` consecutive candidates --
-      far fewer, larger calls, but only equivalent for callables that evaluate column by column.
+      far fewer, larger calls, but only equivalent for callables that evaluate column by column.  The default chunk is 1 GB
+      of kernel values (the callable's own temporaries are a small multiple of that; the part has 288 GB): every chunk
+      costs one read-modify-write of the [m, 2n] block sums, 6 % of the chunk's bytes at that size, 25 % at 256 MB.
 
     ``block_exact=None`` (the default, and what a bare callable handed to ``recombination`` gets): decided once per batch
     by a probe (``resolve_mode``) -- the callable is asked for two blocks at once and one by one; unless the answers
@@ -287,7 +289,7 @@ class CallableKernel:
     warp = "none"
     PROBE_RTOL = 1e-13           # block dependence below this (relative to max |K|) cannot move a selection (SURVEY finding 3)
 
-    def __init__(self, fn, block_exact: bool | None = None, chunk_bytes: int = 256 << 20, input_dtype=torch.float64):
+    def __init__(self, fn, block_exact: bool | None = None, chunk_bytes: int = 1 << 30, input_dtype=torch.float64):
         if not callable(fn):
             raise TypeError("CallableKernel needs a callable (X, Y) -> Tensor")
         self.fn = fn
