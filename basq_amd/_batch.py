@@ -573,7 +573,12 @@ class Batch:
                 if plan.warp == "wsabim":
                     # + U @ (0.5 sum mu cov^2): the one term of wsabim_kernel that is not linear in the block sums
                     with _Timer(ops, trace, "wsabim_sq"):
-                        msg[1:q + 1] += _mm_splitk(ops, self.U, self.sums.wsabim_square_term(geo, S_r), 8)
+                        E = self.sums.wsabim_square_term(geo, S_r)
+                        if plan.sober and not final and geo.n_tail > 0:
+                            # SOBER/_rchq.py:127-135 counts the remainder's kernel columns a second time, in sets
+                            # 0..N_rest-1: the whole kernel, hence its squared-covariance term too
+                            E = E + self.sums.wsabim_square_term(geo, S_r, tail_as_block=True)
+                        msg[1:q + 1] += _mm_splitk(ops, self.U, E, 8)
             msg0 = (msg, Mc, C_cur, reg_blocks)
             pre = None
             self.cls = None
@@ -924,8 +929,11 @@ class FusedSums:
             msg = ops.project(b.U_ext, b.q_ext, b.m_ext, Xpart, totpart, n_chunks, S_r, b.kscale)
         return msg, None, 1, 0
 
-    def wsabim_square_term(self, geo, S):
+    def wsabim_square_term(self, geo, S, tail_as_block=False):
         """E[j, s] = 0.5 * sum_{p in set s} mu_p * cov(pt_j, x_p)^2  with cov = k - K(pt,X) W K(X, x)  (_wsabi.py:240).
+
+        ``tail_as_block``: only the ragged remainder, as a kernel block of its own -- remainder point k in set k (the first
+        of SOBER's two counts of the remainder, ``SOBER/_rchq.py:127-135``).
 
         ``cov`` is ``predictive_covariance``, which carries the likelihood noise on entry [k][k] of every block the
         reference builds: candidate p of a full block meets Nystrom row ``p mod S``, tail point k meets row k.
@@ -936,13 +944,18 @@ class FusedSums:
         """
         b, ops = self.b, self.b.ops
         m, n_obs, Rl = b.m, b.n_obs, b.Rl
+        cand, mu, off, n_full = b.cand, b.mu, b.off, geo.n_full
+        if tail_as_block:
+            t0l = min(max(geo.n_full - b.off, 0), Rl)            # first local tail position
+            cand, mu, Rl = cand[t0l:], mu[t0l:], Rl - t0l
+            off, n_full = b.off + t0l - geo.n_full, S            # positions renumbered from the start of the remainder
         if Rl == 0:
             return ops.zeros(m, S)
         n4 = b.bmatT.shape[0]
         kobs = ops.zeros(n4, Rl) if n4 != n_obs else ops.empty(n4, Rl)
-        ops.gram_into(b.spec, b.nys_ext[m:m + n_obs], n_obs, b.cand, Rl, kobs)   # rows m.. of nys_ext = packed observations
-        n_ch = choose_chunks(local_blocks(b.off, Rl, geo), m, S, b.kp // 4)
-        Epart = ops.blocksum_sq(b.spec, b.nys_ext, m, b.cand, b.mu, Rl, b.off, geo.n_full, S, n_ch, b.bmatT, kobs, n_obs,
+        ops.gram_into(b.spec, b.nys_ext[m:m + n_obs], n_obs, cand, Rl, kobs)   # rows m.. of nys_ext = packed observations
+        n_ch = 1 if tail_as_block else choose_chunks(local_blocks(off, Rl, geo), m, S, b.kp // 4)
+        Epart = ops.blocksum_sq(b.spec, b.nys_ext, m, cand, mu, Rl, off, n_full, S, n_ch, b.bmatT, kobs, n_obs,
                                 b.diag_noise)
         return Epart[0] if n_ch == 1 else ops.sum_parts(Epart)
 

@@ -127,7 +127,10 @@ class WsabiOracle:
         mu_x = self.mean(x)
         mu_y = self.mean(y)
         cov = self.post(x, y)
-        out = mu_x.unsqueeze(1) * cov * mu_y.unsqueeze(0)
+        if mu_x.dim() == 1 and mu_y.dim() == 1:
+            out = mu_x.unsqueeze(1) * cov * mu_y.unsqueeze(0)
+        else:                                                   # batched y [nb, S, d] (SOBER/_rchq.py:124): _wsabi.py:219-222
+            out = mu_x.unsqueeze(1) * cov * mu_y.unsqueeze(1)
         if self.label == "wsabim":
             out = out + 0.5 * (cov ** 2)
         k = min(len(x), len(y))

@@ -20,6 +20,34 @@ CASES = [
 ]
 
 
+# The only configuration the reference publishes timings for: the tutorials' SOBER-API loop
+# (SOBER/BASQ/_basq.py:19-36) -- n_cand = 20 000, n_nys = 500 (a SEPARATE prior sample, :25), batch 100, d = 10, uniform
+# weights, kernel = Kernel(model) = SOBER's predictive_covariance (SOBER/_gp.py:281-305: NO noise on the diagonal) of an
+# RBF GP (tutorial 01) / a Matern-5/2 GP (tutorial 02) with n_obs = 2 .. 902 observations and likelihood noise 1e-10, or
+# BASQ/_wsabi.py's WSABI-M kernel (tutorial 03; its predictive_covariance is BASQ/_gp.py's, WITH the noise diagonal).
+# ``kernel`` is a tests/cases.py kernel dict; the Nystrom points come from pool seed + 1000.
+def _tut(name, family, ls, n_obs, warp="none", diag_noise=0.0, pool_seed=31):
+    post = dict(n_obs=n_obs, noise=1e-10, obs_seed=200 + n_obs, diag_noise=diag_noise)
+    return dict(name=name, N=20_000, d=10, m=500, n=100, pool_seed=pool_seed, weights="none", separate_nys=True,
+                kernel=dict(family=family, lengthscale=ls, outputscale=1.0, posterior=post, warp=warp))
+
+
+TUTORIAL_CASES = [
+    _tut("sober_tut01_rbf_nobs2", "rbf", 2.0, 2),
+    _tut("sober_tut01_rbf_nobs502", "rbf", 2.0, 502),
+    _tut("sober_tut01_rbf_nobs902", "rbf", 2.0, 902),
+    _tut("sober_tut02_matern52_nobs502", "matern52", 4.0, 502),
+    _tut("sober_tut03_wsabim_nobs502", "rbf", 2.0, 502, warp="wsabim", diag_noise=1e-10),
+]
+
+
+def tutorial_inputs(c):
+    """-> (pts_rec, pts_nys) of a tutorial case: two independent pools, as ``prior.sample`` twice (SOBER/BASQ/_basq.py:24-25)."""
+    from basq_amd.pools import gmm_pool
+
+    return gmm_pool(c["N"], c["d"], c["pool_seed"]), gmm_pool(c["m"], c["d"], c["pool_seed"] + 1000)
+
+
 def case_objective(c):
     """``calc_obj`` of the case, or None.  Only correctly rounded IEEE operations (no libm): bit-reproducible."""
     if c.get("objective", "none") == "none":
@@ -67,6 +95,27 @@ def main():
         out.append(dict(case=c, pool_digest=pool_digest(pts), idx=[int(v) for v in idx], w=[float(v) for v in w]))
         print(c["name"], len(idx), float(w.sum()))
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "sober.json")
+    json.dump(out, open(path, "w"), indent=0)
+    print("wrote", path)
+    # tutorial-size cases, structured kernels (tests/cases.py builds the callables)
+    import time
+
+    from tests.cases import build_oracle_kernel
+
+    out = []
+    for c in TUTORIAL_CASES:
+        pts, nys = tutorial_inputs(c)
+        ko, _ = build_oracle_kernel(c)
+        torch.manual_seed(1)
+        t0 = time.perf_counter()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            idx, w = sober_recombination(pts, nys, c["n"], ko, torch.device("cpu"), torch.float64)
+        dt = time.perf_counter() - t0
+        out.append(dict(case=c, pool_digest=pool_digest(pts), idx=[int(v) for v in idx], w=[float(v) for v in w],
+                        reference_cpu_seconds_here=round(dt, 3)))
+        print(c["name"], len(idx), float(w.sum()), f"{dt:.2f} s")
+    path = os.path.join(os.path.dirname(path), "sober_tutorial.json")
     json.dump(out, open(path, "w"), indent=0)
     print("wrote", path)
 

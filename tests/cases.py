@@ -96,8 +96,11 @@ def build_oracle_kernel(c):
         return base, None
     Xobs = build_obs(c)
     W, mean_const, mean_cache, _ = synthetic_gp_state(Xobs, base, k["posterior"]["noise"], k["posterior"]["obs_seed"])
-    state = dict(Xobs=Xobs, W=W, mean_const=mean_const, mean_cache=mean_cache, noise=k["posterior"]["noise"])
-    post = PosteriorOracle(base, Xobs, W, k["posterior"]["noise"])
+    # "diag_noise": what the callable adds to entries [k][k] of every block -- the likelihood noise for BASQ/_gp.py:275-276
+    # (the default), 0 for SOBER/_gp.py:281-305, whose predictive_covariance has that line commented out
+    diag = k["posterior"].get("diag_noise", k["posterior"]["noise"])
+    state = dict(Xobs=Xobs, W=W, mean_const=mean_const, mean_cache=mean_cache, noise=diag)
+    post = PosteriorOracle(base, Xobs, W, diag)
     if k["warp"] == "none":
         return post, state
     return WsabiOracle(post, mean_const, mean_cache, k["warp"]), state
