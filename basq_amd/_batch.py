@@ -111,7 +111,7 @@ class Plan:
     world: int
 
     @staticmethod
-    def of(kernel, variant, objective, comm, ops, trace, n_sets=0):
+    def of(kernel, variant, objective, comm, ops, trace, n_sets=0, owner=None):
         """``n_sets`` = 2 * (min(num_pts - 1, m) + 1), the width of every round's reduction (0: unknown, no limit)."""
         if variant not in ("basq", "sober"):
             raise ValueError(variant)
@@ -131,16 +131,17 @@ class Plan:
             if comm.world > 1 or posterior or warp != "none":
                 raise NotImplementedError("objective row: single process, stationary kernels only")
         # class sums need rounds that are plain block sums of a structured kernel and keep exactly half of the sets
-        classes = cfg.CLASS_SUMS and not opaque and not sober and warp != "wsabim"
+        # (SOBER's first count of the ragged remainder, SOBER/_rchq.py:127-135, rides along as one more irregular chunk)
+        classes = cfg.CLASS_SUMS and not opaque and warp != "wsabim"
         # descriptor-driven rounds: the same restriction + the ops must provide the *_geo entries; a trace that
         # synchronises per phase (host timers, per-round tensors) needs the round-by-round loop
         traced_sync = trace is not None and (trace.host_sync or trace.keep_tensors)
         # ... and they call the GPU null-space / elimination kernels directly: wider reductions than those hold
         # (2 * num_pts > 1024) and the host-LAPACK route (GPU_NULLSPACE off) take the round-by-round loop
         gpu_reduction = cfg.GPU_NULLSPACE and n_sets <= getattr(ops, "NULLSPACE_MAX_M", 1 << 30)
-        async_rounds = (cfg.ASYNC_ROUNDS and not opaque and not sober and objective is None and warp != "wsabim"
+        async_rounds = (cfg.ASYNC_ROUNDS and not opaque and objective is None and warp != "wsabim"
                         and hasattr(ops, "round_next") and not traced_sync and gpu_reduction
-                        and (comm.world == 1 or cfg.REPLICATED_REDUCTION))
+                        and (comm.world == 1 or cfg.REPLICATED_REDUCTION or owner is not None))
         return Plan(opaque, sober, warp, posterior, objective is not None, classes, async_rounds, comm.world)
 
 
@@ -148,7 +149,7 @@ class Batch:
     """State of one recombination in flight; ``steps()`` is the generator the engine drives."""
 
     def __init__(self, ops, comm, pts_local, gid0: int, n_total: int, pts_nys, num_pts: int, kernel, trace=None,
-                 variant: str = "basq", init_weights=None, objective=None, pipelined: bool = False):
+                 variant: str = "basq", init_weights=None, objective=None, pipelined: bool = False, owner: int | None = None):
         """``pts_local`` = this rank's contiguous slice ``[gid0, gid0 + len)`` of the pool.
 
         ``variant="basq"`` follows ``BASQ/_rchq.py`` (uniform start weights, ``init_weights`` ignored);
@@ -163,6 +164,11 @@ class Batch:
 
         ``pipelined``: other batches are in flight on other streams (nothing is deferred behind the range finder then:
         their kernels fill that gap).
+
+        ``owner`` (several ranks): the rank that runs this batch's per-round reductions (null space + elimination) and
+        broadcasts their outcome -- ``3 M + 1`` doubles, stream-ordered -- instead of every rank repeating them.  With k >= G
+        batches in flight, owners dealt round-robin, every GPU carries 1/G of the chains (``RecombinationEngine.run_many``);
+        None = every rank reduces the gathered message itself (no broadcast: the choice for ONE batch at a time).
         """
         if n_total >= 2 ** 31:
             raise ValueError("pool sizes >= 2^31 are not supported")
@@ -183,8 +189,10 @@ class Batch:
         self.gid0, self.n_total, self.num_pts = int(gid0), int(n_total), int(num_pts)
         self.init_weights, self.objective = init_weights, objective
         self.pipelined = pipelined
+        self.owner = None if (owner is None or comm.world == 1) else int(owner) % comm.world
         m_nys = int(pts_nys.shape[0]) if pts_nys.dim() >= 1 else 0
-        self.plan = Plan.of(kernel, variant, objective, comm, ops, trace, n_sets=2 * (min(int(num_pts) - 1, m_nys) + 1))
+        self.plan = Plan.of(kernel, variant, objective, comm, ops, trace, n_sets=2 * (min(int(num_pts) - 1, m_nys) + 1),
+                            owner=self.owner)
 
     # ------------------------------------------------------------------------------------------------
     # the step generator
@@ -435,6 +443,7 @@ class Batch:
         spec, nys_ext, U_ext, kscale, kp = self.spec, self.nys_ext, self.U_ext, self.kscale, self.kp
         diag_noise, diagU, wrow = self.diag_noise, self.diagU, self.wrow
         multi = comm.world > 1
+        owner = self.owner                                       # None: every rank reduces; else: that rank + a broadcast
         n_keep_exp = s                                           # a regular round keeps s = S/2 sets
         reg_hi0 = (pre[4] * S) if (pre is not None and pre[3] >= 2) else 0
         geo_t = ops.geo_init(64, self.R, S, reg_hi0, self.off, self.Rl)
@@ -445,15 +454,24 @@ class Batch:
         cls = None
         records = []                                             # per enqueued round, for the trace: (info|kept buffer)
         cand, mu, gid, wx = self.cand, self.mu, self.gid, self.wx
+        n_extra = self.sums.n_extra
+
+        def tail_block_geo(Xslot, totslot):
+            """SOBER's first count of the remainder (descriptor geometry: ``geo_mode`` 4); no set weight is added there."""
+            ops.blocksum_geo(spec, nys_ext, m_ext, cand, mu, wx, g_row, 4, S, 1, out=(Xslot, totslot))
+            totslot.zero_()
+
         while R_lo > S:
             g_row = geo_t[r]
             Mc, C_cur, parts = None, 1, None
             if cls is not None:                                  # inside an epoch: regrouped class messages + the rest
                 Mc, C_cur = cls["M"], cls["C"]
-                Xirr, totirr = ops.empty(1, m_ext, S), ops.empty(1, S)
+                Xirr, totirr = ops.empty(n_extra, m_ext, S), ops.empty(n_extra, S)
                 self.sums.timed_geo(r, 2, 1.0, lambda: ops.blocksum_geo(spec, nys_ext, m_ext, cand, mu, wx, g_row, 2, S, 1,
-                                                                        out=(Xirr, totirr)))
-                ops.project_chunks(U_ext, q_ext, m_ext, Xirr, totirr, 1, S, kscale, out=Mc[C_cur:C_cur + 1])
+                                                                        out=(Xirr[:1], totirr[:1])))
+                if n_extra == 2:
+                    tail_block_geo(Xirr[1:2], totirr[1:2])
+                ops.project_chunks(U_ext, q_ext, m_ext, Xirr, totirr, n_extra, S, kscale, out=Mc[C_cur:C_cur + n_extra])
                 parts = Mc
             else:
                 if pre is not None:                              # round 1: launched before the basis, host geometry
@@ -462,18 +480,24 @@ class Batch:
                 else:
                     C_cur = plan_C if plan_C is not None else 1
                     if C_cur >= 2:
-                        n_chunks = C_cur + 1
+                        n_chunks = C_cur + n_extra
                         Xpart, totpart = ops.empty(n_chunks, m_ext, S), ops.empty(n_chunks, S)
                         self.sums.timed_geo(r, 1, 1.0, lambda: ops.blocksum_geo(
                             spec, nys_ext, m_ext, cand, mu, wx, g_row, 1, S, C_cur, out=(Xpart[:C_cur], totpart[:C_cur]),
                             class_mod=C_cur))
                         self.sums.timed_geo(r, 2, 1.0, lambda: ops.blocksum_geo(
-                            spec, nys_ext, m_ext, cand, mu, wx, g_row, 2, S, 1, out=(Xpart[C_cur:], totpart[C_cur:])))
+                            spec, nys_ext, m_ext, cand, mu, wx, g_row, 2, S, 1, out=(Xpart[C_cur:C_cur + 1],
+                                                                                     totpart[C_cur:C_cur + 1])))
+                        if n_extra == 2:
+                            tail_block_geo(Xpart[C_cur + 1:], totpart[C_cur + 1:])
                     else:
-                        n_chunks = choose_chunks(max(R_lo // S // comm.world, 1), m_ext, S, kp // 4)
+                        n_plain = choose_chunks(max(R_lo // S // comm.world, 1), m_ext, S, kp // 4)
+                        n_chunks = n_plain + (n_extra - 1)
                         Xpart, totpart = ops.empty(n_chunks, m_ext, S), ops.empty(n_chunks, S)
                         self.sums.timed_geo(r, 3, 1.0, lambda: ops.blocksum_geo(spec, nys_ext, m_ext, cand, mu, wx, g_row, 3, S,
-                                                                                n_chunks, out=(Xpart, totpart)))
+                                                                                n_plain, out=(Xpart[:n_plain], totpart[:n_plain])))
+                        if n_extra == 2:
+                            tail_block_geo(Xpart[n_plain:], totpart[n_plain:])
                 if C_cur >= 2:
                     Mc = ops.project_chunks(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S, kscale)
                     parts = Mc
@@ -490,19 +514,25 @@ class Batch:
                 ops.tail_weights_geo(mu, wx, g_row, S, buf[0, rows])
                 if multi:
                     buf = comm.all_gather(buf[0])
-                XcarT, tot = ops.finalize(buf, buf.shape[0], rows + 1, q, S, diagU, m, min(m, S), diag_noise, wrow, rows,
-                                          min(m, S), geo_row=g_row)
+                fin = (buf, buf.shape[0], rows + 1, q, S, diagU, m, min(m, S), diag_noise, wrow, rows, min(m, S), g_row)
             else:
                 if multi:
                     parts = comm.all_gather(ops.sum_parts(parts) if parts.shape[0] > 1 else parts[0])
-                XcarT, tot = ops.finalize(parts, parts.shape[0], rows, q, S, None, m, min(m, S), 0.0, 0, 0, 0)
-            PhiT = ops.nullspace(XcarT, s, S)
-            keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, tot.clone(), S, s)
+                fin = (parts, parts.shape[0], rows, q, S, None, m, min(m, S), 0.0, 0, 0, 0, None)
+            res, rv = ops.reduction_result(S) if owner is not None else (None, None)
+            if owner is None or comm.rank == owner:
+                XcarT, tot = ops.finalize(*fin, tot_out=None if rv is None else rv["tot"])
+                PhiT = ops.nullspace(XcarT, s, S)
+                keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, tot.clone(), S, s, out=rv)
+            if owner is not None:
+                # the outcome of the owner's reduction (w_star | tot | info, kept, keep_rank: 3 S + 1 doubles), stream-ordered
+                comm.broadcast(res, src=owner)
+                keep_rank, kept, w_star, info, tot = rv["keep_rank"], rv["kept"], rv["w_star"], rv["info"], rv["tot"]
             if trace is not None:
                 records.append(ops.info_kept_buffer(info, kept))
             cls = None
             if Mc is not None and C_cur >= 2:
-                Mn = ops.empty(C_cur // 2 + 1, Mc.shape[1], S)
+                Mn = ops.empty(C_cur // 2 + n_extra, Mc.shape[1], S)
                 ops.regroup_classes(Mc[:C_cur], kept, w_star, tot, out=Mn[:C_cur // 2])
                 cls = dict(M=Mn, C=C_cur // 2, reg_blocks=None)
             # bounds of the next survivor count; the class plan of the next fresh evaluation follows the lower one
@@ -519,6 +549,11 @@ class Batch:
                                                          keep_rank, w_star, tot, Rl_up_n, n_keep_exp)
             r += 1
             R_lo, R_up, Rl_up = R_lo_n, R_up_n, Rl_up_n
+        if multi and owner is None:
+            # every rank ran its own reductions: a cluster-kernel time-out (status 2) is local to ONE rank, and the ranks
+            # must agree on repeating the rounds -- the flag becomes the maximum over the ranks
+            flags = comm.all_gather(geo_t[r, 3:4].to(torch.float64))
+            geo_t[r, 3:4] = flags.max().to(torch.int64).reshape(1)
         table, ready = ops.to_host_async(geo_t[:r + 1], "geo_table")
         yield ready                                              # the ONE wait of the asynchronous rounds
         row = table[r].tolist()
@@ -601,47 +636,42 @@ class Batch:
                 return (yield from self._reduce_with_objective(msg))
             parts = comm.all_gather(msg) if comm.world > 1 else (msg if msg.dim() == 3 else msg.unsqueeze(0))
             M = S_r
-            replicate = cfg.REPLICATED_REDUCTION and comm.world > 1
+            owner = self.owner
+            replicate = cfg.REPLICATED_REDUCTION and comm.world > 1 and owner is None
+            shared = comm.world > 1 and not replicate            # ONE rank reduces, the others receive the outcome
+            red_rank = owner if owner is not None else 0
             XcarT = None
             cluster = not getattr(self, "_no_cluster", False)
-            if comm.rank == 0 or replicate:
+            res, rv = ops.reduction_result(M) if shared else (None, None)
+            if not shared or comm.rank == red_rank:
                 XcarT, tot = ops.finalize(parts, parts.shape[0], parts.shape[1], q, S_r, self.diagU, m, min(m, S_r),
-                                          self.diag_noise, self.wrow, tail_row, n_tail_diag)
+                                          self.diag_noise, self.wrow, tail_row, n_tail_diag,
+                                          tot_out=None if rv is None else rv["tot"])
                 PhiT = yield from self._nullspace(XcarT, s, M, cluster)      # :140-143 (rows = null-space vectors)
                 with _Timer(ops, trace, "eliminate"):
-                    keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, tot.clone(), M, s, cluster)
+                    keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, tot.clone(), M, s, cluster, out=rv)
+            elif not self._gpu_nullspace(M):
+                yield _recorded_event(ops)                       # the reducing rank waits for its host SVD here: same yield count
+            if shared:
+                # one broadcast of the (tiny) reduction result: w_star | tot | info, kept, keep_rank
+                comm.broadcast(res, src=red_rank)
+                keep_rank, kept, w_star, info, tot = rv["keep_rank"], rv["kept"], rv["w_star"], rv["info"], rv["tot"]
+            elif replicate:
+                # a cluster-kernel time-out is local to one rank: the retry below must be a collective decision
+                st = comm.all_gather(info[1:2].to(torch.float64))
+                info[1:2] = st.max().to(torch.int32).reshape(1)
             Mn = None
-            if Mc is not None and C_cur >= 2 and not final and (comm.world == 1 or replicate):
+            if Mc is not None and C_cur >= 2 and not final:
                 # Enqueued BEFORE the host waits for this round's outcome: if exactly half of the sets survive (checked
                 # below), the next round's class messages are a gather + rescale of this round's; otherwise the result
                 # is dropped (the kernel tolerates a short survivor list).
-                Mn = ops.empty(C_cur // 2 + 1, Mc.shape[1], S_r)
+                Mn = ops.empty(C_cur // 2 + self.sums.n_extra, Mc.shape[1], S_r)
                 ops.regroup_classes(Mc[:C_cur], kept, w_star, tot, out=Mn[:C_cur // 2])
-            if comm.world > 1 and not replicate:
-                # one broadcast of the (tiny) reduction result: info | kept | w_star | keep_rank | tot
-                res = ops.empty(2 + 4 * M)
-                if comm.rank == 0:
-                    res[0:2] = info.to(torch.float64)
-                    res[2:2 + M] = kept.to(torch.float64)
-                    res[2 + M:2 + 2 * M] = w_star
-                    res[2 + 2 * M:2 + 3 * M] = keep_rank.to(torch.float64)
-                    res[2 + 3 * M:] = tot
-                comm.broadcast(res)
-                head, ready = ops.to_host_async(res[:2 + M], "head")
-                yield ready
-                hl = head.tolist()                               # one conversion (iterating a tensor costs ~1 us/element)
-                n_keep, status = int(hl[0]), int(hl[1])
-                kept_list = [int(v) for v in hl[2:2 + n_keep]]
-                kept = res[2:2 + M].to(torch.int32)
-                w_star = res[2 + M:2 + 2 * M].contiguous()
-                keep_rank = res[2 + 2 * M:2 + 3 * M].to(torch.int32)
-                tot = res[2 + 3 * M:].contiguous()
-            else:
-                head, ready = ops.to_host_async(ops.info_kept_buffer(info, kept), "head")   # one D2H: status + survivors
-                yield ready
-                hl = head.tolist()
-                n_keep, status = hl[0], hl[1]
-                kept_list = hl[2:2 + n_keep]
+            head, ready = ops.to_host_async(ops.info_kept_buffer(info, kept), "head")   # one D2H: status + survivors
+            yield ready
+            hl = head.tolist()                                   # one conversion (iterating a tensor costs ~1 us/element)
+            n_keep, status = hl[0], hl[1]
+            kept_list = hl[2:2 + n_keep]
             if status == 2:
                 # an 8-work-group cluster kernel gave up waiting for its siblings (they must be co-resident; a GPU shared
                 # with other work may not grant that within the spin limit): nothing of this round has been applied yet --
@@ -675,7 +705,7 @@ class Batch:
             if Mc is not None and C_cur >= 2 and 2 * n_keep == S_r and status == 0:
                 # exactly half of the sets survived: the next round's class messages are a gather + rescale of this round's
                 if Mn is None:
-                    Mn = ops.empty(C_cur // 2 + 1, Mc.shape[1], S_r)
+                    Mn = ops.empty(C_cur // 2 + self.sums.n_extra, Mc.shape[1], S_r)
                     ops.regroup_classes(Mc[:C_cur], kept, w_star, tot, out=Mn[:C_cur // 2])
                 self.cls = dict(M=Mn, C=C_cur // 2, reg_blocks=reg_blocks // 2)
             new_off, new_Rl = next_shard(off, Rl, geo, kept_list)
@@ -791,6 +821,18 @@ class FusedSums:
     def __init__(self, batch: Batch):
         self.b = batch
         self._geo_events = []                                   # (event pair, round, mode, info) awaiting the descriptor table
+        # slots behind the C residue classes of an epoch: the irregular chunk (further blocks + the ragged remainder in set
+        # S-1) and, for the SOBER variant, the remainder once more as a block of its own (point k in set k, no set weight:
+        # SOBER/_rchq.py:127-135)
+        self.n_extra = 2 if batch.plan.sober else 1
+
+    def tail_block(self, geo_, S_, Xslot, totslot):
+        """SOBER's first count of the remainder (host geometry) -> ``Xslot [1, m_ext, S]``; ``totslot [1, S]`` = 0."""
+        b, ops = self.b, self.b.ops
+        t0l = min(max(geo_.n_full - b.off, 0), b.Rl)            # first local remainder position
+        ops.blocksum(b.spec, b.nys_ext, b.m_ext, b.cand[t0l:], b.mu[t0l:], None if b.wx is None else b.wx[t0l:], b.Rl - t0l,
+                     b.off + t0l - geo_.n_full, S_, S_, 1, out=(Xslot, totslot))
+        totslot.zero_()
 
     # -- launches (+ HIP events for the roofline line) -----------------------------------------------------
     def _timing(self):
@@ -840,11 +882,13 @@ class FusedSums:
     # -- one round's block sums ------------------------------------------------------------------------------
     def irregular(self, geo_, S_, reg_blocks):
         """Block sums of the candidates the class partials do not cover (global positions >= reg_blocks * S: further
-        blocks + the ragged tail), one chunk -> ``(Xirr [1, m_ext, S], totirr [1, S])``."""
+        blocks + the ragged tail), one chunk (SOBER: + the remainder as a block of its own) -> ``(Xirr [n_extra, m_ext, S], totirr [n_extra, S])``."""
         b, ops = self.b, self.b.ops
-        Xirr, totirr = ops.empty(1, b.m_ext, S_), ops.empty(1, S_)
+        Xirr, totirr = ops.empty(self.n_extra, b.m_ext, S_), ops.empty(self.n_extra, S_)
         reg_hi = min(max(reg_blocks * S_ - b.off, 0), b.Rl)             # local end of the regular region
-        self.timed(reg_hi, b.Rl, geo_, S_, 1, (Xirr, totirr))
+        self.timed(reg_hi, b.Rl, geo_, S_, 1, (Xirr[:1], totirr[:1]))
+        if self.n_extra == 2:
+            self.tail_block(geo_, S_, Xirr[1:2], totirr[1:2])
         return Xirr, totirr
 
     def evaluate(self, geo_, S_, defer_last=False):
@@ -863,19 +907,29 @@ class FusedSums:
         n_late_classes = cfg.LATE_CLASSES_PIPELINED if b.pipelined else cfg.LATE_CLASSES
         if C == 1:
             n_ch = choose_chunks(local_blocks(off, Rl, geo_), m_ext, S_, kp // 4)
-            Xbuf, totbuf = ops.empty(n_ch, m_ext, S_), ops.empty(n_ch, S_)
+            sober_tail = self.n_extra == 2 and S_ == b.S and geo_.n_tail > 0     # one more chunk: the remainder's first count
+            n_tot = n_ch + (1 if sober_tail else 0)
+            Xbuf, totbuf = ops.empty(n_tot, m_ext, S_), ops.empty(n_tot, S_)
+            if sober_tail:
+                self.tail_block(geo_, S_, Xbuf[n_ch:], totbuf[n_ch:])
             p_split = late_split(off, Rl, geo_.n_full, S_, n_ch, n_late_chunks) if (defer_last and Rl > 0) else None
             if p_split is None:
-                self.timed(0, Rl, geo_, S_, n_ch, (Xbuf, totbuf))
-                return Xbuf, totbuf, n_ch, 1, 0, None
+                self.timed(0, Rl, geo_, S_, n_ch, (Xbuf[:n_ch], totbuf[:n_ch]))
+                return Xbuf, totbuf, n_tot, 1, 0, None
             # the last chunk(s) are launched behind the range finder's GPU work; same chunk boundaries, same sums
             self.timed(0, p_split, geo_, S_, n_ch - n_late_chunks, (Xbuf[:n_ch - n_late_chunks], totbuf[:n_ch - n_late_chunks]))
-            return (Xbuf, totbuf, n_ch, 1, 0,
-                    lambda: self.timed(p_split, Rl, geo_, S_, n_late_chunks, (Xbuf[n_ch - n_late_chunks:], totbuf[n_ch - n_late_chunks:])))
+            return (Xbuf, totbuf, n_tot, 1, 0,
+                    lambda: self.timed(p_split, Rl, geo_, S_, n_late_chunks, (Xbuf[n_ch - n_late_chunks:n_ch], totbuf[n_ch - n_late_chunks:n_ch])))
         reg_blocks = (geo_.nb // C) * C
-        Xbuf, totbuf = ops.empty(C + 1, m_ext, S_), ops.empty(C + 1, S_)
+        n_slots = C + self.n_extra
+        Xbuf, totbuf = ops.empty(n_slots, m_ext, S_), ops.empty(n_slots, S_)
         reg_hi = min(max(reg_blocks * S_ - off, 0), Rl)                  # local end of the regular region
-        irregular = lambda: self.timed(reg_hi, Rl, geo_, S_, 1, (Xbuf[C:C + 1], totbuf[C:C + 1]))   # noqa: E731
+
+        def irregular():
+            self.timed(reg_hi, Rl, geo_, S_, 1, (Xbuf[C:C + 1], totbuf[C:C + 1]))
+            if self.n_extra == 2:
+                self.tail_block(geo_, S_, Xbuf[C + 1:C + 2], totbuf[C + 1:C + 2])
+
         if defer_last and n_late_classes > 0:
             L = max(1, min(n_late_classes, C - 1))               # classes evaluated behind the range finder's GPU work
             self.timed(0, reg_hi, geo_, S_, C - L, (Xbuf[:C - L], totbuf[:C - L]), class_mod=C, class0=0)
@@ -884,10 +938,10 @@ class FusedSums:
                 self.timed(0, reg_hi, geo_, S_, L, (Xbuf[C - L:C], totbuf[C - L:C]), class_mod=C, class0=C - L)
                 irregular()
 
-            return Xbuf, totbuf, C + 1, C, reg_blocks, late_fn
+            return Xbuf, totbuf, n_slots, C, reg_blocks, late_fn
         self.timed(0, reg_hi, geo_, S_, C, (Xbuf[:C], totbuf[:C]), class_mod=C, class0=0)
         irregular()
-        return Xbuf, totbuf, C + 1, C, reg_blocks, None
+        return Xbuf, totbuf, n_slots, C, reg_blocks, None
 
     def message(self, geo, S_r, final, pre):
         """-> ``(msg, Mc, C_cur, reg_blocks)``: the round's message ``[rows, S_r]`` -- or, on one rank without an extra
@@ -902,7 +956,8 @@ class FusedSums:
             with _Timer(ops, trace, "blocksum"):
                 Xirr, totirr = self.irregular(geo, S_r, reg_blocks)
             with _Timer(ops, trace, "project"):
-                ops.project_chunks(b.U_ext, b.q_ext, b.m_ext, Xirr, totirr, 1, S_r, b.kscale, out=Mc[C_cur:C_cur + 1])
+                ops.project_chunks(b.U_ext, b.q_ext, b.m_ext, Xirr, totirr, self.n_extra, S_r, b.kscale,
+                                   out=Mc[C_cur:C_cur + self.n_extra])
                 msg = ops.sum_parts(Mc) if sum_here else Mc
             return msg, Mc, C_cur, reg_blocks
         with _Timer(ops, trace, "blocksum"):
@@ -916,15 +971,8 @@ class FusedSums:
                 Mc = ops.project_chunks(b.U_ext, b.q_ext, b.m_ext, Xpart, totpart, n_chunks, S_r, b.kscale)
                 msg = ops.sum_parts(Mc) if sum_here else Mc
             return msg, Mc, C_cur, reg_blocks
-        if b.plan.sober and not final and geo.n_tail > 0:
-            # SOBER/_rchq.py:127-135: the remainder's kernel columns also go to sets 0..N_rest-1 (no weight added)
-            t0l = max(geo.n_full - b.off, 0)                     # first local tail position
-            if t0l < b.Rl:
-                Xt, _ = ops.blocksum(b.spec, b.nys_ext, b.m_ext, b.cand[t0l:], b.mu[t0l:],
-                                     None if b.wx is None else b.wx[t0l:], b.Rl - t0l, b.off + t0l - geo.n_full, S_r, S_r, 1)
-                Xpart = torch.cat([Xpart, Xt], 0)
-                totpart = torch.cat([totpart, ops.zeros(1, S_r)], 0)
-                n_chunks += 1
+        # (SOBER/_rchq.py:127-135 -- the remainder's kernel columns also go to sets 0..N_rest-1, no weight added -- is one more
+        # chunk of ``evaluate``'s result)
         with _Timer(ops, trace, "project"):
             msg = ops.project(b.U_ext, b.q_ext, b.m_ext, Xpart, totpart, n_chunks, S_r, b.kscale)
         return msg, None, 1, 0
@@ -1012,12 +1060,10 @@ class OpaqueSums:
         nc_max = max(S, min(Rl, kernel.chunk_bytes // (8 * m)))
         nc_max = (nc_max // S) * S                              # whole blocks: every chunk starts at the same set, and at an
                                                                 # even position when the shard does (16-byte loads, see the kernel)
-        ones = ops.zeros(1, min(nc_max, Rl)) + 1.0
         for p0 in range(0, Rl, nc_max):
             nc = min(nc_max, Rl - p0)
             Kc = kernel.dense(ops, b.pts_nys, b.cand[p0:p0 + nc])
-            ops.dense_blocksum(Kc, b.mu[p0:p0 + nc], off + p0, n_full, S, 1.0, E)
-            ops.dense_blocksum(ones[:, :nc], b.mu[p0:p0 + nc], off + p0, n_full, S, 1.0, T)
+            ops.dense_blocksum(Kc, b.mu[p0:p0 + nc], off + p0, n_full, S, 1.0, E, tot=T)   # set weights in the same launch
         return E.unsqueeze(0), T
 
     def _borrow(self, cand, mu, need, S):

@@ -24,6 +24,11 @@ GPU_NULLSPACE = True
 # Multi-rank: every rank reduces the gathered message itself (the kernels sum in a fixed order, so all ranks obtain
 # the same survivors bit for bit) instead of rank 0 reducing and broadcasting the result: one collective less per round.
 REPLICATED_REDUCTION = True
+# Several batches in flight on several ranks (run_many): batch k's reductions run on rank k mod G ONLY and their outcome
+# (3 M + 1 doubles) is broadcast, stream-ordered, on a process group of the batch's own -- the chain of single-work-group
+# kernels (6.3 ms of a 21-ms batch at the headline size) then divides by G like the wide kernels do.  A single batch at a
+# time keeps the replicated form above (nothing to overlap the owner's chain with, one collective less per round).
+OWNER_RANK_REDUCTION = True
 SHARDED_BASIS = True             # multi-rank: split the range finder's Gram products over the ranks (False: rank 0 only)
 
 LATE_CHUNKS = 1                  # chunks of the round-1 block sums deferred behind the range finder (0 = none)

@@ -22,6 +22,7 @@ from dataclasses import dataclass, field
 
 import torch
 
+from . import _config as cfg
 from ._basis import drive
 from ._batch import Batch
 
@@ -37,6 +38,9 @@ class LocalComm:
 
     def broadcast(self, t, src=0):
         return t
+
+    def for_slot(self, i):
+        return self
 
 
 class TorchDistComm:
@@ -58,8 +62,26 @@ class TorchDistComm:
         return out
 
     def broadcast(self, t, src=0):
-        self.dist.broadcast(t, src=src, group=self.group)
+        """``src``: rank WITHIN this communicator's group."""
+        g_src = src if self.group is None else self.dist.get_global_rank(self.group, src)
+        self.dist.broadcast(t, src=g_src, group=self.group)
         return t
+
+    def for_slot(self, i):
+        """A communicator over the same ranks on a process group OF ITS OWN (created on first use, cached; every rank must
+        ask for the slots in the same order -- ``run_many`` does, up front).  Collectives of one process group execute in
+        issue order on one internal stream: with owner-rank reductions a batch's broadcast waits for the owner's chain of
+        single-work-group kernels, and on a shared group every other batch's all-gather would queue behind it.  One group
+        (= one RCCL communicator) per batch in flight keeps the batches' exchanges independent."""
+        key = (id(self.group), i)
+        comm = _SLOT_COMMS.get(key)
+        if comm is None:
+            ranks = list(range(self.dist.get_world_size())) if self.group is None else self.dist.get_process_group_ranks(self.group)
+            comm = _SLOT_COMMS[key] = TorchDistComm(self.dist.new_group(ranks=ranks))
+        return comm
+
+
+_SLOT_COMMS = {}                 # (id of the parent group, slot) -> TorchDistComm on its own process group
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -144,6 +166,11 @@ class RecombinationEngine:
         free = deque(slot_ops)
         active = deque()                                        # [job index, generator, ops, event it waits for]
         pipelined = len(slot_ops) > 1
+        # Several ranks, several batches in flight: batch k's per-round reductions run on rank k mod G only (the outcome is
+        # broadcast), so every GPU carries 1/G of the chains instead of all of them; each batch in flight talks on a process
+        # group of its own (``TorchDistComm.for_slot``).  Job k -> group k mod slots: the same on every rank by construction.
+        owner_mode = cfg.OWNER_RANK_REDUCTION and self.comm.world > 1 and pipelined
+        slot_comms = [self.comm.for_slot(i) for i in range(len(slot_ops))] if owner_mode else None
 
         def advance(entry):
             """Resume a batch until its next wait (-> True) or its end (-> False, result stored, slot freed)."""
@@ -165,8 +192,10 @@ class RecombinationEngine:
                 if job.seed is not None:
                     torch.manual_seed(job.seed)
                 job.times["start"] = time.perf_counter()
-                batch = Batch(ops, self.comm, job.pts_local, job.gid0, job.n_total, job.pts_nys, job.num_pts, job.kernel,
-                              job.trace, job.variant, job.init_weights, job.objective, pipelined=pipelined)
+                comm = slot_comms[k % len(slot_comms)] if owner_mode else self.comm
+                batch = Batch(ops, comm, job.pts_local, job.gid0, job.n_total, job.pts_nys, job.num_pts, job.kernel,
+                              job.trace, job.variant, job.init_weights, job.objective, pipelined=pipelined,
+                              owner=(k % self.comm.world) if owner_mode else None)
                 entry = [k, batch.steps(), ops, None]
                 if advance(entry):
                     active.append(entry)

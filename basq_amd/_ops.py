@@ -212,11 +212,13 @@ class HipOps:
         return out
 
     def finalize(self, parts, n_parts, msg_rows, q, S, diagU=None, ld_diag=0, n_diag=0, diag_noise=0.0, diag_wrow=0,
-                 diag_tail_row=0, n_tail_diag=0, geo_row=None):
-        """``geo_row``: descriptor-driven round -- the tail length comes from the device, ``n_tail_diag`` is its cap."""
+                 diag_tail_row=0, n_tail_diag=0, geo_row=None, tot_out=None):
+        """``geo_row``: descriptor-driven round -- the tail length comes from the device, ``n_tail_diag`` is its cap.
+        ``tot_out``: where the set weights go (a contiguous ``[S]`` slice of a ``reduction_result`` buffer)."""
         self._chk(parts)
         XcarT = self.empty(q + 1, S)
-        tot = self.empty(S)
+        tot = self.empty(S) if tot_out is None else tot_out
+        assert tot.is_contiguous() and tot.numel() == S
         check(self.lib.basq_finalize_geo_f64(_ptr(parts), n_parts, msg_rows, q, S, _ptr(diagU), ld_diag, n_diag,
                                              float(diag_noise), diag_wrow, diag_tail_row, n_tail_diag, _ptr(geo_row),
                                              _ptr(XcarT), _ptr(tot), self._stream()),
@@ -259,19 +261,38 @@ class HipOps:
             buf = cache[n] = self.zeros(n)
         return buf
 
-    def car_eliminate(self, PhiT, mu, M, s, cluster=True):
+    def reduction_result(self, M):
+        """ONE contiguous buffer for the outcome of a round's reduction + typed views into it -- what the rank that ran the
+        reduction broadcasts to the others (owner-rank mode, ``_batch.py``): ``res [3 M + 1]`` float64 =
+        ``w_star [M] | tot [M] | int32: info [2], kept [M], keep_rank [M]``.  -> ``(res, views)``."""
+        res = self.empty(3 * M + 1)
+        ints = res[2 * M:].view(torch.int32)                    # 2 M + 2 int32 words
+        ik = ints[:2 + M]
+        info, kept = ik[:2], ik[2:]
+        info.ik_buffer = ik
+        return res, dict(w_star=res[:M], tot=res[M:2 * M], info=info, kept=kept, keep_rank=ints[2 + M:2 + 2 * M])
+
+    def car_eliminate(self, PhiT, mu, M, s, cluster=True, out=None):
         """In place on PhiT/mu.  -> (keep_rank[M] i32, kept[s] i32, w_star[s] f64, info[2] i32 = [n_keep, status]);
         status 0 ok, 1 = a null vector without a positive entry, 2 = a cluster kernel (this one or the null space's) timed
-        out waiting for its sibling work-groups."""
+        out waiting for its sibling work-groups.  ``out``: the views of ``reduction_result(M)`` to write into."""
         self._chk(PhiT)
         self._chk(mu)
         if M > self.NULLSPACE_MAX_M:
-            return self._car_eliminate_wide(PhiT, mu, M, s)
-        keep_rank = self.empty(M, dtype=torch.int32)
-        ik = self.empty(2 + M, dtype=torch.int32)              # [info(2) | kept(<=M)]  (<= s unless the elimination
-        info, kept = ik[:2], ik[2:]                             #  stopped early, status 1)
-        info.ik_buffer = ik                                     # (info_kept_buffer: one D2H for both)
-        w_star = self.empty(M)
+            res = self._car_eliminate_wide(PhiT, mu, M, s)
+            if out is None:
+                return res
+            for key, val in zip(("keep_rank", "kept", "w_star", "info"), res):
+                out[key].copy_(val[:out[key].numel()])
+            return out["keep_rank"], out["kept"], out["w_star"], out["info"]
+        if out is not None:
+            keep_rank, kept, w_star, info = out["keep_rank"], out["kept"], out["w_star"], out["info"]
+        else:
+            keep_rank = self.empty(M, dtype=torch.int32)
+            ik = self.empty(2 + M, dtype=torch.int32)          # [info(2) | kept(<=M)]  (<= s unless the elimination
+            info, kept = ik[:2], ik[2:]                         #  stopped early, status 1)
+            info.ik_buffer = ik                                 # (info_kept_buffer: one D2H for both)
+            w_star = self.empty(M)
         check(self.lib.basq_car_eliminate_f64(_ptr(PhiT), _ptr(mu), M, s, _ptr(keep_rank), _ptr(kept), _ptr(w_star),
                                               _ptr(info), _ptr(self._reduction_ws(s, M) if cluster else None),
                                               self._stream()), "basq_car_eliminate_f64")
@@ -384,16 +405,20 @@ class HipOps:
               "basq_init_state_f64")
         return mu, gid
 
-    def dense_blocksum(self, Cmat, mu_chunk, pg0, n_full, S, scale, E, square=False):
+    def dense_blocksum(self, Cmat, mu_chunk, pg0, n_full, S, scale, E, square=False, tot=None):
         """E[j, s] += scale * sum_{p in chunk, set(p)=s} mu_p * C[j, p]  (``square``: ... * C[j, p]^2); in place on E.
+        ``tot`` (optional, ``[S]``): ``tot[s] += sum mu_p`` over the same candidates, in the same launch.
 
         ``Cmat`` may be a row-strided view (``stride(1) == 1``) of a wider buffer."""
         self._chk(E)
         if Cmat.dtype != torch.float64 or Cmat.stride(1) != 1:
             raise ValueError("expected a float64 matrix with unit column stride")
+        if tot is not None:
+            self._chk(tot)
+            assert tot.numel() == S
         m, nc = Cmat.shape
         check(self.lib.basq_dense_blocksum_f64(_ptr(Cmat), m, nc, Cmat.stride(0), _ptr(mu_chunk), pg0, n_full, S,
-                                               float(scale), 1 if square else 0, _ptr(E), self._stream()),
+                                               float(scale), 1 if square else 0, _ptr(E), _ptr(tot), self._stream()),
               "basq_dense_blocksum_f64")
 
     def blocksum_sq(self, spec, nys, m, cand, mu, Rl, off, n_full, S, n_chunks, bmatT, kobs, n_obs, noise):

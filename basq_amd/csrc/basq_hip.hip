@@ -316,7 +316,7 @@ struct BlocksumArgs {
     // Device-resident round descriptor (basq_round_next_i64): when set, the candidate range comes from HBM instead of the
     // launch arguments, so the host can enqueue a round before it knows how many candidates survived the previous one.
     const long long* geo;                      // {R, n_full, reg_hi, violation, nb, n_tail, -, -}
-    int geo_mode;                              // 1: positions [0, reg_hi)   2: [reg_hi, R)   3: [0, R)
+    int geo_mode;                              // 1: positions [0, reg_hi)   2: [reg_hi, R)   3: [0, R)   4: the remainder [n_full, R) as a block of its own
 };
 
 // Candidate range of a descriptor-driven launch (wave-uniform scalar loads and arithmetic; the formulas of blocksum_impl).
@@ -329,6 +329,7 @@ __device__ __forceinline__ void blocksum_apply_geo(BlocksumArgs& A) {
     long long lo = 0, hi = R;
     if (A.geo_mode == 1) hi = reg_hi;
     else if (A.geo_mode == 2) lo = reg_hi;
+    else if (A.geo_mode == 4) lo = n_full;
     if (lo < s_off) lo = s_off;
     if (hi > s_end) hi = s_end;
     if (hi < lo) hi = lo;
@@ -336,11 +337,18 @@ __device__ __forceinline__ void blocksum_apply_geo(BlocksumArgs& A) {
     A.cand += skip * KP;
     A.mu += skip;
     if (A.wx) A.wx += skip;
-    const long long off = lo, Rl = hi - lo;
+    long long off = lo;
+    const long long Rl = hi - lo;
+    long long nf = n_full;
+    if (A.geo_mode == 4) {                                    // the ragged remainder as ONE block of its own: point k in set k
+        off = lo - n_full;                                    // (SOBER/_rchq.py:127-135; fewer than S points)
+        nf = A.S;
+    }
     A.off = off;
     A.Rl = Rl;
-    A.n_full = n_full;
-    const long long lim = (off + Rl < n_full) ? (off + Rl) : n_full;
+    A.n_full = nf;
+    const long long n_full_eff = nf;
+    const long long lim = (off + Rl < n_full_eff) ? (off + Rl) : n_full_eff;
     if (lim > off) {
         A.blk_lo = off / A.S;
         A.blk_hi = (lim + A.S - 1) / A.S;
@@ -3678,14 +3686,16 @@ template <int JR, bool SQ>
 __global__ void __launch_bounds__(256) dense_blocksum_kernel(const double* __restrict__ C, int m, long long nc,
                                                              long long ldc, const double* __restrict__ mu,
                                                              long long pg0, long long n_full, int S, double scale,
-                                                             double* __restrict__ E) {
+                                                             double* __restrict__ E, double* __restrict__ T) {
     const int j0 = blockIdx.x * JR;
     const double* rows[JR];
 #pragma unroll
     for (int jr = 0; jr < JR; ++jr) rows[jr] = C + (long long)((j0 + jr < m) ? (j0 + jr) : (m - 1)) * ldc;
     const long long blk_end = (pg0 + nc < n_full) ? (pg0 + nc) : n_full;     // end of the block positions of this chunk
+    const bool do_tot = T != nullptr && blockIdx.x == 0;                      // the set weights ride along in work-group 0
     for (int s = threadIdx.x; s < S; s += 256) {
         double acc[JR];
+        double wacc = 0.0;
 #pragma unroll
         for (int jr = 0; jr < JR; ++jr) acc[jr] = 0.0;
         long long o = ((s - pg0 % S) % S + S) % S;                            // first chunk offset whose position = s mod S
@@ -3693,6 +3703,8 @@ __global__ void __launch_bounds__(256) dense_blocksum_kernel(const double* __res
         // two positions per trip: 2 JR + 2 independent loads in flight per lane
         for (; o + S < oe; o += 2 * (long long)S) {
             const double w0 = mu[o], w1 = mu[o + S];
+            wacc += w0;
+            wacc += w1;
             double c0[JR], c1[JR];
 #pragma unroll
             for (int jr = 0; jr < JR; ++jr) { c0[jr] = rows[jr][o]; c1[jr] = rows[jr][o + S]; }
@@ -3704,6 +3716,7 @@ __global__ void __launch_bounds__(256) dense_blocksum_kernel(const double* __res
         }
         for (; o < oe; o += S) {
             const double w0 = mu[o];
+            wacc += w0;
 #pragma unroll
             for (int jr = 0; jr < JR; ++jr) {
                 const double c = rows[jr][o];
@@ -3714,6 +3727,7 @@ __global__ void __launch_bounds__(256) dense_blocksum_kernel(const double* __res
             long long t = ((n_full > pg0) ? n_full : pg0) - pg0;
             for (; t < nc; ++t) {
                 const double w0 = mu[t];
+                wacc += w0;
 #pragma unroll
                 for (int jr = 0; jr < JR; ++jr) {
                     const double c = rows[jr][t];
@@ -3724,6 +3738,7 @@ __global__ void __launch_bounds__(256) dense_blocksum_kernel(const double* __res
 #pragma unroll
         for (int jr = 0; jr < JR; ++jr)
             if (j0 + jr < m) E[(long long)(j0 + jr) * S + s] += scale * acc[jr];
+        if (do_tot) T[s] += wacc;
     }
 }
 
@@ -3740,7 +3755,8 @@ template <int JR, bool SQ>
 __global__ void __launch_bounds__(1024) dense_blocksum_pairs_kernel(const double* __restrict__ C, int m, long long nc,
                                                                     long long ldc, const double* __restrict__ mu,
                                                                     long long pg0, long long n_full, int S, int NS,
-                                                                    double scale, double* __restrict__ E) {
+                                                                    double scale, double* __restrict__ E,
+                                                                    double* __restrict__ T) {
     extern __shared__ double dbs_red[];                          // [NS][JR][S] slice partials, then [waves][JR] tail partials
     const int half = S >> 1;
     const int t = threadIdx.x % half, k = threadIdx.x / half;   // set pair, position slice (blockDim.x = half * NS)
@@ -3754,10 +3770,13 @@ __global__ void __launch_bounds__(1024) dense_blocksum_pairs_kernel(const double
     long long o = (long long)(((2 * t - ph) % S + S) % S) + (long long)k * S;   // first offset of set 2t in slice k
     const long long step = (long long)NS * S;
     double a0[JR], a1[JR];
+    double wa0 = 0.0, wa1 = 0.0;                                 // set weights (consumed by work-group 0 only)
 #pragma unroll
     for (int jr = 0; jr < JR; ++jr) { a0[jr] = 0.0; a1[jr] = 0.0; }
     for (; o + step + 1 < oe; o += 2 * step) {                   // two blocks per trip: 2 JR + 2 loads of 16 bytes in flight
         const DPair w0 = *reinterpret_cast<const DPair*>(mu + o), w1 = *reinterpret_cast<const DPair*>(mu + o + step);
+        wa0 += w0.x; wa1 += w0.y;
+        wa0 += w1.x; wa1 += w1.y;
         DPair c0[JR], c1[JR];
 #pragma unroll
         for (int jr = 0; jr < JR; ++jr) {
@@ -3774,6 +3793,7 @@ __global__ void __launch_bounds__(1024) dense_blocksum_pairs_kernel(const double
     }
     for (; o + 1 < oe; o += step) {
         const DPair w0 = *reinterpret_cast<const DPair*>(mu + o);
+        wa0 += w0.x; wa1 += w0.y;
 #pragma unroll
         for (int jr = 0; jr < JR; ++jr) {
             const DPair c = *reinterpret_cast<const DPair*>(rows[jr] + o);
@@ -3783,41 +3803,52 @@ __global__ void __launch_bounds__(1024) dense_blocksum_pairs_kernel(const double
     }
     if (o < oe) {                                                // the chunk's block positions end inside this pair
         const double w0 = mu[o];
+        wa0 += w0;
 #pragma unroll
         for (int jr = 0; jr < JR; ++jr) {
             const double c = rows[jr][o];
             a0[jr] = __builtin_fma(SQ ? w0 * c : w0, c, a0[jr]);
         }
     }
-    // slices -> slice 0, in slice order
+    // slices -> slice 0, in slice order (row JR of a slice's LDS image = its set weights)
+    const bool do_tot = T != nullptr && blockIdx.x == 0;
     if (NS > 1) {
         if (k > 0) {
 #pragma unroll
             for (int jr = 0; jr < JR; ++jr) {
-                double* dst = dbs_red + ((long long)(k * JR + jr)) * S + 2 * t;
+                double* dst = dbs_red + ((long long)(k * (JR + 1) + jr)) * S + 2 * t;
                 dst[0] = a0[jr];
                 dst[1] = a1[jr];
             }
+            double* dw = dbs_red + ((long long)(k * (JR + 1) + JR)) * S + 2 * t;
+            dw[0] = wa0;
+            dw[1] = wa1;
         }
         __syncthreads();
         if (k == 0) {
-            for (int kk = 1; kk < NS; ++kk)
+            for (int kk = 1; kk < NS; ++kk) {
 #pragma unroll
                 for (int jr = 0; jr < JR; ++jr) {
-                    const double* src = dbs_red + ((long long)(kk * JR + jr)) * S + 2 * t;
+                    const double* src = dbs_red + ((long long)(kk * (JR + 1) + jr)) * S + 2 * t;
                     a0[jr] += src[0];
                     a1[jr] += src[1];
                 }
+                const double* sw = dbs_red + ((long long)(kk * (JR + 1) + JR)) * S + 2 * t;
+                wa0 += sw[0];
+                wa1 += sw[1];
+            }
         }
     }
     // ragged tail: offsets [tl, nc) all belong to set S-1 (BASQ/_rchq.py:91-99)
     const long long tl = ((n_full > pg0) ? n_full : pg0) - pg0;
     if (tl < nc) {                                               // work-group uniform
         double tt[JR];
+        double tw = 0.0;
 #pragma unroll
         for (int jr = 0; jr < JR; ++jr) tt[jr] = 0.0;
         for (long long q = tl + threadIdx.x; q < nc; q += blockDim.x) {
             const double w0 = mu[q];
+            tw += w0;
 #pragma unroll
             for (int jr = 0; jr < JR; ++jr) {
                 const double c = rows[jr][q];
@@ -3827,16 +3858,21 @@ __global__ void __launch_bounds__(1024) dense_blocksum_pairs_kernel(const double
 #pragma unroll
         for (int jr = 0; jr < JR; ++jr)
             for (int sh = 32; sh >= 1; sh >>= 1) tt[jr] += __shfl_xor(tt[jr], sh, 64);
+        for (int sh = 32; sh >= 1; sh >>= 1) tw += __shfl_xor(tw, sh, 64);
         __syncthreads();                                         // the slice partials have been consumed
         const int wave = threadIdx.x >> 6, nwaves = (blockDim.x + 63) >> 6;
-        if ((threadIdx.x & 63) == 0)
+        if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-            for (int jr = 0; jr < JR; ++jr) dbs_red[wave * JR + jr] = tt[jr];
+            for (int jr = 0; jr < JR; ++jr) dbs_red[wave * (JR + 1) + jr] = tt[jr];
+            dbs_red[wave * (JR + 1) + JR] = tw;
+        }
         __syncthreads();
         if (k == 0 && t == half - 1)
-            for (int w = 0; w < nwaves; ++w)
+            for (int w = 0; w < nwaves; ++w) {
 #pragma unroll
-                for (int jr = 0; jr < JR; ++jr) a1[jr] += dbs_red[w * JR + jr];
+                for (int jr = 0; jr < JR; ++jr) a1[jr] += dbs_red[w * (JR + 1) + jr];
+                wa1 += dbs_red[w * (JR + 1) + JR];
+            }
     }
     if (k == 0) {
 #pragma unroll
@@ -3846,6 +3882,10 @@ __global__ void __launch_bounds__(1024) dense_blocksum_pairs_kernel(const double
                 e[0] += scale * a0[jr];
                 e[1] += scale * a1[jr];
             }
+        if (do_tot) {
+            T[2 * t] += wa0;
+            T[2 * t + 1] += wa1;
+        }
     }
 }
 
@@ -4413,7 +4453,7 @@ int basq_blocksum_geo_f64(const basq_kernel_spec* spec, const double* nys, int32
                           int32_t n_chunks, int32_t class_mod, int32_t class0, double* Xpart, double* totpart,
                           void* stream) {
     if (!spec_ok(spec) || !nys || !cand || !mu || !Xpart || !totpart || !geo) return BASQ_EINVAL;
-    if (m < 1 || S < 1 || n_chunks < 1 || geo_mode < 1 || geo_mode > 3) return BASQ_EINVAL;
+    if (m < 1 || S < 1 || n_chunks < 1 || geo_mode < 1 || geo_mode > 4) return BASQ_EINVAL;
     if (class_mod < 0 || class0 < 0 || (class_mod > 0 && class0 + n_chunks > class_mod)) return BASQ_EINVAL;
     if (class_mod > 0 && geo_mode != 1) return BASQ_EINVAL;       // residue classes cover the regular region only
     BlocksumArgs A;
@@ -4477,24 +4517,30 @@ int basq_box_muller_f64(const double* u, int64_t n, const double* u_tail, double
 }
 
 int basq_dense_blocksum_f64(const double* C, int32_t m, int64_t nc, int64_t ldc, const double* mu, int64_t pg0,
-                            int64_t n_full, int32_t S, double scale, int32_t square, double* E, void* stream) {
+                            int64_t n_full, int32_t S, double scale, int32_t square, double* E, double* tot, void* stream) {
     if (!C || !mu || !E || m < 1 || nc < 0 || ldc < nc || pg0 < 0 || n_full < 0 || S < 1 || n_full % S != 0)
         return BASQ_EINVAL;
     if (nc == 0) return BASQ_OK;
     if (S % 2 == 0 && pg0 % 2 == 0 && S >= 4 && S <= 2048 && nc >= 4 * (int64_t)S) {
-        // 16 bytes per lane: set pairs x position slices (dense_blocksum_pairs_kernel)
+        // 16 bytes per lane: set pairs x position slices (dense_blocksum_pairs_kernel).  Slices: as many as keep the whole
+        // grid resident at once (20 waves per CU at this kernel's 84 registers): the launch then has no second, partly
+        // filled round of work-groups (1250 work-groups of 7 waves ran as 1.6 rounds: 81 % of the time useful).
         constexpr int JR8 = 8;
         const int half = S / 2;
-        int NS = 512 / half;
-        NS = NS < 1 ? 1 : (NS > 16 ? 16 : NS);
+        const long long grid_n = (m + JR8 - 1) / JR8;
         const long long nblocks = (nc + S - 1) / S;
-        while (NS > 1 && (long long)NS * 2 > nblocks) --NS;     // at least two blocks per slice
+        int NS = 1;
+        for (int cand_ns = 2; cand_ns <= 16; ++cand_ns) {
+            const long long waves = grid_n * ((half * cand_ns + 63) / 64);
+            if (half * cand_ns > 1024 || waves > 256LL * 20 || (long long)cand_ns * 2 > nblocks) break;
+            NS = cand_ns;
+        }
         const int nthr = half * NS;
-        size_t lds = (size_t)NS * JR8 * S * sizeof(double);
-        const size_t lds_tail = (size_t)((nthr + 63) / 64) * JR8 * sizeof(double);
+        size_t lds = (NS > 1) ? (size_t)NS * (JR8 + 1) * S * sizeof(double) : 0;
+        const size_t lds_tail = (size_t)((nthr + 63) / 64) * (JR8 + 1) * sizeof(double);
         if (lds < lds_tail) lds = lds_tail;
-        if (lds <= 160 * 1024 - 512) {
-            const dim3 grid8((unsigned)((m + JR8 - 1) / JR8)), block8((unsigned)nthr);
+        if (nthr <= 1024 && lds <= 160 * 1024 - 512) {
+            const dim3 grid8((unsigned)grid_n), block8((unsigned)nthr);
             const void* fn = square ? (const void*)dense_blocksum_pairs_kernel<JR8, true>
                                     : (const void*)dense_blocksum_pairs_kernel<JR8, false>;
             if (lds > 64 * 1024 &&
@@ -4502,10 +4548,10 @@ int basq_dense_blocksum_f64(const double* C, int32_t m, int64_t nc, int64_t ldc,
                 return BASQ_ELAUNCH;
             if (square)
                 hipLaunchKernelGGL((dense_blocksum_pairs_kernel<JR8, true>), grid8, block8, lds, (hipStream_t)stream, C, m,
-                                   (long long)nc, (long long)ldc, mu, (long long)pg0, (long long)n_full, S, NS, scale, E);
+                                   (long long)nc, (long long)ldc, mu, (long long)pg0, (long long)n_full, S, NS, scale, E, tot);
             else
                 hipLaunchKernelGGL((dense_blocksum_pairs_kernel<JR8, false>), grid8, block8, lds, (hipStream_t)stream, C, m,
-                                   (long long)nc, (long long)ldc, mu, (long long)pg0, (long long)n_full, S, NS, scale, E);
+                                   (long long)nc, (long long)ldc, mu, (long long)pg0, (long long)n_full, S, NS, scale, E, tot);
             BASQ_CHECK_LAUNCH();
             return BASQ_OK;
         }
@@ -4514,10 +4560,10 @@ int basq_dense_blocksum_f64(const double* C, int32_t m, int64_t nc, int64_t ldc,
     const dim3 grid((unsigned)((m + JR - 1) / JR)), block(256);
     if (square)
         hipLaunchKernelGGL((dense_blocksum_kernel<JR, true>), grid, block, 0, (hipStream_t)stream, C, m, (long long)nc,
-                           (long long)ldc, mu, (long long)pg0, (long long)n_full, S, scale, E);
+                           (long long)ldc, mu, (long long)pg0, (long long)n_full, S, scale, E, tot);
     else
         hipLaunchKernelGGL((dense_blocksum_kernel<JR, false>), grid, block, 0, (hipStream_t)stream, C, m, (long long)nc,
-                           (long long)ldc, mu, (long long)pg0, (long long)n_full, S, scale, E);
+                           (long long)ldc, mu, (long long)pg0, (long long)n_full, S, scale, E, tot);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }

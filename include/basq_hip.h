@@ -261,7 +261,9 @@ int basq_reweight_compact_f64(const double* cand, const double* mu, const int64_
  *       already enqueued for later rounds is a no-op inside the buffers the host sized for the expected counts.
  *   basq_blocksum_geo_f64: basq_blocksum_f64 with the candidate range taken from the descriptor -- geo_mode 1: positions
  *       [0, reg_hi) (class_mod > 0 allowed), 2: [reg_hi, R), 3: [0, R), each intersected with this rank's shard (the
- *       pointers, which address the shard's first candidate, are advanced on the device).
+ *       pointers, which address the shard's first candidate, are advanced on the device); 4: the ragged remainder
+ *       [n_full, R) as ONE block of its own -- remainder point k in set k -- the first of the two counts SOBER/_rchq.py
+ *       gives the remainder (:127-135; the caller drops the set weights of that launch: the reference adds none there).
  *   basq_reweight_compact_geo_f64: basq_reweight_compact_f64 with off, Rl, n_full from the descriptor, new_off from the
  *       NEXT round's descriptor (geo_next, written by basq_round_next_i64 just before) and n_keep from info[0]; the
  *       launch is sized for R_max >= Rl candidates and the outputs hold out_rows
@@ -308,9 +310,11 @@ int basq_init_state_f64(double* mu, int64_t* gid, int64_t Rl, int64_t gid0, int6
  * C [m, nc] (row stride ldc) = values of the Nystrom rows against nc consecutive candidates whose first GLOBAL
  * position is pg0 (set(p) = p % S below n_full, S-1 from n_full on); mu is indexed from the chunk start.
  * E [m, S] is accumulated into (zero it first); chunks must be submitted in position order (fixed summation order).
+ * tot (may be NULL): tot[s] += sum of mu[p] over the same candidates -- the set weights `tot_weights` (BASQ/_rchq.py:90,
+ * :98), unscaled -- in the same launch.
  */
 int basq_dense_blocksum_f64(const double* C, int32_t m, int64_t nc, int64_t ldc, const double* mu, int64_t pg0,
-                            int64_t n_full, int32_t S, double scale, int32_t square, double* E, void* stream);
+                            int64_t n_full, int32_t S, double scale, int32_t square, double* E, double* tot, void* stream);
 
 /*
  * WSABI-M's non-linear term, fused (BASQ/_wsabi.py:227-249: CLy = mu_x cov mu_y + 0.5 cov^2, cov = the GP's predictive

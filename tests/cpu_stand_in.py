@@ -219,7 +219,7 @@ class CpuStandInOps:
         return torch.cat([totpart.sum(0).unsqueeze(0), outputscale * (U @ X)], 0)
 
     def finalize(self, parts, n_parts, msg_rows, q, S, diagU=None, ld_diag=0, n_diag=0, diag_noise=0.0, diag_wrow=0,
-                 diag_tail_row=0, n_tail_diag=0, geo_row=None):
+                 diag_tail_row=0, n_tail_diag=0, geo_row=None, tot_out=None):
         self._count("finalize")
         if geo_row is not None:
             n_tail_diag = min(n_tail_diag, int(geo_row[5]))
@@ -237,13 +237,28 @@ class CpuStandInOps:
             if n_diag > 0:
                 feat[:, :n_diag] += diag_noise * wgt[:n_diag].unsqueeze(0) * diagU[:, :n_diag]
         XcarT = torch.cat([torch.ones(1, S, dtype=torch.float64), feat / tot.unsqueeze(0)], 0)
+        if tot_out is not None:
+            tot_out.copy_(tot)
+            tot = tot_out
         return XcarT, tot
+
+    def reduction_result(self, M):
+        """Same layout as ``HipOps.reduction_result``: one float64 buffer, typed views into it."""
+        res = torch.zeros(3 * M + 1, dtype=torch.float64)
+        ints = res[2 * M:].view(torch.int32)
+        ik = ints[:2 + M]
+        return res, dict(w_star=res[:M], tot=res[M:2 * M], info=ik[:2], kept=ik[2:], keep_rank=ints[2 + M:2 + 2 * M])
 
     def nullspace(self, XcarT, s, M, cluster=True):
         self._count("nullspace")
         return householder_nullspace(XcarT)
 
-    def car_eliminate(self, PhiT, mu, M, s, cluster=True):
+    def car_eliminate(self, PhiT, mu, M, s, cluster=True, out=None):
+        if out is not None:
+            res = self.car_eliminate(PhiT, mu, M, s, cluster)
+            for key, val in zip(("keep_rank", "kept", "w_star", "info"), res):
+                out[key].copy_(val)
+            return out["keep_rank"], out["kept"], out["w_star"], out["info"]
         self._count("car")
         Phi = PhiT.T.clone()                                   # [M, M-s]
         status = 0
@@ -322,10 +337,13 @@ class CpuStandInOps:
 
     def blocksum_geo(self, spec, nys, m, cand, mu, wx, geo_row, mode, S, n_chunks, out=None, class_mod=0, class0=0):
         R, n_full, reg_hi, off, Rl = (int(geo_row[k]) for k in (0, 1, 2, 6, 7))
-        lo, hi = (0, reg_hi) if mode == 1 else ((reg_hi, R) if mode == 2 else (0, R))
+        lo, hi = (0, reg_hi) if mode == 1 else ((reg_hi, R) if mode == 2 else ((n_full, R) if mode == 4 else (0, R)))
         lo, hi = max(lo, off), min(hi, off + Rl)               # the mode's range, restricted to this rank's shard
         hi = max(hi, lo)
         sk = lo - off
+        if mode == 4:                                          # the remainder as a block of its own: point k in set k
+            return self.blocksum(spec, nys, m, cand[sk:], mu[sk:], None if wx is None else wx[sk:], hi - lo, lo - n_full, S, S,
+                                 n_chunks, out=out)
         return self.blocksum(spec, nys, m, cand[sk:], mu[sk:], None if wx is None else wx[sk:], hi - lo, lo, n_full, S,
                              n_chunks, out=out, class_mod=class_mod, class0=class0)
 
@@ -359,12 +377,14 @@ class CpuStandInOps:
         gid = gid0 + torch.arange(max(Rl, 1), dtype=torch.int64)
         return mu, gid
 
-    def dense_blocksum(self, Cmat, mu_chunk, pg0, n_full, S, scale, E, square=False):
+    def dense_blocksum(self, Cmat, mu_chunk, pg0, n_full, S, scale, E, square=False, tot=None):
         self._count("dense_sq" if square else "dense")
         m, nc = Cmat.shape
         pg = pg0 + torch.arange(nc)
         sets = torch.where(pg < n_full, pg % S, torch.full_like(pg, S - 1))
         E.index_add_(1, sets, scale * ((Cmat * Cmat) if square else Cmat) * mu_chunk[:nc].unsqueeze(0))
+        if tot is not None:
+            tot.reshape(-1).index_add_(0, sets, mu_chunk[:nc])
 
     def gram_into(self, spec, packA, na, packB, nb, out):
         out[:na, :nb] = self.gram(spec, packA, na, packB, nb)

@@ -331,8 +331,13 @@ def test_dense_blocksum_vs_standin(hip_ops, m, nc, pg0, n_full, S, square):
     Eg = hip_ops.to_device(E0.clone())
     wide = hip_ops.zeros(m, nc + 7)
     wide[:, :nc] = hip_ops.to_device(Cm)
-    hip_ops.dense_blocksum(wide[:, :nc], hip_ops.to_device(mu), pg0, n_full, S, 0.5, Eg, square=square)
+    T0 = _rand(S, 1, 33).reshape(-1).contiguous()
+    Tc = T0.clone()
+    cpu.dense_blocksum(torch.ones(1, nc, dtype=torch.float64), mu, pg0, n_full, S, 1.0, Tc.reshape(1, -1))
+    Tg = hip_ops.to_device(T0.clone())
+    hip_ops.dense_blocksum(wide[:, :nc], hip_ops.to_device(mu), pg0, n_full, S, 0.5, Eg, square=square, tot=Tg)
     assert (Eg.cpu() - Ec).abs().max().item() <= 1e-12 * Ec.abs().max().item()
+    assert (Tg.cpu() - Tc).abs().max().item() <= 1e-12 * Tc.abs().max().item()       # the set weights of the same launch
 
 
 @pytest.mark.parametrize("family,d,m,n_obs,Rl,off,n_full,S,n_chunks,noise", [

@@ -113,7 +113,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q, opaque=()):
+def _worker(rank, world, port, q, opaque=(), owner_mode=True, n_slots=2, names=("rbf_ragged", "cfg1_posterior_1e4", "rbf_1e4")):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -121,10 +121,11 @@ def _worker(rank, world, port, q, opaque=()):
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from basq_amd._engine import TorchDistComm
+        import basq_amd._config as cfg
+        from basq_amd._engine import EngineTrace, TorchDistComm
         from basq_amd._partition import initial_shards
 
-        names = ["rbf_ragged", "cfg1_posterior_1e4", "rbf_1e4"]
+        cfg.OWNER_RANK_REDUCTION = owner_mode
         jobs = []
         for nm in names:
             c = BY_NAME[nm]
@@ -137,10 +138,13 @@ def _worker(rank, world, port, q, opaque=()):
 
                 ko, _ = build_oracle_kernel(c)
                 kern = CallableKernel(lambda x, y, ko=ko: ko(x, y))
-            jobs.append(Job(pts[off:off + n].clone(), off, c["N"], nys, c["n"], kern, seed=c["torch_seed"]))
-        slots = [CpuStandInOps(), CpuStandInOps()]
+            jobs.append(Job(pts[off:off + n].clone(), off, c["N"], nys, c["n"], kern, seed=c["torch_seed"],
+                            trace=EngineTrace(host_sync=False)))
+        slots = [CpuStandInOps() for _ in range(n_slots)]
         res = RecombinationEngine(slots[0], TorchDistComm()).run_many(jobs, slots)
-        q.put((rank, [(i.tolist(), w.tolist()) for i, w in res], slots[0].calls.get("round_next", 0)))
+        q.put((rank, [(i.tolist(), w.tolist()) for i, w in res], slots[0].calls.get("round_next", 0),
+               [[r["kept"] for r in j.trace.rounds] for j in jobs],
+               sum(sl.calls.get("car", 0) for sl in slots)))
     finally:
         dist.destroy_process_group()
 
@@ -161,7 +165,7 @@ def test_run_many_sharded_matches_goldens(world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, out, n_next in res:
+    for rank, out, n_next, _, _ in res:
         assert n_next > 0                                                     # descriptor-driven rounds on several ranks
         for nm, (idx, w) in zip(["rbf_ragged", "cfg1_posterior_1e4", "rbf_1e4"], out):
             fx = load_golden(nm)
@@ -169,6 +173,47 @@ def test_run_many_sharded_matches_goldens(world):
             gw = torch.tensor(fx["w"], dtype=torch.float64)
             assert ((torch.tensor(w, dtype=torch.float64) - gw).abs() / gw).max().item() <= 1e-6
     assert all(r[1] == res[0][1] for r in res)                                # bit-identical across the ranks
+
+
+OWNER_NAMES = ("rbf_ragged", "cfg1_posterior_1e4", "rbf_1e4", "wsabil_noise_ragged", "matern52_posterior", "posterior_noise_ragged",
+               "rbf_2e4_defaults", "wsabil_2e4")
+
+
+@pytest.mark.parametrize("world,n_slots,owner_mode", [(2, 2, True), (4, 4, True), (8, 4, True), (3, 2, True), (2, 3, False)])
+def test_run_many_owner_rank_reductions(world, n_slots, owner_mode):
+    """Several ranks x several batches in flight with OWNER-RANK reductions: batch k's null space + elimination run on rank
+    k mod G only, the outcome travels by a broadcast on the batch's own process group (``_config.OWNER_RANK_REDUCTION``).
+    Eight jobs (stationary, posterior, WSABI-L; with and without a ragged remainder / a visible noise diagonal) on worlds
+    2, 3, 4 and 8: every rank returns the golden indices AND the golden per-round kept sets of every job, all ranks are
+    bit-identical, and the eliminations really were dealt out (each rank ran about 1/G of them -- in the replicated mode,
+    ``owner_mode`` False, every rank runs all of them)."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, (), owner_mode, n_slots, OWNER_NAMES)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, n_next, kept, _ in res:
+        assert n_next > 0
+        for nm, (idx, w), kr in zip(OWNER_NAMES, out, kept):
+            fx = load_golden(nm)
+            assert idx == fx["idx"], f"rank {rank} {nm}"
+            gw = torch.tensor(fx["w"], dtype=torch.float64)
+            assert ((torch.tensor(w, dtype=torch.float64) - gw).abs() / gw).max().item() <= 1e-6
+            assert kr == [r["kept"] for r in fx["rounds"]], f"rank {rank} {nm}: per-round kept sets"
+    assert all(r[1] == res[0][1] for r in res)
+    cars = sorted(r[4] for r in res)
+    total_rounds = sum(load_golden(nm)["n_rounds"] for nm in OWNER_NAMES)
+    if owner_mode:
+        assert sum(cars) == total_rounds and cars[-1] <= total_rounds // world + 2 * max(load_golden(nm)["n_rounds"] for nm in OWNER_NAMES)
+    else:
+        assert all(c == total_rounds for c in cars)
 
 
 @pytest.mark.parametrize("opaque", [("rbf_ragged",), ("cfg1_posterior_1e4",), ("rbf_ragged", "rbf_1e4")])
@@ -190,7 +235,7 @@ def test_run_many_sharded_with_opaque_callables_and_more_jobs_than_slots(opaque)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, out, _ in res:
+    for rank, out, _, _, _ in res:
         for nm, (idx, w) in zip(["rbf_ragged", "cfg1_posterior_1e4", "rbf_1e4"], out):
             fx = load_golden(nm)
             assert idx == fx["idx"], f"rank {rank} {nm}"
