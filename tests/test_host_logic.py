@@ -510,7 +510,7 @@ def test_cluster_timeout_is_retried_on_single_workgroup_kernels():
     class TimingOut(CpuStandInOps):
         seen_cluster_false = 0
 
-        def car_eliminate(self, PhiT, mu, M, s, cluster=True):
+        def car_eliminate(self, PhiT, mu, M, s, cluster=True, out=None):
             out = super().car_eliminate(PhiT, mu, M, s, cluster)
             if not cluster:
                 TimingOut.seen_cluster_false += 1
