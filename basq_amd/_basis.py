@@ -192,6 +192,33 @@ class _DenseProducts:
     def full(self):
         return self.A
 
+    def qr_of_product(self, Q, flags, passes, transpose=False):
+        """Orthonormal basis of ``range(A Q)`` (``transpose``: ``A^T Q``) by CholeskyQR -> ``[m, k]``."""
+        return _cholqr(self.ops, self.at(Q) if transpose else self.a(Q), flags, passes)
+
+    def lq_factors(self, Q):
+        """``B = Q^T A = L1 L2 Qb^T`` by CholeskyQR2 on the rows of ``Y = A^T Q`` -> ``(G1, G2, i1, i2, k)`` with the factors in
+        the lower triangles of ``G1``, ``G2`` (``nystrom_basis_steps``)."""
+        ops = self.ops
+        Y = self.at(Q)
+        k = Y.shape[1]
+        G1 = _mm_splitk(ops, Y.t(), Y, 32)                     # = B B^T
+        if cfg.FUSED_CHOLQR and k <= getattr(ops, "CHOLQR_FUSED_MAX_Q", 0):
+            Yq, i1 = ops.cholqr(G1, Y)                          # = (L1^-1 B)^T, G1 -> L1 in place
+            G2 = _mm_splitk(ops, Yq.t(), Yq, 32)
+            i2 = ops.chol_factor(G2)
+        elif k <= getattr(ops, "CHOL_FACTOR_MAX_Q", 0):
+            i1 = ops.chol_factor(G1)
+            Yq = ops.trsm_rows(Y, G1)                           # = (L1^-1 B)^T
+            G2 = _mm_splitk(ops, Yq.t(), Yq, 32)
+            i2 = ops.chol_factor(G2)
+        else:
+            W1, i1 = ops.chol_inv(G1)
+            Yq = _mm_splitk(ops, Y, W1, 1)
+            G2 = _mm_splitk(ops, Yq.t(), Yq, 32)
+            _, i2 = ops.chol_inv(G2)
+        return G1, G2, i1, i2, k
+
 
 class _ShardedProducts:
     """Rows ``[r0, r0 + mr)`` of ``A`` on this rank (multi-GPU, SURVEY 8e: the range finder no longer idles W-1 GPUs).
@@ -232,6 +259,58 @@ class _ShardedProducts:
         g = self.comm.all_gather(blk)
         return torch.cat([g[r, :n] for r, (_, n) in enumerate(self.shards)], 0)
 
+    # -- CholeskyQR with the rows divided over the ranks (round 4) ---------------------------------------------------
+    # ``X = A Q`` is born row-sharded (``X_r = A_rows @ Q``), and CholeskyQR needs X only through ``G = X^T X = sum_r X_r^T X_r``:
+    # every rank multiplies and solves ITS rows -- ``G_r`` (q x q) all-gathered and added in rank order, the q x q Cholesky
+    # replicated (it is the serial part), ``Q_r = X_r L^-T`` local -- and the blocks that travel are those of Q, not of X.
+    # One small collective more per pass (80 KB per rank at q = 99); the Gram product and the triangular solve, which
+    # every rank used to run on all m rows, divide by the rank count.
+    def _gram_sum(self, Xr):
+        ops, k = self.ops, Xr.shape[1]
+        Gr = _mm_splitk(ops, Xr.t(), Xr, 32) if Xr.shape[0] > 0 else ops.zeros(k, k)
+        return ops.sum_parts(self.comm.all_gather(Gr))          # rank order: the same G, bit for bit, on every rank
+
+    def _gather_rows(self, Xr):
+        blk = self.ops.zeros(self.mb, Xr.shape[1])
+        if Xr.shape[0]:
+            blk[:Xr.shape[0]] = Xr
+        g = self.comm.all_gather(blk)
+        return torch.cat([g[r, :n] for r, (_, n) in enumerate(self.shards)], 0)
+
+    def _local_product(self, Q):
+        return _mm_splitk(self.ops, self.rows, Q, 64) if self.rows.shape[0] else self.ops.zeros(0, Q.shape[1])
+
+    def _sharded_ok(self, k):
+        return cfg.SHARDED_CHOLQR and k <= getattr(self.ops, "CHOL_FACTOR_MAX_Q", 0)
+
+    def _cholqr_rows(self, Xr, flags, passes):
+        ops = self.ops
+        for _ in range(passes):
+            G = self._gram_sum(Xr)
+            if Xr.shape[0] and cfg.FUSED_CHOLQR and Xr.shape[1] <= getattr(ops, "CHOLQR_FUSED_MAX_Q", 0):
+                Xr, info = ops.cholqr(G, Xr)
+                flags.append(info)
+            else:
+                flags.append(ops.chol_factor(G))
+                Xr = ops.trsm_rows(Xr, G) if Xr.shape[0] else Xr
+        return Xr, G
+
+    def qr_of_product(self, Q, flags, passes, transpose=False):
+        if not self._sharded_ok(Q.shape[1]):
+            return _cholqr(self.ops, self.a(Q), flags, passes)
+        Xr, _ = self._cholqr_rows(self._local_product(Q), flags, passes)
+        return self._gather_rows(Xr)
+
+    def lq_factors(self, Q):
+        k = Q.shape[1]
+        if not self._sharded_ok(k):
+            return _DenseProducts.lq_factors(self, Q)
+        flags = []
+        Yq, G1 = self._cholqr_rows(self._local_product(Q), flags, 1)     # G1 -> L1 in place (every rank: the same bits)
+        G2 = self._gram_sum(Yq)
+        i2 = self.ops.chol_factor(G2)
+        return G1, G2, flags[0], i2, k
+
 
 def nystrom_basis_steps(ops, A, q_req: int, trace=None, overlap=None, notes=None):
     """``ker_svd_sparsify`` as a step generator -> ``U [min(q, m), m]`` (see :func:`nystrom_basis`).
@@ -256,30 +335,14 @@ def nystrom_basis_steps(ops, A, q_req: int, trace=None, overlap=None, notes=None
     if cfg.GPU_RANGE_FINDER and q_req <= m:
         with _Timer(ops, trace, "basis.gpu_range"):
             flags = []
-            Q = _cholqr(ops, prod.a(R), flags, passes=1)
-            Q = _cholqr(ops, prod.at(Q), flags, passes=1)
-            Q = _cholqr(ops, prod.a(Q), flags, passes=1)
-            Q = _cholqr(ops, prod.at(Q), flags, passes=1)
-            Q = _cholqr(ops, prod.a(Q), flags, passes=2)         # the basis that is actually used
+            Q = prod.qr_of_product(R, flags, 1)
+            Q = prod.qr_of_product(Q, flags, 1, transpose=True)
+            Q = prod.qr_of_product(Q, flags, 1)
+            Q = prod.qr_of_product(Q, flags, 1, transpose=True)
+            Q = prod.qr_of_product(Q, flags, 2)                  # the basis that is actually used
             # LQ of B = Q^T A ([k, m]) by CholeskyQR2 on its rows, formed on Y = B^T = A^T Q ([m, k]: tall, row-parallel):
             #   B = L1 L2 Qb^T  ->  the left singular vectors of B are those of L = L1 L2
-            Y = prod.at(Q)
-            k = Y.shape[1]
-            G1 = _mm_splitk(ops, Y.t(), Y, 32)                 # = B B^T
-            if cfg.FUSED_CHOLQR and k <= getattr(ops, "CHOLQR_FUSED_MAX_Q", 0):
-                Yq, i1 = ops.cholqr(G1, Y)                      # = (L1^-1 B)^T, G1 -> L1 in place
-                G2 = _mm_splitk(ops, Yq.t(), Yq, 32)
-                i2 = ops.chol_factor(G2)
-            elif k <= getattr(ops, "CHOL_FACTOR_MAX_Q", 0):
-                i1 = ops.chol_factor(G1)
-                Yq = ops.trsm_rows(Y, G1)                       # = (L1^-1 B)^T
-                G2 = _mm_splitk(ops, Yq.t(), Yq, 32)
-                i2 = ops.chol_factor(G2)
-            else:
-                W1, i1 = ops.chol_inv(G1)
-                Yq = _mm_splitk(ops, Y, W1, 1)
-                G2 = _mm_splitk(ops, Yq.t(), Yq, 32)
-                _, i2 = ops.chol_inv(G2)
+            G1, G2, i1, i2, k = prod.lq_factors(Q)
             L = _mm_splitk(ops, torch.tril(G1), torch.tril(G2), 1)
             bad = torch.stack([f.reshape(()) for f in flags + [i1, i2]]).max()
             both, ready = ops.to_host_async(torch.cat([L.reshape(-1), bad.to(torch.float64).reshape(1)]), "basisL")

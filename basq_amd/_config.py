@@ -29,6 +29,8 @@ REPLICATED_REDUCTION = True
 # kernels (6.3 ms of a 21-ms batch at the headline size) then divides by G like the wide kernels do.  A single batch at a
 # time keeps the replicated form above (nothing to overlap the owner's chain with, one collective less per round).
 OWNER_RANK_REDUCTION = True
+SHARDED_CHOLQR = True            # multi-rank range finder: Gram product + triangular solve of every CholeskyQR pass on the rank's
+                                 # own rows (q x q partial Grams all-gathered, the q x q factor replicated); False: on all m rows
 SHARDED_BASIS = True             # multi-rank: split the range finder's Gram products over the ranks (False: rank 0 only)
 
 LATE_CHUNKS = 1                  # chunks of the round-1 block sums deferred behind the range finder (0 = none)

@@ -46,6 +46,63 @@ def _sober_worker(rank, world, port, i, q):
         dist.destroy_process_group()
 
 
+def _timeout_worker(rank, world, port, name, q, bad_rank):
+    """One rank's cluster kernels 'time out' (status 2) now and then; the others never do."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import warnings
+
+        from basq_amd._engine import RecombinationEngine, TorchDistComm
+        from basq_amd._partition import initial_shards
+        from tests.cpu_stand_in import CpuStandInOps
+
+        class TimingOut(CpuStandInOps):
+            def car_eliminate(self, PhiT, mu, M, s, cluster=True, out=None):
+                res = super().car_eliminate(PhiT, mu, M, s, cluster, out)
+                if cluster and rank == bad_rank and self.calls["car"] in (2, 5):
+                    res[3][1] = 2
+                return res
+
+        c = BY_NAME[name]
+        pts, nys = build_pool(c)
+        off, n = initial_shards(c["N"], world)[rank]
+        torch.manual_seed(c["torch_seed"])
+        with warnings.catch_warnings(record=True) as wlist:
+            warnings.simplefilter("always")
+            idx, w = RecombinationEngine(TimingOut(), TorchDistComm()).run(pts[off:off + n].clone(), off, c["N"], nys, c["n"],
+                                                                           build_product_kernel(c))
+        q.put((rank, idx.tolist(), w.tolist(), sum("timed out" in str(x.message) or "repeated" in str(x.message) for x in wlist)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,world,bad_rank", [("rbf_ragged", 2, 1), ("cfg1_posterior_1e4", 3, 2)])
+def test_cluster_timeout_on_one_rank_is_a_collective_decision(name, world, bad_rank):
+    """with the reduction replicated on every rank, a cluster kernel's time-out (status 2) is local to ONE rank.
+    The retry -- in the descriptor-driven rounds: the fall-back to the round-by-round loop -- must be taken by ALL ranks or
+    their all-gathers pair up across different rounds.  The status travels with the next exchange (maximum over the ranks);
+    every rank returns the golden batch and every rank reports the retry."""
+    fx = load_golden(name)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_timeout_worker, args=(r, world, port, name, q, bad_rank)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    gw = torch.tensor(fx["w"], dtype=torch.float64)
+    for rank, idx, w, n_warn in res:
+        assert idx == fx["idx"], f"rank {rank}"
+        assert ((torch.tensor(w, dtype=torch.float64) - gw).abs() / gw).max().item() <= 1e-6
+        assert n_warn >= 1, f"rank {rank} did not report the retry"
+
+
 def _worker(rank, world, port, name, q, rank0_only=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

@@ -484,9 +484,13 @@ def test_box_muller_vs_torch_randn(hip_ops, n):
 
 
 def test_sharded_products_on_device(hip_ops):
-    """The row-sharded range finder's device code (split-K batched GEMM on a row block, padded all-gather layout)
-    against the dense range finder, on one GPU: a loop-back communicator that plays both ranks of a 2-rank group."""
+    """The row-sharded range finder's device code -- split-K GEMM on a row block, padded all-gather layout, and (round 4)
+    CholeskyQR with the Gram product and the triangular solve on the rank's own rows -- against the dense range finder, on
+    ONE GPU: two host threads play the ranks of a 2-rank group and exchange through a barrier (same device, same library)."""
+    import threading
+
     import basq_amd._basis as E
+    from basq_amd._ops import HipOps
     from basq_amd.kernels import StationaryKernel
     from basq_amd.pools import gmm_pool
 
@@ -496,47 +500,66 @@ def test_sharded_products_on_device(hip_ops):
     center = hip_ops.col_mean(nys)
     A = kern.dense(hip_ops, nys, nys, center)
     shards = [(0, 501), (501, 499)]
+    torch.cuda.synchronize()
 
-    class LoopBack:
-        """all_gather answers with what the OTHER emulated rank would have contributed, computed right here."""
-        rank, world = 0, 2
+    class ThreadComm:
+        world = 2
+        slots, barrier = [None, None], threading.Barrier(2)
 
-        def __init__(self):
-            self.other = None
-
-        def broadcast(self, t, src=0):
-            return t
+        def __init__(self, rank):
+            self.rank = rank
 
         def all_gather(self, blk):
-            return torch.stack([blk, self.other(blk)], 0)
+            torch.cuda.synchronize()
+            ThreadComm.slots[self.rank] = blk
+            ThreadComm.barrier.wait()
+            out = torch.stack([ThreadComm.slots[0], ThreadComm.slots[1]], 0)
+            ThreadComm.barrier.wait()
+            return out
 
-    comm = LoopBack()
-    prod = E._ShardedProducts(hip_ops, comm, A[:501].contiguous(), shards, m)
-    state = {}
-    orig_a = prod.a
+        def broadcast(self, t, src=0):
+            torch.cuda.synchronize()
+            if self.rank == src:
+                ThreadComm.slots[src] = t
+            ThreadComm.barrier.wait()
+            t.copy_(ThreadComm.slots[src])
+            torch.cuda.synchronize()
+            ThreadComm.barrier.wait()
+            return t
 
-    def a(Q):
-        state["Q"] = Q
-        return orig_a(Q)
+    results, errors = [None, None], []
+    seed_state = torch.get_rng_state()
 
-    def other(blk):
-        out = torch.zeros_like(blk)
-        if blk.shape[1] == m:                                     # full(): the row block itself
-            out[:499] = A[501:]
-        else:
-            out[:499] = E._mm_splitk(hip_ops, A[501:].contiguous(), state["Q"], 64)
-        return out
+    def run(rank):
+        try:
+            ops = HipOps(hip_ops.device)
+            if rank != 0:                                         # one process here: only "rank 0" may consume the generator
+                ops.host_uniform = lambda n, tag: torch.zeros(n, dtype=torch.float64)
+            r0, mr = shards[rank]
+            prod = E._ShardedProducts(ops, ThreadComm(rank), A[r0:r0 + mr].contiguous(), shards, m)
+            results[rank] = E.nystrom_basis(ops, prod, q)
+            if rank == 0:
+                assert torch.equal(prod.full(), A)
+            else:
+                prod.full()
+        except Exception as exc:                                  # noqa: BLE001  (re-raised in the main thread)
+            errors.append(exc)
+            ThreadComm.barrier.abort()
 
-    comm.other = other
-    prod.a = a
-    prod.at = a
-    torch.manual_seed(5)
-    Us = E.nystrom_basis(hip_ops, prod, q)
+    torch.manual_seed(5)                                          # rank 0 draws the test matrix; rank 1 only advances
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
     torch.manual_seed(5)
     Ud = E.nystrom_basis(hip_ops, A, q)
+    assert torch.equal(results[0], results[1])                    # the same bits on both ranks
+    Us = results[0]
     sign = torch.sign((Us * Ud).sum(1, keepdim=True))
     assert (Us * sign - Ud).abs().max().item() <= 1e-7
-    assert torch.equal(prod.full(), A)
+    del seed_state
 
 
 def test_fuzz_single_workgroup_kernels(hip_ops):
