@@ -15,8 +15,9 @@ Rank 0 prints ONE JSON line.
 * value     = steps one after the other (each call returns before the next starts: the reference's synchronous call);
               ``value_concurrent2`` (``concurrent`` object) = max(K, 12) of the same steps with TWO independent batches in flight
               (``basq_amd.recombination_many``: the reference's own pair, selection + quadrature, ``BASQ/_basq.py:82-88,
-              104-106``), results bit-identical to the sequential runs; ``value_concurrent3`` on one GPU, ``value_concurrent4`` on
-              multi-GPU lines;
+              104-106``), results bit-identical to the sequential runs; ``value_concurrent3`` on one GPU, ``value_concurrent4`` /
+              ``value_concurrent8`` on multi-GPU lines (owner-rank reductions: batch k's chain on rank k mod N), with an ``rccl``
+              object naming the process group the line was measured on;
 * roofline  = the dominant kernel (``blocksum_kernel``): algorithmic flops = pairs * (3d + 3)
               (SURVEY §8d) over its HIP-event time on the launch stream, against the fp64 vector peak;
 * cpu_baseline = the oracle (= the reference's CPU op sequence) on this host's cores, bounded sample.
@@ -142,8 +143,10 @@ def main():
     # ---- several batches in flight (outside the timed region of `value`): the same K steps through recombination_many ----
     concurrent = {}
     if not (args.no_concurrent or args.no_roofline_batch or args.plain):
-        for k_fl in ([2, 3] if world == 1 and not force_dist else [2, 4]):
-            n_c = max(args.steps, 12)                                # enough steps for the pipeline's fill and drain not to dominate
+        # several ranks: batch k's reductions live on rank k mod G (owner-rank mode, basq_amd/_config.py), so the chains only
+        # spread over all G GPUs with at least G batches in flight
+        for k_fl in ([2, 3] if world == 1 and not force_dist else sorted({2, 4, max(4, min(world, 8))})):
+            n_c = max(args.steps, 12, 3 * k_fl)                      # enough steps for the pipeline's fill and drain not to dominate
             calls, seeds = [], [1] * n_c
             for k in range(n_c):
                 pts_nys, pts_local = pools_dev[k % len(pools_dev)]
@@ -316,6 +319,16 @@ def main():
                     f"{best['seconds_per_batch']:.1f}s/batch); un-sampled anchor: profiles/r02_cpu_full_batch.txt"),
         )
 
+    rccl_info = None
+    if dist is not None:
+        import basq_amd._config as bcfg
+
+        rccl_info = {"world": dist.get_world_size(), "backend": dist.get_backend(),
+                     "sequential_batch": "reduction replicated on every rank (one all-gather of the (q+1) x 2n message per round)",
+                     "batches_in_flight": ("owner-rank reductions: batch k's null space + elimination on rank k mod world, outcome "
+                                           "broadcast (3*2n+1 doubles) on the batch's own process group"
+                                           if bcfg.OWNER_RANK_REDUCTION else "reduction replicated on every rank"),
+                     "process_groups_for_batches_in_flight": max(concurrent) if concurrent else 0}
     if rank == 0:
         value = args.steps / dt
         out = {
@@ -341,7 +354,10 @@ def main():
             "value_concurrent2": concurrent[2]["value"] if 2 in concurrent else None,
             "value_concurrent3": concurrent[3]["value"] if 3 in concurrent else None,
             "value_concurrent4": concurrent[4]["value"] if 4 in concurrent else None,
+            "value_concurrent8": concurrent[8]["value"] if 8 in concurrent else None,
             "concurrent": [concurrent[k] for k in sorted(concurrent)] or None,
+            # proof of the N-rank run for the driver's SCALE record: the process group this line was measured on
+            "rccl": rccl_info,
             "roofline": {
                 # The contract's vocabulary is hbm | mfma.  On gfx950 the f64 matrix instructions and the fp64 VALU share ONE
                 # pipe per SIMD (16 lanes x 1 op per cycle; profiles/r02_l_microbench_mfma_f64_4x4x4.txt), and this kernel
