@@ -132,7 +132,9 @@ class Plan:
                 raise NotImplementedError("objective row: single process, stationary kernels only")
         # class sums need rounds that are plain block sums of a structured kernel and keep exactly half of the sets
         # (SOBER's first count of the ragged remainder, SOBER/_rchq.py:127-135, rides along as one more irregular chunk)
-        classes = cfg.CLASS_SUMS and not opaque and warp != "wsabim"
+        # and WSABI-M's squared covariance as one more per-pair block sum -- its likelihood-noise cross terms, which sit on
+        # one Nystrom row per candidate, are evaluated per round: FusedSums.wsabim_class_round)
+        classes = cfg.CLASS_SUMS and not opaque
         # descriptor-driven rounds: the same restriction + the ops must provide the *_geo entries; a trace that
         # synchronises per phase (host timers, per-round tensors) needs the round-by-round loop
         traced_sync = trace is not None and (trace.host_sync or trace.keep_tensors)
@@ -605,7 +607,7 @@ class Batch:
                 self._retry_msg = None
             else:
                 msg, Mc, C_cur, reg_blocks = self.sums.message(geo, S_r, final, pre)
-                if plan.warp == "wsabim":
+                if plan.warp == "wsabim" and Mc is None:         # (a class round has added the term to its class messages)
                     # + U @ (0.5 sum mu cov^2): the one term of wsabim_kernel that is not linear in the block sums
                     with _Timer(ops, trace, "wsabim_sq"):
                         E = self.sums.wsabim_square_term(geo, S_r)
@@ -958,7 +960,14 @@ class FusedSums:
             with _Timer(ops, trace, "project"):
                 ops.project_chunks(b.U_ext, b.q_ext, b.m_ext, Xirr, totirr, self.n_extra, S_r, b.kscale,
                                    out=Mc[C_cur:C_cur + self.n_extra])
-                msg = ops.sum_parts(Mc) if sum_here else Mc
+                if b.plan.warp == "wsabim":
+                    with _Timer(ops, trace, "wsabim_sq"):
+                        noise_part = self.wsabim_class_round(geo, S_r, Mc, C_cur, reg_blocks, fresh=False)
+                    msg = ops.sum_parts(Mc)
+                    if noise_part is not None:
+                        msg += noise_part
+                else:
+                    msg = ops.sum_parts(Mc) if sum_here else Mc
             return msg, Mc, C_cur, reg_blocks
         with _Timer(ops, trace, "blocksum"):
             if pre is not None:
@@ -969,13 +978,78 @@ class FusedSums:
             # start of an epoch: one message per residue class; the [m, S] partials are not needed again
             with _Timer(ops, trace, "project"):
                 Mc = ops.project_chunks(b.U_ext, b.q_ext, b.m_ext, Xpart, totpart, n_chunks, S_r, b.kscale)
-                msg = ops.sum_parts(Mc) if sum_here else Mc
+                if b.plan.warp == "wsabim":
+                    with _Timer(ops, trace, "wsabim_sq"):
+                        noise_part = self.wsabim_class_round(geo, S_r, Mc, C_cur, reg_blocks, fresh=True)
+                    msg = ops.sum_parts(Mc)
+                    if noise_part is not None:
+                        msg += noise_part
+                else:
+                    msg = ops.sum_parts(Mc) if sum_here else Mc
             return msg, Mc, C_cur, reg_blocks
         # (SOBER/_rchq.py:127-135 -- the remainder's kernel columns also go to sets 0..N_rest-1, no weight added -- is one more
         # chunk of ``evaluate``'s result)
         with _Timer(ops, trace, "project"):
             msg = ops.project(b.U_ext, b.q_ext, b.m_ext, Xpart, totpart, n_chunks, S_r, b.kscale)
         return msg, None, 1, 0
+
+    def _kobs_live(self):
+        """``outputscale * k(Xobs, x_p)`` of this rank's live candidates -> ``[n_obs4, Rl]`` (rows beyond n_obs zero)."""
+        b, ops = self.b, self.b.ops
+        n4, Rl = b.bmatT.shape[0], max(b.Rl, 1)
+        kobs = ops.zeros(n4, Rl) if n4 != b.n_obs else ops.empty(n4, Rl)
+        if b.Rl:
+            ops.gram_into(b.spec, b.nys_ext[b.m:b.m + b.n_obs], b.n_obs, b.cand, b.Rl, kobs)   # rows m.. of nys_ext = packed observations
+        return kobs
+
+    def wsabim_class_round(self, geo, S, Mc, C_cur, reg_blocks, fresh):
+        """WSABI-M's ``0.5 cov^2`` (``_wsabi.py:240-242``) in a round whose block sums are kept per residue class.
+
+        ``0.5 (c + noise [j == kappa])^2 = 0.5 c^2 + [j == kappa] (noise c + 0.5 noise^2)``, c = the noise-free posterior
+        covariance.  The first term is a per-pair block sum like the kernel itself: per class at the start of an epoch
+        (``fresh``; ``basq_blocksum_sq_f64`` in class mode), projected and ADDED to the class messages ``Mc`` -- from then on it
+        is regrouped with them, and only the candidates outside the regular region are evaluated again.  The bracket sits on
+        ONE Nystrom row per candidate -- the row of its position inside its block, which changes every round -- so it is
+        evaluated every round (``basq_cov_diag_f64``, one thread per candidate) -> the returned ``[rows, S]`` part of the
+        message (None without noise)."""
+        b, ops = self.b, self.b.ops
+        m, q, Rl, off, n_obs = b.m, b.q, b.Rl, b.off, b.n_obs
+        kobs = self._kobs_live()
+        reg_hi = min(max(reg_blocks * S - off, 0), Rl)           # local end of the regular region
+        n_slots = (C_cur if fresh else 0) + self.n_extra
+        Epart = ops.empty(n_slots, m, S)
+        k = 0
+        if fresh:
+            ops.blocksum_sq(b.spec, b.nys_ext, m, b.cand, b.mu, reg_hi, off, geo.n_full, S, C_cur, b.bmatT, kobs, n_obs, 0.0,
+                            class_mod=C_cur, class0=0, out=Epart[:C_cur])
+            k = C_cur
+        ops.blocksum_sq(b.spec, b.nys_ext, m, b.cand[reg_hi:], b.mu[reg_hi:], Rl - reg_hi, off + reg_hi, geo.n_full, S, 1,
+                        b.bmatT, kobs[:, reg_hi:], n_obs, 0.0, out=Epart[k:k + 1])
+        t0l = min(max(geo.n_full - off, 0), Rl)                  # first local remainder position
+        if self.n_extra == 2:                                    # SOBER's first count of the remainder: point k in set k
+            ops.blocksum_sq(b.spec, b.nys_ext, m, b.cand[t0l:], b.mu[t0l:], Rl - t0l, off + t0l - geo.n_full, S, S, 1,
+                            b.bmatT, kobs[:, t0l:], n_obs, 0.0, out=Epart[k + 1:k + 2])
+        Me = ops.project_chunks(b.U, q, m, Epart, ops.zeros(n_slots, S), n_slots, S, 1.0)
+        slots = Mc[:C_cur + self.n_extra] if fresh else Mc[C_cur:C_cur + self.n_extra]
+        slots[:, 1:q + 1] += Me[:, 1:q + 1]
+        if b.diag_noise == 0.0:
+            return None
+        val = ops.cov_diag(b.spec, b.nys_ext, m, b.cand, Rl, off, geo.n_full, S, b.bmatT, kobs, n_obs, b.diag_noise)
+        part = ops.zeros(Mc.shape[1], S)
+        if t0l > 0:                                              # full blocks: candidate in set s meets the noise on row s
+            dvec = ops.zeros(1, S)
+            ops.dense_blocksum(val[:t0l].unsqueeze(0), b.mu[:t0l], off, geo.n_full, S, 1.0, dvec)
+            nd = min(m, S)
+            part[1:q + 1, :nd] = b.U[:, :nd] * dvec[0, :nd]
+        if Rl > t0l:                                             # remainder: point k meets it on row k; all of it is in set S-1
+            k0 = off + t0l - geo.n_full
+            k1 = min(k0 + (Rl - t0l), m)
+            if k1 > k0:
+                dt = b.mu[t0l:t0l + (k1 - k0)] * val[t0l:t0l + (k1 - k0)]
+                part[1:q + 1, S - 1] += b.U[:, k0:k1] @ dt
+                if self.n_extra == 2:                            # ... and, SOBER, once more in set k
+                    part[1:q + 1, k0:k1] += b.U[:, k0:k1] * dt
+        return part
 
     def wsabim_square_term(self, geo, S, tail_as_block=False):
         """E[j, s] = 0.5 * sum_{p in set s} mu_p * cov(pt_j, x_p)^2  with cov = k - K(pt,X) W K(X, x)  (_wsabi.py:240).

@@ -62,8 +62,9 @@ SIGNATURES = {
                                                 _i32, _vp, _vp, _vp, _vp, _vp]),
     "basq_init_state_f64": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
     "basq_dense_blocksum_f64": (C.c_int, [_vp, _i32, _i64, _i64, _vp, _i64, _i64, _i32, _f64, _i32, _vp, _vp, _vp]),
-    "basq_blocksum_sq_f64": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _i32,
-                                       _f64, _vp, _vp]),
+    "basq_blocksum_sq_f64": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp,
+                                       _i64, _i32, _f64, _vp, _vp]),
+    "basq_cov_diag_f64": (C.c_int, [_vp, _vp, _i32, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _f64, _vp, _vp]),
     "basq_box_muller_f64": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "basq_chol_inv_f64": (C.c_int, [_vp, _i32, _vp, _vp, _f64, _vp]),
     "basq_chol_factor_f64": (C.c_int, [_vp, _i32, _vp, _f64, _vp]),

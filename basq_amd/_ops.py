@@ -421,20 +421,37 @@ class HipOps:
                                                float(scale), 1 if square else 0, _ptr(E), _ptr(tot), self._stream()),
               "basq_dense_blocksum_f64")
 
-    def blocksum_sq(self, spec, nys, m, cand, mu, Rl, off, n_full, S, n_chunks, bmatT, kobs, n_obs, noise):
+    def blocksum_sq(self, spec, nys, m, cand, mu, Rl, off, n_full, S, n_chunks, bmatT, kobs, n_obs, noise, class_mod=0,
+                    class0=0, out=None):
         """WSABI-M's squared-covariance block sums, fused (``basq_blocksum_sq_f64``) -> ``Epart [n_chunks, m, S]``.
 
-        ``bmatT [n_obs4, >= m padded to 64]``, ``kobs [n_obs4, >= Rl]`` (zero rows beyond ``n_obs``)."""
+        ``bmatT [n_obs4, >= m padded to 64]``, ``kobs [n_obs4, >= Rl]`` (zero rows beyond ``n_obs``).  ``class_mod > 0``: chunk
+        c = the blocks ``b % class_mod == class0 + c`` (full blocks only), as for ``blocksum``."""
         self._chk(bmatT)
-        self._chk(kobs)
-        Epart = self.empty(n_chunks, m, S)
+        if kobs.dtype != torch.float64 or kobs.stride(1) != 1:  # (a column-offset view of a wider buffer is fine)
+            raise ValueError("expected a float64 matrix with unit column stride")
+        Epart = self.empty(n_chunks, m, S) if out is None else out
+        assert Epart.is_contiguous() and tuple(Epart.shape) == (n_chunks, m, S)
         if Rl == 0:
             return Epart.zero_()
         sc = self.spec_c(spec)
         check(self.lib.basq_blocksum_sq_f64(C.byref(sc), _ptr(nys), m, _ptr(cand), _ptr(mu), Rl, off, n_full, S, n_chunks,
-                                            _ptr(bmatT), bmatT.stride(0), _ptr(kobs), kobs.stride(0), int(n_obs),
-                                            float(noise), _ptr(Epart), self._stream()), "basq_blocksum_sq_f64")
+                                            int(class_mod), int(class0), _ptr(bmatT), bmatT.stride(0), _ptr(kobs),
+                                            kobs.stride(0), int(n_obs), float(noise), _ptr(Epart), self._stream()),
+              "basq_blocksum_sq_f64")
         return Epart
+
+    def cov_diag(self, spec, nys, m, cand, Rl, off, n_full, S, bmatT, kobs, n_obs, noise):
+        """``out[p] = noise * cov(nys_kappa(p), x_p) + noise^2 / 2`` for the Rl local candidates (``basq_cov_diag_f64``):
+        the noise cross terms of WSABI-M's squared covariance, which sit on one Nystrom row per candidate."""
+        out = self.empty(max(Rl, 1))
+        if Rl == 0:
+            return out.zero_()
+        sc = self.spec_c(spec)
+        check(self.lib.basq_cov_diag_f64(C.byref(sc), _ptr(nys), m, _ptr(cand), Rl, off, n_full, S, _ptr(bmatT),
+                                         bmatT.stride(0), _ptr(kobs), kobs.stride(0), int(n_obs), float(noise), _ptr(out),
+                                         self._stream()), "basq_cov_diag_f64")
+        return out
 
     def gram_into(self, spec, packA, na, packB, nb, out):
         """``out[:na, :nb] = outputscale * k(A, B)`` for a caller-provided row-major buffer (row stride ``out.stride(0)``)."""

@@ -770,20 +770,30 @@ __global__ void __launch_bounds__(256) blocksum_sq_kernel(const BlocksumArgs A, 
     const int jrow = j0 + g;
     const bool col_ok = (s0 + c) < A.S;
     const long long lim = (A.off + A.Rl < A.n_full) ? (A.off + A.Rl) : A.n_full;
-    long long bA = A.blk_lo + (long long)chunk * A.blk_per_chunk;
-    long long bB = bA + A.blk_per_chunk;
-    if (bB > A.blk_hi) bB = A.blk_hi;
+    // blocks of this chunk: a contiguous range, or -- residue-class mode, as in blocksum_kernel -- every class_mod-th block
+    long long bA, bB, bstep;
+    if (A.class_mod > 0) {
+        bstep = A.class_mod;
+        const long long cls = A.class0 + chunk;
+        bA = A.blk_lo + ((cls - A.blk_lo % bstep) % bstep + bstep) % bstep;
+        bB = A.blk_hi;
+    } else {
+        bstep = 1;
+        bA = A.blk_lo + (long long)chunk * A.blk_per_chunk;
+        bB = bA + A.blk_per_chunk;
+        if (bB > A.blk_hi) bB = A.blk_hi;
+    }
     // candidate of this lane's column in block i (weight mu / 2, zero when the position is not held here)
     auto frag = [&](CandFrag<KK>& f, long long pl, bool ok) -> long long {
         load_cand<KK>(f, A, pl, ok, g);
         f.w = 0.5 * f.wm;
         return ok ? pl : 0;
     };
-    for (long long i = bA; i < bB; i += 2) {
-        const long long pg0 = i * A.S + s0 + c, pg1 = pg0 + A.S;
+    for (long long i = bA; i < bB; i += 2 * bstep) {
+        const long long pg0 = i * A.S + s0 + c, pg1 = pg0 + bstep * A.S;
         CandFrag<KK> f0, f1;
         const long long r0 = frag(f0, pg0 - A.off, col_ok && pg0 >= A.off && pg0 < lim);
-        const long long r1 = frag(f1, pg1 - A.off, col_ok && (i + 1 < bB) && pg1 >= A.off && pg1 < lim);
+        const long long r1 = frag(f1, pg1 - A.off, col_ok && (i + bstep < bB) && pg1 >= A.off && pg1 < lim);
         // the noise sits on Nystrom row kappa = position inside the block = set index of the column
         sq_pair_accumulate<KK, FAM, JT>(a, f0, f1, r0, r1, s0 + c, s0 + c, jrow, ap, g, Q, acc, ek, exp_tab);
     }
@@ -3889,6 +3899,36 @@ __global__ void __launch_bounds__(1024) dense_blocksum_pairs_kernel(const double
     }
 }
 
+// The likelihood noise inside WSABI-M's squared covariance, per candidate (BASQ/_gp.py:275-276 under _wsabi.py:240-242):
+// predictive_covariance adds the noise to entry [kappa][kappa] of every kernel block -- candidate p meets it on the Nystrom
+// row kappa = its position inside its block (p % S below n_full, p - n_full in the ragged remainder) -- so
+//     0.5 (c + noise)^2 = 0.5 c^2 + (noise c + 0.5 noise^2)      on that one row,     c = cov(nys_kappa, x_p) without noise.
+// The first term is a plain per-pair block sum (basq_blocksum_sq_f64 with noise = 0: it regroups over the rounds of an epoch
+// like every other block sum); this kernel evaluates the bracket, one thread per candidate (0 where kappa >= m):
+//     out[p] = noise * (outputscale k(nys_kappa, x_p) - sum_o bmatT[o][kappa] kobs[o][p]) + 0.5 noise^2
+template <int FAM>
+__global__ void cov_diag_kernel(const double* __restrict__ nys, int kp, int m, const double* __restrict__ cand,
+                                long long Rl, long long off, long long n_full, int S, const double* __restrict__ bmatT,
+                                long long ldb, const double* __restrict__ kobs, long long ldk, int n_obs,
+                                double outputscale, double noise, double* __restrict__ out) {
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= Rl) return;
+    const long long pg = off + p;
+    const long long kappa = (pg < n_full) ? (pg % S) : (pg - n_full);
+    if (kappa >= m) {
+        out[p] = 0.0;
+        return;
+    }
+    const double* a = nys + kappa * kp;
+    const double* b = cand + p * kp;
+    double D = 0.0;
+    for (int k = 0; k < kp; ++k) D = __builtin_fma(a[k], b[k], D);
+    double corr = 0.0;
+    for (int o = 0; o < n_obs; ++o) corr = __builtin_fma(bmatT[(long long)o * ldb + kappa], kobs[(long long)o * ldk + p], corr);
+    const double c = __builtin_fma(outputscale, kernel_from_arg<FAM>(D), -corr);
+    out[p] = __builtin_fma(noise, c, 0.5 * noise * noise);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Box-Muller transform of torch's CPU ``normal_fill`` (aten/native/cpu/DistributionTemplates.h): blocks of 16
 // uniforms -> 16 normals (u1 = 1 - u[j], u2 = u[j+8]; r = sqrt(-2 log u1), t = 2 pi u2; out[j] = r cos t,
@@ -4058,19 +4098,46 @@ int basq_blocksum_f64(const basq_kernel_spec* spec, const double* nys, int32_t m
                          stream, blocksum_exp_scheme(spec));
 }
 
+int basq_cov_diag_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand, int64_t Rl,
+                      int64_t off, int64_t n_full, int32_t S, const double* bmatT, int64_t ldb, const double* kobs,
+                      int64_t ldk, int32_t n_obs, double noise, double* out, void* stream) {
+    if (!spec_ok(spec) || !nys || !cand || !bmatT || !kobs || !out) return BASQ_EINVAL;
+    if (m < 1 || Rl < 0 || off < 0 || n_full < 0 || S < 1 || n_obs < 1 || n_full % S != 0 || ldb < m || ldk < Rl)
+        return BASQ_EINVAL;
+    if (Rl == 0) return BASQ_OK;
+    const int kp = basq_kp(spec->d);
+    const dim3 grid((unsigned)((Rl + 255) / 256)), block(256);
+#define BASQ_COV_DIAG(FAM)                                                                                              \
+    hipLaunchKernelGGL((cov_diag_kernel<FAM>), grid, block, 0, (hipStream_t)stream, nys, kp, m, cand, (long long)Rl,    \
+                       (long long)off, (long long)n_full, S, bmatT, (long long)ldb, kobs, (long long)ldk, n_obs,         \
+                       spec->outputscale, noise, out)
+    switch (spec->family) {
+        case BASQ_FAMILY_RBF: BASQ_COV_DIAG(BASQ_FAMILY_RBF); break;
+        case BASQ_FAMILY_MATERN52: BASQ_COV_DIAG(BASQ_FAMILY_MATERN52); break;
+        case BASQ_FAMILY_MATERN32: BASQ_COV_DIAG(BASQ_FAMILY_MATERN32); break;
+        default: return BASQ_EUNSUPPORTED;
+    }
+#undef BASQ_COV_DIAG
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
 int basq_blocksum_sq_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
                          const double* mu, int64_t Rl, int64_t off, int64_t n_full, int32_t S, int32_t n_chunks,
+                         int32_t class_mod, int32_t class0,
                          const double* bmatT, int64_t ldb, const double* kobs, int64_t ldk, int32_t n_obs, double noise,
                          double* Epart, void* stream) {
     if (!spec_ok(spec) || !nys || !cand || !mu || !bmatT || !kobs || !Epart) return BASQ_EINVAL;
     if (m < 1 || Rl < 1 || off < 0 || n_full < 0 || S < 1 || n_chunks < 1 || n_obs < 1) return BASQ_EINVAL;
     if (n_full % S != 0) return BASQ_EINVAL;
+    if (class_mod < 0 || class0 < 0 || (class_mod > 0 && class0 + n_chunks > class_mod)) return BASQ_EINVAL;
+    if (class_mod > 0 && off + Rl > n_full) return BASQ_EINVAL;   // residue classes cover full blocks only
     const int jt = BASQ_JT_FOR(basq_kp(spec->d) / 4);
     if (ldb < (((int64_t)m + 16 * jt - 1) / (16 * jt)) * (16 * jt) || ldk < Rl) return BASQ_EINVAL;   // fragment reads stay inside
     BlocksumArgs A;
     A.nys = nys; A.cand = cand; A.mu = mu; A.wx = nullptr; A.Xpart = Epart; A.totpart = nullptr;
     A.Rl = Rl; A.off = off; A.n_full = n_full; A.m = m; A.S = S; A.n_chunks = n_chunks;
-    A.class_mod = 0; A.class0 = 0;
+    A.class_mod = class_mod; A.class0 = class0;
     A.geo = nullptr; A.geo_mode = 0;
     A.n_stiles = (S + 15) / 16;
     const long long lim = (off + Rl < n_full) ? (off + Rl) : n_full;

@@ -327,11 +327,28 @@ int basq_dense_blocksum_f64(const double* C, int32_t m, int64_t nc, int64_t ldc,
  * ldb >= m rounded up to 64, the extra columns zero; ldk >= Rl.  nys / cand / mu / Rl / off / n_full / S / n_chunks as
  * for basq_blocksum_f64 (contiguous chunks).  No [m, candidates] matrix is formed; replaces the dense
  * covariance chunks + library GEMM + basq_dense_blocksum_f64(square = 1) of the unfused path.
+ * class_mod / class0: residue classes of the block index as for basq_blocksum_f64 (the squared term is a per-pair block sum
+ * like any other: with noise = 0 its class sums regroup over the rounds of an epoch, basq_regroup_classes_f64; the noise
+ * cross terms, which sit on ONE Nystrom row per candidate, then come from basq_cov_diag_f64).
  */
 int basq_blocksum_sq_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
                          const double* mu, int64_t Rl, int64_t off, int64_t n_full, int32_t S, int32_t n_chunks,
+                         int32_t class_mod, int32_t class0,
                          const double* bmatT, int64_t ldb, const double* kobs, int64_t ldk, int32_t n_obs, double noise,
                          double* Epart, void* stream);
+
+/*
+ * The likelihood noise INSIDE WSABI-M's squared covariance (BASQ/_gp.py:275-276 under BASQ/_wsabi.py:240-242), per candidate:
+ * predictive_covariance adds the noise to entry [kappa][kappa] of every kernel block, and candidate p meets it on ONE Nystrom
+ * row, kappa = p % S below n_full, p - n_full in the ragged remainder.  0.5 (c + noise)^2 = 0.5 c^2 + (noise c + 0.5 noise^2):
+ *     out[p] = noise * cov(nys_kappa, y_p) + 0.5 noise^2     (cov without noise, operands as for basq_blocksum_sq_f64;
+ *                                                              0 where kappa >= m)
+ * for the Rl local candidates (positions off ..).  The caller sums mu[p] * out[p] per set (basq_dense_blocksum_f64 on the
+ * [1, Rl] row) and adds U[:, kappa] times it to the round's message.
+ */
+int basq_cov_diag_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand, int64_t Rl,
+                      int64_t off, int64_t n_full, int32_t S, const double* bmatT, int64_t ldb, const double* kobs,
+                      int64_t ldk, int32_t n_obs, double noise, double* out, void* stream);
 
 /*
  * Gaussian test matrix of torch.svd_lowrank (BASQ/_rchq.py:29 -> torch._lowrank: R = torch.randn(m, q)): the

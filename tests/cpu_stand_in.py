@@ -390,10 +390,12 @@ class CpuStandInOps:
         out[:na, :nb] = self.gram(spec, packA, na, packB, nb)
         return out
 
-    def blocksum_sq(self, spec, nys, m, cand, mu, Rl, off, n_full, S, n_chunks, bmatT, kobs, n_obs, noise):
-        """E[j, s] = sum_p (mu_p / 2) cov(j, p)^2, cov = s2 k - B ko (+ noise on entry [kappa][kappa] of each block)."""
+    def blocksum_sq(self, spec, nys, m, cand, mu, Rl, off, n_full, S, n_chunks, bmatT, kobs, n_obs, noise, class_mod=0,
+                    class0=0, out=None):
+        """E[j, s] = sum_p (mu_p / 2) cov(j, p)^2, cov = s2 k - B ko (+ noise on entry [kappa][kappa] of each block).
+        ``class_mod > 0``: chunk c = the blocks b with b % class_mod == class0 + c; otherwise everything lands in chunk 0."""
         self._count("blocksum_sq")
-        Epart = torch.zeros(n_chunks, m, S, dtype=torch.float64)
+        Epart = torch.zeros(n_chunks, m, S, dtype=torch.float64) if out is None else out.zero_()
         if Rl == 0:
             return Epart
         step = max(S, (1 << 22) // max(m, 1))
@@ -406,8 +408,31 @@ class CpuStandInOps:
                 hit = kappa < m
                 cov[kappa[hit], torch.arange(nc)[hit]] += noise
             sets = torch.where(pg < n_full, pg % S, torch.full_like(pg, S - 1))
-            Epart[0].index_add_(1, sets, 0.5 * (cov * cov) * mu[p0:p0 + nc].unsqueeze(0))
+            vals = 0.5 * (cov * cov) * mu[p0:p0 + nc].unsqueeze(0)
+            if class_mod > 0:
+                cls = (pg // S) % class_mod - class0
+                for c in range(n_chunks):
+                    sel = cls == c
+                    Epart[c].index_add_(1, sets[sel], vals[:, sel])
+            else:
+                Epart[0].index_add_(1, sets, vals)
         return Epart
+
+    def cov_diag(self, spec, nys, m, cand, Rl, off, n_full, S, bmatT, kobs, n_obs, noise):
+        """out[p] = noise * cov(nys_kappa(p), x_p) + noise^2 / 2 (0 where kappa >= m): see basq_cov_diag_f64."""
+        self._count("cov_diag")
+        out = torch.zeros(max(Rl, 1), dtype=torch.float64)
+        if Rl == 0:
+            return out
+        pg = off + torch.arange(Rl)
+        kappa = torch.where(pg < n_full, pg % S, pg - n_full)
+        hit = kappa < m
+        kp = nys.shape[1]
+        D = (nys[kappa[hit], :kp] * cand[:Rl][hit, :kp]).sum(1)
+        kval = spec.outputscale * self._kfun(spec, D)
+        corr = (bmatT[:n_obs][:, kappa[hit]] * kobs[:n_obs, :Rl][:, hit]).sum(0)
+        out[:Rl][hit] = noise * (kval - corr) + 0.5 * noise * noise
+        return out
 
     def box_muller(self, u, u_tail=None):
         def bm(v):

@@ -373,6 +373,50 @@ def test_blocksum_sq_vs_standin(hip_ops, family, d, m, n_obs, Rl, off, n_full, S
     assert (Eg - Ec).abs().max().item() <= 2e-12 * Ec.abs().max().item()
 
 
+@pytest.mark.parametrize("family,d,m,n_obs,nb,S,C,off_blocks,noise", [
+    ("rbf", 10, 300, 202, 64, 200, 16, 0, 1e-3),               # an epoch start: 16 classes of a 64-block region
+    ("matern52", 6, 130, 61, 37, 50, 8, 3, 1e-2),               # a shard that starts at block 3; blocks not a multiple of C
+    ("rbf", 4, 70, 50, 9, 30, 2, 0, 0.0),                       # C = 2, odd block count
+])
+def test_blocksum_sq_classes_and_cov_diag_vs_standin(hip_ops, family, d, m, n_obs, nb, S, C, off_blocks, noise):
+    """Round 4: WSABI-M's squared covariance per residue class (``basq_blocksum_sq_f64`` with class_mod: chunk c = the blocks
+    b = c mod C) and the per-candidate noise cross terms (``basq_cov_diag_f64``) against the stand-in; the class sums add up to
+    the contiguous-chunk result of the same range."""
+    cpu = CpuStandInOps()
+    spec = _spec(family, d)
+    Rl, off = nb * S, off_blocks * S
+    n_full = off + Rl
+    nys, obs, cand = _rand(m, d, 61), _rand(n_obs, d, 62), _rand(Rl, d, 63)
+    center = nys.mean(0)
+    g = torch.Generator().manual_seed(9)
+    mu = torch.rand(Rl, generator=g, dtype=torch.float64) + 0.05
+    Bm = 0.1 * _rand(m, n_obs, 64)
+    n4, mp = (n_obs + 3) // 4 * 4, (m + 63) // 64 * 64
+
+    def run(ops):
+        pa = ops.pack(spec, ops.to_device(torch.cat([nys, obs], 0)), ops.to_device(center), 0, pad_rows_to=64)
+        pb = ops.pack(spec, ops.to_device(cand), ops.to_device(center), 1)
+        bT = ops.zeros(n4, mp)
+        bT[:n_obs, :m] = ops.to_device(Bm).t()
+        kobs = ops.zeros(n4, Rl)
+        ops.gram_into(spec, pa[m:m + n_obs], n_obs, pb, Rl, kobs)
+        mud = ops.to_device(mu)
+        Ecls = ops.blocksum_sq(spec, pa, m, pb, mud, Rl, off, n_full, S, C, bT, kobs, n_obs, 0.0, class_mod=C, class0=0)
+        Eall = ops.blocksum_sq(spec, pa, m, pb, mud, Rl, off, n_full, S, 1, bT, kobs, n_obs, 0.0)
+        val = ops.cov_diag(spec, pa, m, pb, Rl + 0, off, n_full, S, bT, kobs, n_obs, noise if noise else 1e-3)
+        # a shard that ends inside the ragged remainder: the last S - 3 candidates renumbered as remainder points 0..
+        tail = ops.cov_diag(spec, pa, m, pb[Rl - (S - 3):], S - 3, n_full, n_full, S, bT, kobs[:, Rl - (S - 3):], n_obs, 1e-3)
+        return Ecls, Eall, val, tail
+
+    Ec, Eca, vc, tc = run(cpu)
+    Eg, Ega, vg, tg = (t.cpu() for t in run(hip_ops))
+    scale = Eca.abs().max().item()
+    assert (Eg - Ec).abs().max().item() <= 2e-12 * scale
+    assert (Eg.sum(0) - Ega[0]).abs().max().item() <= 1e-11 * scale       # the classes tile the range
+    assert (vg[:Rl] - vc[:Rl]).abs().max().item() <= 1e-12 * vc.abs().max().item()
+    assert (tg[:S - 3] - tc[:S - 3]).abs().max().item() <= 1e-12 * tc.abs().max().item()
+
+
 def test_quadrature_step_vs_oracle(hip_ops):
     """EZy = w . mean_predict(X), VarZy = w^T K(X, X) w with the structured kernels' own mean
     (BASQ/_quadrature.py:53-64), against the oracle's CPU kernels."""
