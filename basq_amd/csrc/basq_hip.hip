@@ -4602,6 +4602,8 @@ int basq_dense_blocksum_f64(const double* C, int32_t m, int64_t nc, int64_t ldc,
             if (half * cand_ns > 1024 || waves > 256LL * 20 || (long long)cand_ns * 2 > nblocks) break;
             NS = cand_ns;
         }
+        static const int ns_env = [] { const char* e = getenv("BASQ_DBS_NS"); return e ? atoi(e) : 0; }();   // A/B knob
+        if (ns_env > 0 && half * ns_env <= 1024 && (long long)ns_env * 2 <= nblocks) NS = ns_env;
         const int nthr = half * NS;
         size_t lds = (NS > 1) ? (size_t)NS * (JR8 + 1) * S * sizeof(double) : 0;
         const size_t lds_tail = (size_t)((nthr + 63) / 64) * (JR8 + 1) * sizeof(double);
