@@ -409,6 +409,17 @@ def make_cov_psd(A, max_iter: int = 10):
     A = torch.sqrt(torch.nan_to_num(A) * torch.nan_to_num(A).T)
 
     def psd(M_):
+        # Screening (round 4; the spectrum of a 500 x 500 Gram costs 10.8 ms on the GPU, 0.4 s on the host, against 6.7 ms for the
+        # whole batch: profiles/r06_c_sober_phases.txt): if M - tau I has a Cholesky factor, every eigenvalue of M is >= tau,
+        # three orders above what a computed spectrum can be off by (~1e-13 trace) -- both of the reference's tests pass,
+        # and neither needs to be run.  Only a matrix that fails the screening takes the reference's sequence below.
+        n = M_.shape[0]
+        if n > 0:
+            tau = (1e-10 * n ** 0.5) * torch.diagonal(M_).mean()             # (a device scalar: no read-back for it)
+            shifted = M_.clone()
+            shifted.diagonal().sub_(tau)
+            if int(torch.linalg.cholesky_ex(shifted).info.item()) == 0:
+                return True
         if int(torch.linalg.cholesky_ex(M_).info.item()) != 0:
             return False
         if M_.shape[0] > cfg.PSD_EIG_MAX_M:
