@@ -3760,8 +3760,19 @@ __global__ void __launch_bounds__(256) dense_blocksum_kernel(const double* __res
 // and added wave by wave: every sum has a fixed order.  Needs S even and an even first position (the engine cuts its
 // chunks that way); everything else takes the kernel above.
 struct __attribute__((aligned(8))) DPair { double x, y; };
+// The kernel values are read exactly once: a non-temporal 16-byte load (no L2 allocation) when the host asks for it
+// (BASQ_DBS_NT, A/B knob) -- the block sums E, which every chunk reads and writes back, then keep the cache.
+typedef double DVec2 __attribute__((ext_vector_type(2)));
+template <bool NT>
+__device__ __forceinline__ DPair load_pair(const double* p) {
+    if (NT) {
+        const DVec2 v = __builtin_nontemporal_load(reinterpret_cast<const DVec2*>(p));
+        return DPair{v.x, v.y};
+    }
+    return *reinterpret_cast<const DPair*>(p);
+}
 
-template <int JR, bool SQ>
+template <int JR, bool SQ, bool NT>
 __global__ void __launch_bounds__(1024) dense_blocksum_pairs_kernel(const double* __restrict__ C, int m, long long nc,
                                                                     long long ldc, const double* __restrict__ mu,
                                                                     long long pg0, long long n_full, int S, int NS,
@@ -3790,8 +3801,8 @@ __global__ void __launch_bounds__(1024) dense_blocksum_pairs_kernel(const double
         DPair c0[JR], c1[JR];
 #pragma unroll
         for (int jr = 0; jr < JR; ++jr) {
-            c0[jr] = *reinterpret_cast<const DPair*>(rows[jr] + o);
-            c1[jr] = *reinterpret_cast<const DPair*>(rows[jr] + o + step);
+            c0[jr] = load_pair<NT>(rows[jr] + o);
+            c1[jr] = load_pair<NT>(rows[jr] + o + step);
         }
 #pragma unroll
         for (int jr = 0; jr < JR; ++jr) {
@@ -3806,7 +3817,7 @@ __global__ void __launch_bounds__(1024) dense_blocksum_pairs_kernel(const double
         wa0 += w0.x; wa1 += w0.y;
 #pragma unroll
         for (int jr = 0; jr < JR; ++jr) {
-            const DPair c = *reinterpret_cast<const DPair*>(rows[jr] + o);
+            const DPair c = load_pair<NT>(rows[jr] + o);
             a0[jr] = __builtin_fma(SQ ? w0.x * c.x : w0.x, c.x, a0[jr]);
             a1[jr] = __builtin_fma(SQ ? w0.y * c.y : w0.y, c.y, a1[jr]);
         }
@@ -4610,17 +4621,22 @@ int basq_dense_blocksum_f64(const double* C, int32_t m, int64_t nc, int64_t ldc,
         if (lds < lds_tail) lds = lds_tail;
         if (nthr <= 1024 && lds <= 160 * 1024 - 512) {
             const dim3 grid8((unsigned)grid_n), block8((unsigned)nthr);
-            const void* fn = square ? (const void*)dense_blocksum_pairs_kernel<JR8, true>
-                                    : (const void*)dense_blocksum_pairs_kernel<JR8, false>;
+            static const int nt_env = [] { const char* e = getenv("BASQ_DBS_NT"); return e ? atoi(e) : 0; }();   // A/B knob
+            // non-temporal 16-byte loads need 16-byte aligned pairs: even row stride, aligned base
+            const bool nt = nt_env != 0 && ldc % 2 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+            const void* fn = square ? (nt ? (const void*)dense_blocksum_pairs_kernel<JR8, true, true>
+                                          : (const void*)dense_blocksum_pairs_kernel<JR8, true, false>)
+                                    : (nt ? (const void*)dense_blocksum_pairs_kernel<JR8, false, true>
+                                          : (const void*)dense_blocksum_pairs_kernel<JR8, false, false>);
             if (lds > 64 * 1024 &&
                 hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return BASQ_ELAUNCH;
-            if (square)
-                hipLaunchKernelGGL((dense_blocksum_pairs_kernel<JR8, true>), grid8, block8, lds, (hipStream_t)stream, C, m,
-                                   (long long)nc, (long long)ldc, mu, (long long)pg0, (long long)n_full, S, NS, scale, E, tot);
-            else
-                hipLaunchKernelGGL((dense_blocksum_pairs_kernel<JR8, false>), grid8, block8, lds, (hipStream_t)stream, C, m,
-                                   (long long)nc, (long long)ldc, mu, (long long)pg0, (long long)n_full, S, NS, scale, E, tot);
+#define BASQ_DBS_LAUNCH(SQv, NTv)                                                                                         \
+    hipLaunchKernelGGL((dense_blocksum_pairs_kernel<JR8, SQv, NTv>), grid8, block8, lds, (hipStream_t)stream, C, m,         \
+                       (long long)nc, (long long)ldc, mu, (long long)pg0, (long long)n_full, S, NS, scale, E, tot)
+            if (square) { if (nt) BASQ_DBS_LAUNCH(true, true); else BASQ_DBS_LAUNCH(true, false); }
+            else { if (nt) BASQ_DBS_LAUNCH(false, true); else BASQ_DBS_LAUNCH(false, false); }
+#undef BASQ_DBS_LAUNCH
             BASQ_CHECK_LAUNCH();
             return BASQ_OK;
         }

@@ -36,6 +36,7 @@ job_ab_idle()     { B=${AB_LIB:-basq_amd/csrc/libbasq_hip_bpf2.so}; for i in 1 2
 job_ab_late()     { timeout -k 10 400 python tools/ab_engine.py LATE_CLASSES 2 3 0 4 5 --reps 8 --visits 3 2>&1 | grep -v amdgpu.ids > "$out/ab_late_classes.txt"; rc=$?; cat "$out/ab_late_classes.txt"; return $rc; }
 job_sober_tut()   { timeout -k 10 600 python tools/bench_sober_tutorial.py > "$out/sober_tutorial.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/sober_tutorial.txt" | cut -c1-330; return $rc; }
 job_dense_sweep() { for S in 400 200; do for ns in 0 1 2 3 4 5; do BASQ_DBS_NS=$ns timeout -k 10 120 python tools/bench_dense_blocksum.py --S $S 2>&1 | grep -v amdgpu.ids >> "$out/dense_sweep.txt" || return 1; done; done; cat "$out/dense_sweep.txt"; }
+job_dense_fresh() { for nt in 0 1; do for fr in "" "--fresh"; do BASQ_DBS_NT=$nt timeout -k 10 120 python tools/bench_dense_blocksum.py --S 400 $fr 2>&1 | grep -v amdgpu.ids >> "$out/dense_fresh.txt" || return 1; done; done; BASQ_DBS_NT=1 timeout -k 10 200 python -m pytest tests/test_kernels_gpu.py -q -k dense_blocksum 2>&1 | tail -1 >> "$out/dense_fresh.txt"; cat "$out/dense_fresh.txt"; }
 job_sober_phases() { timeout -k 10 300 python tools/sober_phases.py > "$out/sober_phases.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/sober_phases.txt" | cut -c1-400; return $rc; }
 job_opaque_cfg4() { timeout -k 10 1100 python tools/bench_opaque_cfg4.py > "$out/opaque_cfg4.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/opaque_cfg4.txt" | cut -c1-250; return $rc; }
 
