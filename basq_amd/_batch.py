@@ -997,7 +997,9 @@ class FusedSums:
         """``outputscale * k(Xobs, x_p)`` of this rank's live candidates -> ``[n_obs4, Rl]`` (rows beyond n_obs zero)."""
         b, ops = self.b, self.b.ops
         n4, Rl = b.bmatT.shape[0], max(b.Rl, 1)
-        kobs = ops.zeros(n4, Rl) if n4 != b.n_obs else ops.empty(n4, Rl)
+        kobs = ops.empty(n4, Rl)
+        if n4 != b.n_obs:
+            kobs[b.n_obs:].zero_()                              # only the padding rows (the fragment loads read whole groups of 4)
         if b.Rl:
             ops.gram_into(b.spec, b.nys_ext[b.m:b.m + b.n_obs], b.n_obs, b.cand, b.Rl, kobs)   # rows m.. of nys_ext = packed observations
         return kobs
@@ -1037,10 +1039,20 @@ class FusedSums:
         val = ops.cov_diag(b.spec, b.nys_ext, m, b.cand, Rl, off, geo.n_full, S, b.bmatT, kobs, n_obs, b.diag_noise)
         part = ops.zeros(Mc.shape[1], S)
         if t0l > 0:                                              # full blocks: candidate in set s meets the noise on row s
-            dvec = ops.zeros(1, S)
-            ops.dense_blocksum(val[:t0l].unsqueeze(0), b.mu[:t0l], off, geo.n_full, S, 1.0, dvec)
+            # dvec[s] = sum of mu_p val_p over the local candidates of set s: the shard's leading partial block, its whole
+            # blocks as one [blocks, S] column sum, its trailing partial block (fixed shapes -> a fixed summation order)
+            wv = b.mu[:t0l] * val[:t0l]
+            dvec = ops.zeros(S)
+            lead = min((-off) % S, t0l)
+            if lead:
+                dvec[off % S:off % S + lead] += wv[:lead]
+            nbk = (t0l - lead) // S
+            if nbk:
+                dvec += wv[lead:lead + nbk * S].view(nbk, S).sum(0)
+            if t0l - lead - nbk * S:
+                dvec[:t0l - lead - nbk * S] += wv[lead + nbk * S:]
             nd = min(m, S)
-            part[1:q + 1, :nd] = b.U[:, :nd] * dvec[0, :nd]
+            part[1:q + 1, :nd] = b.U[:, :nd] * dvec[:nd]
         if Rl > t0l:                                             # remainder: point k meets it on row k; all of it is in set S-1
             k0 = off + t0l - geo.n_full
             k1 = min(k0 + (Rl - t0l), m)
@@ -1074,7 +1086,9 @@ class FusedSums:
         if Rl == 0:
             return ops.zeros(m, S)
         n4 = b.bmatT.shape[0]
-        kobs = ops.zeros(n4, Rl) if n4 != n_obs else ops.empty(n4, Rl)
+        kobs = ops.empty(n4, Rl)
+        if n4 != n_obs:
+            kobs[n_obs:].zero_()
         ops.gram_into(b.spec, b.nys_ext[m:m + n_obs], n_obs, cand, Rl, kobs)   # rows m.. of nys_ext = packed observations
         n_ch = 1 if tail_as_block else choose_chunks(local_blocks(off, Rl, geo), m, S, b.kp // 4)
         Epart = ops.blocksum_sq(b.spec, b.nys_ext, m, cand, mu, Rl, off, n_full, S, n_ch, b.bmatT, kobs, n_obs,
