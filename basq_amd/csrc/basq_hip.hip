@@ -3760,8 +3760,8 @@ __global__ void __launch_bounds__(256) dense_blocksum_kernel(const double* __res
 // and added wave by wave: every sum has a fixed order.  Needs S even and an even first position (the engine cuts its
 // chunks that way); everything else takes the kernel above.
 struct __attribute__((aligned(8))) DPair { double x, y; };
-// The kernel values are read exactly once: a non-temporal 16-byte load (no L2 allocation) when the host asks for it
-// (BASQ_DBS_NT, A/B knob) -- the block sums E, which every chunk reads and writes back, then keep the cache.
+// The kernel values are read exactly once: non-temporal 16-byte loads (no L2 allocation; the default whenever the pairs are
+// 16-byte aligned) -- the block sums E, which every chunk reads and writes back, then keep the cache.
 typedef double DVec2 __attribute__((ext_vector_type(2)));
 template <bool NT>
 __device__ __forceinline__ DPair load_pair(const double* p) {
@@ -4621,7 +4621,10 @@ int basq_dense_blocksum_f64(const double* C, int32_t m, int64_t nc, int64_t ldc,
         if (lds < lds_tail) lds = lds_tail;
         if (nthr <= 1024 && lds <= 160 * 1024 - 512) {
             const dim3 grid8((unsigned)grid_n), block8((unsigned)nthr);
-            static const int nt_env = [] { const char* e = getenv("BASQ_DBS_NT"); return e ? atoi(e) : 0; }();   // A/B knob
+            // (A/B knob BASQ_DBS_NT=0: plain loads.  Measured on 1-GB chunks, S = 400: 6.05 vs 5.19 TB/s back to back, 4.88 vs
+            //  4.21 TB/s when the chunk was written by an element-wise kernel just before, as inside a batch --
+            //  profiles/r06_f_dense_blocksum_nontemporal_ab.txt)
+            static const int nt_env = [] { const char* e = getenv("BASQ_DBS_NT"); return e ? atoi(e) : 1; }();
             // non-temporal 16-byte loads need 16-byte aligned pairs: even row stride, aligned base
             const bool nt = nt_env != 0 && ldc % 2 == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
             const void* fn = square ? (nt ? (const void*)dense_blocksum_pairs_kernel<JR8, true, true>

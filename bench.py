@@ -292,8 +292,8 @@ def main():
         from oracle.cpu_baseline import baseline_matrix
         from oracle.kernels_oracle import StationaryOracle
 
-        # SURVEY §8d matrix: {float64, float32} x {8 threads, all host cores}; ~5 s of CPU work per cell at N=1e6
-        stride = args.cpu_stride or max(1, N // 25_000)
+        # SURVEY §8d matrix: {float64, float32} x {8 threads, all host cores}; ~3.5 s of CPU work per cell at N=1e6 (~15 s in all)
+        stride = args.cpu_stride or max(1, N // 70_000)         # every 14th block at N = 1e6: ~3.5 s of CPU work per cell
         ncpu = os.cpu_count() or 1
         # 8 threads (comparable with SURVEY's probe) and 32 (the largest team that still helps: beyond it the 200-column
         # blocks of the hot loop thrash -- profiles/r02_cpu_full_batch.txt); never more than the host has
