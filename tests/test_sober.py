@@ -231,3 +231,99 @@ def test_sober_tutorial_gpu_matches_golden(i):
     assert idx.cpu().tolist() == fx["idx"]
     gw = torch.tensor(fx["w"], dtype=torch.float64)
     assert ((w.cpu() - gw).abs() / gw).max().item() <= _tut_rtol(c)
+
+
+# ---- differential fuzz of the SOBER variant (round 4: it now runs on the residue-class + descriptor paths) ------------------
+def _sober_fuzz_cases(count, seed=3):
+    """Random sizes, kernels WITHOUT a noise diagonal (SOBER's own ``predictive_covariance``, ``SOBER/_gp.py:281-305``; under
+    ``SOBER/_rchq.py``'s batched calls a noise diagonal would land on entries [i][i][:], see ``_tut_rtol``), importance weights none /
+    random / with zeros."""
+    import numpy as np
+
+    from tests.cases import K, case
+
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i in range(count):
+        N = int(torch.randint(60, 7000, (1,), generator=g))
+        d = int(torch.randint(2, 11, (1,), generator=g))
+        n = int(torch.randint(3, 60, (1,), generator=g))
+        m = int(torch.randint(5, min(N, 220) + 1, (1,), generator=g))
+        fam = ["rbf", "matern52", "matern32"][i % 3]
+        post = dict(n_obs=int(torch.randint(5, 100, (1,), generator=g)), noise=[1e-6, 1e-3][i % 2], obs_seed=70 + i, diag_noise=0.0)
+        kind = i % 4
+        if kind == 0:
+            kern = K(fam, 1.0 + 0.5 * (i % 4), 1.0)
+        elif kind == 1:
+            kern = K(fam, 1.5 + 0.5 * (i % 3), 1.2, posterior=post)
+        elif kind == 2:
+            kern = K("rbf", 2.0, 1.0, posterior=post, warp="wsabil")
+        else:
+            kern = K("rbf", 2.0, 1.0, posterior=post, warp="wsabim")
+        c = case(f"sfz{i}", N, d, m, n, kern, pool_seed=700 + i, torch_seed=i)
+        c["weights"] = ["none", "is", "zeros"][(i // 4) % 3]
+        rng = np.random.Generator(np.random.PCG64(9000 + i))
+        w0 = None
+        if c["weights"] != "none":
+            k = rng.integers(1, 1 << 20, size=N, dtype=np.int64).astype(np.float64)
+            if c["weights"] == "zeros":
+                k[rng.integers(0, 10, size=N) < 3] = 0.0
+            w0 = torch.from_numpy(k / k.sum())
+        out.append((c, w0))
+    return out
+
+
+def _sober_fuzz(run_engine, count, min_compared):
+    import warnings
+
+    from oracle.rchq_oracle import recombination_sober_oracle
+    from tests.cases import build_oracle_kernel, build_pool, build_product_kernel, observation_gram_condition
+
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        compared = skipped = 0
+        for c, w0 in _sober_fuzz_cases(count):
+            pts, nys = build_pool(c)
+            ko, state = build_oracle_kernel(c)
+            A = ko(nys, nys)
+            ev = torch.linalg.eigvalsh(0.5 * (A + A.T))
+            if int((ev > 1e-8 * ev.abs().max()).sum()) < c["m"] or observation_gram_condition(c, state) > 1e6:
+                skipped += 1          # make_cov_psd's jitter branch / a numerically rank-deficient Gram / an ill-conditioned posterior
+                continue
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                torch.manual_seed(c["torch_seed"])
+                io, wo = recombination_sober_oracle(pts, nys, c["n"], ko, None if w0 is None else w0.clone())
+                torch.manual_seed(c["torch_seed"])
+                ie, we = run_engine(pts, nys, c, build_product_kernel(c, state), w0)
+            assert io.tolist() == ie.tolist(), f"{c['name']}: N={c['N']} d={c['d']} n={c['n']} m={c['m']} {c['kernel']} weights {c['weights']}"
+            if len(wo):
+                assert ((we - wo).abs() / wo).max().item() <= 1e-5, c["name"]
+            compared += 1
+        assert compared >= min_compared, (compared, skipped)
+    finally:
+        torch.set_default_dtype(prev)
+
+
+def test_sober_differential_fuzz_engine_vs_oracle():
+    """The SOBER variant's host logic (CPU stand-in) against the oracle of ``SOBER/_rchq.py``: structured kernels, importance
+    weights with zeros, ragged sizes -- on the residue-class + descriptor paths (remainder counted twice: ``:127-135``, ``:155-166``)."""
+    from basq_amd._engine import RecombinationEngine
+    from tests.cpu_stand_in import CpuStandInOps
+
+    def run(pts, nys, c, kern, w0):
+        return RecombinationEngine(CpuStandInOps()).run(pts, 0, c["N"], nys, c["n"], kern, variant="sober", init_weights=w0)
+
+    _sober_fuzz(run, 24, 12)
+
+
+@pytest.mark.gpu
+def test_sober_differential_fuzz_gpu():
+    from basq_amd import sober
+
+    def run(pts, nys, c, kern, w0):
+        idx, w = sober.recombination(pts, nys, c["n"], kern, torch.device("cuda:0"), torch.float64, init_weights=w0)
+        return idx.cpu(), w.cpu()
+
+    _sober_fuzz(run, 72, 40)

@@ -62,6 +62,29 @@ pmc() {
     local name=$1 ctrs=$2
     ( cd /tmp && timeout -k 10 600 rocprofv3 --pmc $ctrs --output-format csv -d "$ROOT/$out/pmc_$name" -o "$name" -- python3 "$ROOT/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-roofline-batch > "$ROOT/$out/pmc_$name.log" 2>&1 )
 }
+# the dense block sums under the FETCH_SIZE / WRITE_SIZE counters (their roof is bytes: 8 B per pair, read once)
+pmc_dense() {
+    local name=$1 ctrs=$2
+    ( cd /tmp && timeout -k 10 300 rocprofv3 --pmc $ctrs --output-format csv -d "$ROOT/$out/pmc_$name" -o "$name" -- python3 "$ROOT/tools/bench_dense_blocksum.py" --reps 4 > "$ROOT/$out/pmc_$name.log" 2>&1 )
+}
+job_pmc_dense()   { pmc_dense dfetch "FETCH_SIZE" && pmc_dense dwrite "WRITE_SIZE" && python - "$out" <<'PY' > "$out/pmc_dense_summary.txt"
+import csv, glob, sys
+out = sys.argv[1]
+for tag, ctr in (("dfetch", "FETCH_SIZE"), ("dwrite", "WRITE_SIZE")):
+    vals = []
+    for fn in glob.glob(f"{out}/pmc_{tag}/**/*counter_collection.csv", recursive=True):
+        acc = {}
+        for r in csv.DictReader(open(fn)):
+            if "dense_blocksum_pairs" in r["Kernel_Name"] and r["Counter_Name"] == ctr:
+                acc[r["Dispatch_Id"]] = acc.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+        vals += list(acc.values())
+    if vals:
+        v = sorted(vals)[len(vals) // 2]
+        print(f"{ctr}: median {v:.0f} KiB per launch = {v * 1024 / 1e9:.3f} GB over {len(vals)} launches "
+              f"(algorithmic: 1.056 GB of kernel values read once + 0.032 GB of block sums read and written; gfx950 tallies the "
+              f"128-B requests of 16-B-per-lane streaming reads at 64 B, MI355X_MICROARCH.md: FETCH_SIZE x 2 for such reads)")
+PY
+cat "$out/pmc_dense_summary.txt"; }
 job_pmc()         { pmc fetch "FETCH_SIZE" && pmc write "WRITE_SIZE" && pmc pipe "SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" && python tools/pmc_summary.py "$out" > "$out/pmc_summary.json"; rc=$?; cut -c1-400 "$out/pmc_summary.json"; return $rc; }
 
 for j in "$@"; do
