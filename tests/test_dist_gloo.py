@@ -183,6 +183,58 @@ def test_sharded_sober_variant_matches_golden(i, world):
         assert ((torch.tensor(w, dtype=torch.float64) - gw).abs() / gw).max().item() <= 1e-6
 
 
+def _sober_tutorial_worker(rank, world, port, i, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from basq_amd._engine import RecombinationEngine, TorchDistComm
+        from basq_amd._partition import initial_shards
+        from oracle.make_golden_sober import TUTORIAL_CASES, tutorial_inputs
+        from tests.cases import build_product_kernel
+        from tests.cpu_stand_in import CpuStandInOps
+
+        c = TUTORIAL_CASES[i]
+        pts, nys = tutorial_inputs(c)
+        off, n = initial_shards(c["N"], world)[rank]
+        ops = CpuStandInOps()
+        torch.manual_seed(1)
+        idx, w = RecombinationEngine(ops, TorchDistComm()).run(pts[off:off + n].clone(), off, c["N"], nys, c["n"],
+                                                               build_product_kernel(c), variant="sober")
+        q.put((rank, idx.tolist(), w.tolist(), ops.calls.get("regroup", 0)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("i,world", [(1, 2), (4, 3), (3, 4)])
+def test_sharded_sober_tutorial_cases_on_the_class_paths(i, world):
+    """Round 4: the SOBER variant at the tutorials' size on several ranks -- residue-class sums (regrouped rounds), the
+    remainder's first count as one more irregular chunk (shards that end inside the remainder), WSABI-M's squared covariance
+    per class with its per-candidate noise terms (case 4) -- against the goldens of the imported ``SOBER/_rchq.py``."""
+    import json
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sober_tutorial.json")) as f:
+        fx = json.load(f)[i]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sober_tutorial_worker, args=(r, world, port, i, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    gw = torch.tensor(fx["w"], dtype=torch.float64)
+    rtol = 1e-5 if fx["case"]["kernel"]["warp"] == "wsabim" else 1e-6        # (tests/test_sober.py::_tut_rtol)
+    for rank, idx, w, n_regroup in res:
+        assert idx == fx["idx"], f"rank {rank}"
+        assert ((torch.tensor(w, dtype=torch.float64) - gw).abs() / gw).max().item() <= rtol
+        assert n_regroup > 0                                                  # the class path was taken
+    assert all(r[1] == res[0][1] and r[2] == res[0][2] for r in res)
+
+
 def _basis_worker(rank, world, port, name, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
