@@ -525,7 +525,7 @@ class Batch:
             if owner is None or comm.rank == owner:
                 XcarT, tot = ops.finalize(*fin, tot_out=None if rv is None else rv["tot"])
                 PhiT = ops.nullspace(XcarT, s, S)
-                keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, tot.clone(), S, s, out=rv)
+                keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, tot, S, s, out=rv)
             if owner is not None:
                 # the outcome of the owner's reduction (w_star | tot | info, kept, keep_rank: 3 S + 1 doubles), stream-ordered
                 comm.broadcast(res, src=owner)
@@ -651,7 +651,7 @@ class Batch:
                                           tot_out=None if rv is None else rv["tot"])
                 PhiT = yield from self._nullspace(XcarT, s, M, cluster)      # :140-143 (rows = null-space vectors)
                 with _Timer(ops, trace, "eliminate"):
-                    keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, tot.clone(), M, s, cluster, out=rv)
+                    keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, tot, M, s, cluster, out=rv)
             elif not self._gpu_nullspace(M):
                 yield _recorded_event(ops)                       # the reducing rank waits for its host SVD here: same yield count
             if shared:
@@ -761,7 +761,7 @@ class Batch:
         s_car = q + 2
         if R > s_car:
             PhiT = yield from self._nullspace(XcarT, s_car, R)
-            _, kept, w_star, info = ops.car_eliminate(PhiT, tot.clone(), R, s_car)
+            _, kept, w_star, info = ops.car_eliminate(PhiT, tot, R, s_car)
             head, ready = ops.to_host_async(ops.info_kept_buffer(info, kept), "head")
             yield ready
             hl = head.tolist()

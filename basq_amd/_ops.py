@@ -273,7 +273,7 @@ class HipOps:
         return res, dict(w_star=res[:M], tot=res[M:2 * M], info=info, kept=kept, keep_rank=ints[2 + M:2 + 2 * M])
 
     def car_eliminate(self, PhiT, mu, M, s, cluster=True, out=None):
-        """In place on PhiT/mu.  -> (keep_rank[M] i32, kept[s] i32, w_star[s] f64, info[2] i32 = [n_keep, status]);
+        """Destroys PhiT; ``mu`` is read only.  -> (keep_rank[M] i32, kept[s] i32, w_star[s] f64, info[2] i32 = [n_keep, status]);
         status 0 ok, 1 = a null vector without a positive entry, 2 = a cluster kernel (this one or the null space's) timed
         out waiting for its sibling work-groups.  ``out``: the views of ``reduction_result(M)`` to write into."""
         self._chk(PhiT)

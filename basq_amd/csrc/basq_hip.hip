@@ -1512,8 +1512,7 @@ __global__ void __launch_bounds__(1024) car_eliminate_kernel(double* __restrict_
     const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
     if (tid < M) {
         keep_rank[tid] = keep ? rank : -1;
-        mu_g[tid] = mu[tid];
-        if (keep) { kept[rank] = tid; w_star[rank] = mu[tid]; }
+        if (keep) { kept[rank] = tid; w_star[rank] = mu[tid]; }     // (mu_g stays as it came: ABI 13)
     }
     if (tid == 0) { info[0] = total; info[1] = status; }
 }
@@ -1663,8 +1662,7 @@ __global__ void __launch_bounds__(1024) car_eliminate_lds_kernel(const double* _
     const int rank = base + __popcll(bal & ((1ull << lane) - 1ull));
     if (tid < M) {
         keep_rank[tid] = keep ? rank : -1;
-        mu_g[tid] = mu_r;
-        if (keep) { kept[rank] = tid; w_star[rank] = mu_r; }
+        if (keep) { kept[rank] = tid; w_star[rank] = mu_r; }        // (mu_g stays as it came: ABI 13)
     }
     if (tid == 0) { info[0] = total; info[1] = status; }
 }
@@ -1984,8 +1982,7 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) car_eliminate_cluster_kernel(co
                 const int k = 2 * h + b, col = BASQ_PAIRCOL(k), rank = b ? r1 : r0;
                 if (col < M) {
                     keep_rank[col] = keep[k] ? rank : -1;
-                    mu_g[col] = mu[k];
-                    if (keep[k]) { kept[rank] = col; w_star[rank] = mu[k]; }
+                    if (keep[k]) { kept[rank] = col; w_star[rank] = mu[k]; }   // (mu_g stays as it came: ABI 13)
                 }
             }
             base += __popcll(bal[2 * h]) + __popcll(bal[2 * h + 1]);

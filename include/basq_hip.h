@@ -217,8 +217,8 @@ int64_t basq_reduction_ws_doubles(int32_t s, int32_t M);
  * Caratheodory elimination -- the loop of Tchernychova_Lyons_CAR, BASQ/_rchq.py:146-175, in the
  * reference's floating-point op order (separate multiply / subtract, outer product then divide).
  * PhiT is the null-space basis as ROWS: PhiT[k][i] = Phi[i][k], [M-s, M] (the last M-s rows of the
- * full Vh of the SVD at :140-143); it is destroyed.  mu [M] holds the set weights on entry and the
- * reduced weights on exit (zero for eliminated sets).  Outputs: keep_rank[M] (rank among survivors
+ * full Vh of the SVD at :140-143); it is destroyed.  mu [M] holds the set weights and is READ ONLY (since ABI 13: the
+ * in-place update of earlier versions cost every caller a copy per round -- the reduced weights are w_star).  Outputs: keep_rank[M] (rank among survivors
  * or -1), kept[<=s] ascending survivor ids, w_star[<=s], info[0] = n_keep, info[1] = status
  * (0 ok, 1 = a null vector had no positive entry: the reference would raise at :152; 2 = a cluster kernel's
  * bounded spin timed out -- never in a healthy run).  Null vectors live in registers (one work-group for M <= 256,

@@ -260,6 +260,7 @@ class CpuStandInOps:
                 out[key].copy_(val)
             return out["keep_rank"], out["kept"], out["w_star"], out["info"]
         self._count("car")
+        mu = mu.clone()                                        # (read only for the caller, as the C entry)
         Phi = PhiT.T.clone()                                   # [M, M-s]
         status = 0
         for _ in range(M - s):
