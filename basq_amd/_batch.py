@@ -532,21 +532,22 @@ class Batch:
                 keep_rank, kept, w_star, info, tot = rv["keep_rank"], rv["kept"], rv["w_star"], rv["info"], rv["tot"]
             if trace is not None:
                 records.append(ops.info_kept_buffer(info, kept))
-            cls = None
-            if Mc is not None and C_cur >= 2:
-                Mn = ops.empty(C_cur // 2 + n_extra, Mc.shape[1], S)
-                ops.regroup_classes(Mc[:C_cur], kept, w_star, tot, out=Mn[:C_cur // 2])
-                cls = dict(M=Mn, C=C_cur // 2, reg_blocks=None)
             # bounds of the next survivor count; the class plan of the next fresh evaluation follows the lower one
             R_lo_n = (R_lo // S) * n_keep_exp
             R_up_n = (R_up // S) * n_keep_exp + (S - 1)
             # this rank's shard [off, off + Rl): at most ceil(Rl / S) + 1 blocks touch it, each keeps n_keep_exp; + the tail
             Rl_up_n = min(R_up_n, (-(-Rl_up // S) + 1) * n_keep_exp + (S - 1)) if multi else R_up_n
+            cls = None
             plan_C = None
-            if cls is None:
+            if Mc is not None and C_cur >= 2:
+                # next round's class messages AND its descriptor, one launch (both read the elimination's outcome)
+                Mn = ops.empty(C_cur // 2 + n_extra, Mc.shape[1], S)
+                ops.regroup_round_next(Mc[:C_cur], kept, w_star, tot, Mn[:C_cur // 2], g_row, info, keep_rank, S, -1, True,
+                                       geo_t[r + 1])
+                cls = dict(M=Mn, C=C_cur // 2, reg_blocks=None)
+            else:
                 plan_C = classes_for(R_lo_n // S) if self.plan.classes else 1
-            ops.round_next(g_row, info, keep_rank, S, -1 if cls is not None else (plan_C if plan_C >= 2 else 0),
-                           True, geo_t[r + 1])
+                ops.round_next(g_row, info, keep_rank, S, plan_C if plan_C >= 2 else 0, True, geo_t[r + 1])
             cand, mu, gid, wx = ops.reweight_compact_geo(cand, mu, gid, wx, g_row, geo_t[r + 1], info, Rl_up, S, kp,
                                                          keep_rank, w_star, tot, Rl_up_n, n_keep_exp)
             r += 1

@@ -57,6 +57,7 @@ SIGNATURES = {
     "basq_finalize_geo_f64": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i64, _i32, _f64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "basq_tail_weights_geo_f64": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp]),
     "basq_round_next_i64": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "basq_regroup_round_next_f64": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp]),
     "basq_blocksum_geo_f64": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "basq_reweight_compact_geo_f64": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _i64,
                                                 _i32, _vp, _vp, _vp, _vp, _vp]),

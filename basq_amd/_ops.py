@@ -368,6 +368,16 @@ class HipOps:
         check(self.lib.basq_round_next_i64(_ptr(geo_row), _ptr(info), _ptr(keep_rank), S, int(class_mode),
                                            1 if expect_half else 0, _ptr(geo_next), self._stream()), "basq_round_next_i64")
 
+    def regroup_round_next(self, T, kept, w_star, tot, out, geo_row, info, keep_rank, S, class_mode, expect_half, geo_next):
+        """``regroup_classes`` + ``round_next`` in one launch (``basq_regroup_round_next_f64``)."""
+        Cn, rows, S_ = T.shape
+        assert T.is_contiguous() and out.is_contiguous() and tuple(out.shape) == (Cn // 2, rows, S_) and S_ == S
+        check(self.lib.basq_regroup_round_next_f64(_ptr(T), rows, S, Cn, _ptr(kept), _ptr(w_star), _ptr(tot), _ptr(out),
+                                                   _ptr(geo_row), _ptr(info), _ptr(keep_rank), int(class_mode),
+                                                   1 if expect_half else 0, _ptr(geo_next), self._stream()),
+              "basq_regroup_round_next_f64")
+        return out
+
     def blocksum_geo(self, spec, nys, m, cand, mu, wx, geo_row, mode, S, n_chunks, out=None, class_mod=0, class0=0):
         """``blocksum`` with the candidate range read from a round descriptor (``mode`` 1: regular region, 2: the rest,
         3: everything)."""

@@ -2891,11 +2891,10 @@ __global__ void reweight_compact_geo_kernel(const double* __restrict__ cand, con
 //   (regular region = the largest multiple of class_mode blocks), -1: the classes are inherited (regular region halves),
 //   0: no classes.  Sticky violation flag: the elimination failed (status) or did not keep exactly half of the sets
 //   while the host had already enqueued a regrouping that relies on it -- the host then repeats the batch round by round.
-__global__ void round_next_kernel(const long long* __restrict__ gp, const int* __restrict__ info,
-                                  const int* __restrict__ keep_rank, int S, int class_mode, int expect_half,
-                                  long long* __restrict__ gn) {
+__device__ __forceinline__ void round_next_body(const int lane, const long long* __restrict__ gp,
+                                                const int* __restrict__ info, const int* __restrict__ keep_rank, int S,
+                                                int class_mode, int expect_half, long long* __restrict__ gn) {
     // one wave: the lanes share the two prefix counts of the shard's new offset / end (survivors_before of _partition.py)
-    const int lane = threadIdx.x;
     const long long R = gp[0], n_full = gp[1], off = gp[6], Rl = gp[7];
     const long long nb = n_full / S, n_tail = R - n_full;
     const int n_keep = info[0], status = info[1];
@@ -2918,7 +2917,7 @@ __global__ void round_next_kernel(const long long* __restrict__ gp, const int* _
             before[e] = nb * n_keep + (last_kept ? (P - n_full) : 0);
         }
     }
-    if (lane != 0 || blockIdx.x != 0) return;
+    if (lane != 0) return;
     // after a violation every later descriptor-driven launch of the batch sees an EMPTY round (the buffers the host sized
     // for the expected survivor counts are never overrun); the flag tells the host to repeat the rounds one by one
     const long long Rn = viol ? 0 : nb * n_keep + (last_kept ? n_tail : 0);
@@ -2934,6 +2933,12 @@ __global__ void round_next_kernel(const long long* __restrict__ gp, const int* _
     gn[5] = Rn - nbn * S;
     gn[6] = viol ? 0 : before[0];
     gn[7] = viol ? 0 : (before[1] - before[0]);
+}
+
+__global__ void round_next_kernel(const long long* __restrict__ gp, const int* __restrict__ info,
+                                  const int* __restrict__ keep_rank, int S, int class_mode, int expect_half,
+                                  long long* __restrict__ gn) {
+    if (blockIdx.x == 0 && threadIdx.x < 64) round_next_body(threadIdx.x, gp, info, keep_rank, S, class_mode, expect_half, gn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -4185,6 +4190,50 @@ __global__ void regroup_classes_kernel(const double* __restrict__ Tin, int rows,
     }
     const double v = Tin[((long long)(2 * cp + par) * rows + j) * S + s];
     Tout[e] = (v * w_star[k]) / tot[s];                                        // the order of BASQ/_rchq.py:113-114
+}
+
+// The two launches that follow every elimination inside an epoch, as ONE (round 4): the regrouping of the class messages and,
+// in one extra work-group, the next round's descriptor (both read the elimination's outcome; neither reads the other's).
+__global__ void regroup_round_next_kernel(const double* __restrict__ Tin, int rows, int S, int C, const int* __restrict__ kept,
+                                          const double* __restrict__ w_star, const double* __restrict__ tot,
+                                          double* __restrict__ Tout, int n_regroup_blocks, const long long* __restrict__ gp,
+                                          const int* __restrict__ info, const int* __restrict__ keep_rank, int class_mode,
+                                          int expect_half, long long* __restrict__ gn) {
+#pragma clang fp contract(off)
+    if ((int)blockIdx.x >= n_regroup_blocks) {
+        if (threadIdx.x < 64) round_next_body(threadIdx.x, gp, info, keep_rank, S, class_mode, expect_half, gn);
+        return;
+    }
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = (long long)(C / 2) * rows * S;
+    if (e >= n) return;
+    const int sp = (int)(e % S);
+    const long long rest = e / S;
+    const int j = (int)(rest % rows), cp = (int)(rest / rows);
+    const int H = S / 2, par = sp / H, k = sp - par * H;
+    const int s = kept[k];
+    if ((unsigned)s >= (unsigned)S) {
+        Tout[e] = 0.0;
+        return;
+    }
+    const double v = Tin[((long long)(2 * cp + par) * rows + j) * S + s];
+    Tout[e] = (v * w_star[k]) / tot[s];                                        // the order of BASQ/_rchq.py:113-114
+}
+
+int basq_regroup_round_next_f64(const double* Tin, int32_t rows, int32_t S, int32_t C, const int32_t* kept,
+                                const double* w_star, const double* tot, double* Tout, const int64_t* geo,
+                                const int32_t* info, const int32_t* keep_rank, int32_t class_mode, int32_t expect_half,
+                                int64_t* geo_next, void* stream) {
+    if (!Tin || !kept || !w_star || !tot || !Tout || rows < 1 || S < 2 || (S & 1) || C < 2 || (C & 1)) return BASQ_EINVAL;
+    if (!geo || !info || !keep_rank || !geo_next) return BASQ_EINVAL;
+    const long long n = (long long)(C / 2) * rows * S;
+    const long long nb = (n + 255) / 256;
+    if (nb + 1 > 0x7fffffffLL) return BASQ_EINVAL;
+    hipLaunchKernelGGL(regroup_round_next_kernel, dim3((unsigned)(nb + 1)), dim3(256), 0, (hipStream_t)stream, Tin, rows, S, C,
+                       kept, w_star, tot, Tout, (int)nb, (const long long*)geo, info, keep_rank, class_mode, expect_half,
+                       (long long*)geo_next);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
 }
 
 int basq_regroup_classes_f64(const double* Tin, int32_t rows, int32_t S, int32_t C, const int32_t* kept,

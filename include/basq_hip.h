@@ -284,6 +284,12 @@ int basq_finalize_geo_f64(const double* parts, int32_t n_parts, int32_t msg_rows
 int basq_tail_weights_geo_f64(const double* mu, const double* wx, const int64_t* geo, int32_t S, double* out, void* stream);
 int basq_round_next_i64(const int64_t* geo, const int32_t* info, const int32_t* keep_rank, int32_t S, int32_t class_mode,
                         int32_t expect_half, int64_t* geo_next, void* stream);
+/* basq_regroup_classes_f64 + basq_round_next_i64 in ONE launch (the two that follow every elimination inside an epoch; both read
+ * the elimination's outcome, neither reads the other's): arguments as for the two entries. */
+int basq_regroup_round_next_f64(const double* Tin, int32_t rows, int32_t S, int32_t C, const int32_t* kept,
+                                const double* w_star, const double* tot, double* Tout, const int64_t* geo,
+                                const int32_t* info, const int32_t* keep_rank, int32_t class_mode, int32_t expect_half,
+                                int64_t* geo_next, void* stream);
 int basq_blocksum_geo_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
                           const double* mu, const double* wx, const int64_t* geo, int32_t geo_mode, int32_t S,
                           int32_t n_chunks, int32_t class_mod, int32_t class0, double* Xpart, double* totpart,

@@ -336,6 +336,11 @@ class CpuStandInOps:
         n_off, n_Rl = (0, 0) if viol else next_shard(off, Rl, RoundGeometry.of(R, S), kept)
         geo_next[:] = torch.tensor([Rn, nbn * S, reg_blocks * S, viol, nbn, Rn - nbn * S, n_off, n_Rl], dtype=torch.int64)
 
+    def regroup_round_next(self, T, kept, w_star, tot, out, geo_row, info, keep_rank, S, class_mode, expect_half, geo_next):
+        self.regroup_classes(T, kept, w_star, tot, out=out)
+        self.round_next(geo_row, info, keep_rank, S, class_mode, expect_half, geo_next)
+        return out
+
     def blocksum_geo(self, spec, nys, m, cand, mu, wx, geo_row, mode, S, n_chunks, out=None, class_mod=0, class0=0):
         R, n_full, reg_hi, off, Rl = (int(geo_row[k]) for k in (0, 1, 2, 6, 7))
         lo, hi = (0, reg_hi) if mode == 1 else ((reg_hi, R) if mode == 2 else ((n_full, R) if mode == 4 else (0, R)))

@@ -695,6 +695,18 @@ def test_regroup_classes_vs_standin(hip_ops, C, rows, S):
     dev = hip_ops.to_device
     Tg = hip_ops.regroup_classes(dev(T), dev(kept_full), dev(w_star), dev(tot))
     assert torch.equal(Tg.cpu(), Tc)                                          # mul then div, same order: bit-exact
+    # round 4: the same regrouping fused with the next round's descriptor (basq_regroup_round_next_f64) -- both outputs
+    # bit-identical to the two separate launches
+    keep_rank = torch.full((S,), -1, dtype=torch.int32)
+    keep_rank[kept.long()] = torch.arange(S // 2, dtype=torch.int32)
+    info = torch.tensor([S // 2, 0], dtype=torch.int32)
+    R = 37 * S + 11
+    geo = hip_ops.geo_init(3, R, S, (37 // C) * C * S)
+    hip_ops.round_next(geo[0], dev(info), dev(keep_rank), S, -1, True, geo[1])
+    Tf = hip_ops.empty(C // 2, rows, S)
+    hip_ops.regroup_round_next(dev(T), dev(kept_full), dev(w_star), dev(tot), Tf, geo[0], dev(info), dev(keep_rank), S, -1, True, geo[2])
+    assert torch.equal(Tf.cpu(), Tc)
+    assert torch.equal(geo[1].cpu(), geo[2].cpu())
 
 
 @pytest.mark.parametrize("q,m,S,n_chunks", [(99, 1000, 200, 17), (9, 50, 20, 3), (199, 333, 400, 5), (100, 10_000, 200, 2)])
