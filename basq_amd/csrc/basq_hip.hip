@@ -144,13 +144,31 @@ __device__ __forceinline__ double kernel_from_arg(double D) {
     }
 }
 
+// sqrt(x) for x in [1e-30, 1e300) -- the clamped squared distance of the Matern kernels -- without the library routine's
+// scaling and special-case handling (two v_ldexp_f64, a v_cmp_class_f64 and four selects per value: 16 instructions, where
+// the block sums are bound by their instruction count): v_rsq_f64 + the coupled Newton step for (sqrt, 1/(2 sqrt)) + one
+// residual correction, 8 instructions, error <= 1 ulp (round 4; the Gram / mat-vec kernels keep the library sqrt).
+__device__ __forceinline__ double sqrt_pos_fast(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+
+#ifndef BASQ_FAST_SQRT
+#define BASQ_FAST_SQRT 1        // A/B builds: -DBASQ_FAST_SQRT=0 (library sqrt in the block sums)
+#endif
 template <int FAM, int XS>
 __device__ __forceinline__ double kernel_from_arg_k(double D, const ExpK& k, const double* tab) {
     if (FAM == BASQ_FAMILY_RBF) {
         return exp_nonpos_k<XS>(D, k, tab);
     } else {
         const double r2 = fmax(-2.0 * D, 1e-30);
-        const double r = sqrt(r2);
+        const double r = BASQ_FAST_SQRT ? sqrt_pos_fast(r2) : sqrt(r2);
         if (FAM == BASQ_FAMILY_MATERN52) {
             const double a = 0x1.1e3779b97f4a8p+1 * r;
             const double poly = (a + 1.0) + (5.0 / 3.0) * r2;
