@@ -183,12 +183,29 @@ def main():
 
     # ---- per-seed latencies (outside the timed region): one synchronised batch per pool seed, median reported ----
     per_seed_ms = []
+    parity = None
+    golden_names = ["cfg3_rbf_1e6"] + [f"cfg3_rbf_1e6_pool{sd}" for sd in POOL_SEEDS[1:]]
+    check_golden = (N, d, n) == (WORKLOAD["N"], WORKLOAD["d"], WORKLOAD["n"])
     for k in range(0 if args.no_roofline_batch else len(POOL_SEEDS)):
         barrier()
         t1 = time.perf_counter()
-        one_batch(k=k)
+        i_k, w_k = one_batch(k=k)
         barrier()
         per_seed_ms.append(1e3 * (time.perf_counter() - t1))
+        # every pool the timed loop cycles through has a golden produced by running the reference itself (tests/golden/,
+        # fixtures only: nothing of the reference is read here): the batches `value` is measured on ARE the reference's
+        gpath = os.path.join(ROOT, "tests", "golden", golden_names[k] + ".json")
+        if check_golden and os.path.exists(gpath):
+            with open(gpath) as f:
+                fx = json.load(f)
+            same = i_k.cpu().tolist() == fx["idx"]
+            gw = torch.tensor(fx["w"], dtype=torch.float64)
+            rel = float(((w_k.cpu() - gw).abs() / gw).max().item()) if same else float("nan")
+            parity = parity or dict(pools_checked=0, indices_identical=True, max_rel_weight_error=0.0,
+                                    source="tests/golden/cfg3_rbf_1e6*.json (reference-generated, oracle/make_golden.py)")
+            parity["pools_checked"] += 1
+            parity["indices_identical"] = bool(parity["indices_identical"] and same)
+            parity["max_rel_weight_error"] = max(parity["max_rel_weight_error"], rel) if same else float("nan")
 
     # ---- kernel-level roofline: one extra traced batch (HIP events on the launch stream, no host syncs: the batch stays on
     #      the code path the timed steps take -- descriptor-driven rounds -- and reports its launches after the fact) ----
@@ -401,6 +418,7 @@ def main():
             },
             "cpu_baseline": cpu,
             "result_digest": {"n_selected": int(idx.numel()), "w_sum": float(w.sum().item())},
+            "parity_vs_golden": parity,
         }
         line = json.dumps(out)
     if dist is not None:

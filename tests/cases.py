@@ -60,6 +60,12 @@ CASES = [
     case("cfg2_rbf_1e5", 100_000, 10, 1_000, 100, K("rbf", 2.0)),
     # BASELINE config 3 / headline metric: N=1e6, d=10, n=100, m=1e4 (reference: ~2 min of CPU).
     case("cfg3_rbf_1e6", 1_000_000, 10, 10_000, 100, K("rbf", 2.0), slow=True),
+    # the other four pools bench.py cycles through (pool seeds 0-4, torch.manual_seed(1) before every call):
+    # every batch the headline number is measured on has a reference-generated golden
+    case("cfg3_rbf_1e6_pool1", 1_000_000, 10, 10_000, 100, K("rbf", 2.0), pool_seed=1, slow=True),
+    case("cfg3_rbf_1e6_pool2", 1_000_000, 10, 10_000, 100, K("rbf", 2.0), pool_seed=2, slow=True),
+    case("cfg3_rbf_1e6_pool3", 1_000_000, 10, 10_000, 100, K("rbf", 2.0), pool_seed=3, slow=True),
+    case("cfg3_rbf_1e6_pool4", 1_000_000, 10, 10_000, 100, K("rbf", 2.0), pool_seed=4, slow=True),
     # BASELINE config 4: Matern-5/2, N=1e6, d=32, n=200, m=1e4.
     case("cfg4_matern52_1e6_d32", 1_000_000, 32, 10_000, 200, K("matern52", 4.0), pool_seed=7, slow=True),
     # BASELINE config 5: WSABI-L, N=5e5, d=10, n=100, m=5e3, n_obs=202.
