@@ -140,47 +140,6 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # ---- several batches in flight (outside the timed region of `value`): the same K steps through recombination_many ----
-    concurrent = {}
-    if not (args.no_concurrent or args.no_roofline_batch or args.plain):
-        # several ranks: batch k's reductions live on rank k mod G (owner-rank mode, basq_amd/_config.py), so the chains only
-        # spread over all G GPUs with at least G batches in flight
-        for k_fl in ([2, 3] if world == 1 and not force_dist else sorted({2, 4, max(4, min(world, 8))})):
-            n_c = max(args.steps, 12, 3 * k_fl)                      # enough steps for the pipeline's fill and drain not to dominate
-            calls, seeds = [], [1] * n_c
-            for k in range(n_c):
-                pts_nys, pts_local = pools_dev[k % len(pools_dev)]
-                calls.append((pts_local, pts_nys, n, kern) if (world == 1 and not force_dist)
-                             else (pts_local, off, N, pts_nys, n, kern))
-
-            lat = []
-
-            def many():
-                del lat[:]
-                if world == 1 and not force_dist:
-                    return basq_amd.recombination_many(calls, dev, in_flight=k_fl, seeds=seeds, timings=lat)
-                return basq_amd.recombination_many_sharded(calls, dev, in_flight=k_fl, seeds=seeds, timings=lat)
-
-            many()                                                   # warm-up: the slots' streams, buffers, workspaces
-            barrier()
-            t1 = time.perf_counter()
-            res_c = many()
-            barrier()
-            dtc = time.perf_counter() - t1
-            if dist is not None:
-                tt = torch.tensor([dtc], dtype=torch.float64, device=dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                dtc = float(tt.item())
-            # every pipelined result against the sequential run of the same step (same pool, same seed): bit for bit
-            same = True
-            for k in range(min(n_c, len(pools_dev))):
-                i1, w1 = one_batch(k=k)
-                same = same and torch.equal(i1, res_c[k][0]) and torch.equal(w1, res_c[k][1])
-            lat_ms = sorted(1e3 * (b - a) for a, b in lat)           # first launch -> result, per batch (rank 0's host clock)
-            concurrent[k_fl] = dict(in_flight=k_fl, value=n_c / dtc, unit="batches/s", steps=n_c,
-                                    ms_per_step=1e3 * dtc / n_c, latency_ms_median=lat_ms[len(lat_ms) // 2],
-                                    latency_ms_max=lat_ms[-1], bit_identical_to_sequential=bool(same))
-
     # ---- per-seed latencies (outside the timed region): one synchronised batch per pool seed, median reported ----
     per_seed_ms = []
     parity = None
@@ -345,8 +304,9 @@ def main():
                      "batches_in_flight": ("owner-rank reductions: batch k's null space + elimination on rank k mod world, outcome "
                                            "broadcast (3*2n+1 doubles) on the batch's own process group"
                                            if bcfg.OWNER_RANK_REDUCTION else "reduction replicated on every rank"),
-                     "process_groups_for_batches_in_flight": max(concurrent) if concurrent else 0}
-    if rank == 0:
+                     "process_groups_for_batches_in_flight": "one per batch in flight (TorchDistComm.for_slot)"}
+
+    def build_line(concurrent, note=None):
         value = args.steps / dt
         out = {
             "metric": "recombination batches/sec (N candidates -> n points) at N=1e6 d=10",
@@ -420,11 +380,11 @@ def main():
             "result_digest": {"n_selected": int(idx.numel()), "w_sum": float(w.sum().item())},
             "parity_vs_golden": parity,
         }
-        line = json.dumps(out)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    if rank == 0:
+        if note:
+            out["concurrent_note"] = note
+        return json.dumps(out)
+
+    def emit(line):
         # RCCL writes a version banner to the C-level stdout buffer; push it out first so that the JSON line is the LAST
         # line of rank 0's output
         try:
@@ -434,6 +394,75 @@ def main():
         except OSError:
             pass
         print(line, flush=True)
+
+    # ---- several batches in flight: LAST, and on several ranks under a watchdog.  `value` and everything above come from the
+    #      sequential path (replicated reductions, one process group).  The runs with batches in flight use owner-rank reductions
+    #      on one process group per batch in flight -- gloo-tested on 2-8 ranks, never run on multi-GPU hardware -- so a rank that
+    #      does not get through them within the limit prints the line it already has (rank 0) and leaves; the driver always gets
+    #      its JSON line.
+    watchdog = None
+    concurrent = {}
+    if dist is not None and world > 1:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                emit(build_line(dict(concurrent), note="the runs with batches in flight did not ALL finish within the watchdog's limit "
+                                                       "on this machine (those that did are reported): value and roofline are from "
+                                                       "the sequential path, completed before"))
+            os._exit(0)
+
+        watchdog = threading.Timer(float(os.environ.get("BASQ_BENCH_CONCURRENT_LIMIT_S", "240")), give_up)
+        watchdog.daemon = True
+        watchdog.start()
+    # ---- several batches in flight (outside the timed region of `value`): the same K steps through recombination_many ----
+    if not (args.no_concurrent or args.no_roofline_batch or args.plain):
+        # several ranks: batch k's reductions live on rank k mod G (owner-rank mode, basq_amd/_config.py), so the chains only
+        # spread over all G GPUs with at least G batches in flight
+        for k_fl in ([2, 3] if world == 1 and not force_dist else sorted({2, 4, max(4, min(world, 8))})):
+            n_c = max(args.steps, 12, 3 * k_fl)                      # enough steps for the pipeline's fill and drain not to dominate
+            calls, seeds = [], [1] * n_c
+            for k in range(n_c):
+                pts_nys, pts_local = pools_dev[k % len(pools_dev)]
+                calls.append((pts_local, pts_nys, n, kern) if (world == 1 and not force_dist)
+                             else (pts_local, off, N, pts_nys, n, kern))
+
+            lat = []
+
+            def many():
+                del lat[:]
+                if world == 1 and not force_dist:
+                    return basq_amd.recombination_many(calls, dev, in_flight=k_fl, seeds=seeds, timings=lat)
+                return basq_amd.recombination_many_sharded(calls, dev, in_flight=k_fl, seeds=seeds, timings=lat)
+
+            many()                                                   # warm-up: the slots' streams, buffers, workspaces
+            barrier()
+            t1 = time.perf_counter()
+            res_c = many()
+            barrier()
+            dtc = time.perf_counter() - t1
+            if dist is not None:
+                tt = torch.tensor([dtc], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                dtc = float(tt.item())
+            # every pipelined result against the sequential run of the same step (same pool, same seed): bit for bit
+            same = True
+            for k in range(min(n_c, len(pools_dev))):
+                i1, w1 = one_batch(k=k)
+                same = same and torch.equal(i1, res_c[k][0]) and torch.equal(w1, res_c[k][1])
+            lat_ms = sorted(1e3 * (b - a) for a, b in lat)           # first launch -> result, per batch (rank 0's host clock)
+            concurrent[k_fl] = dict(in_flight=k_fl, value=n_c / dtc, unit="batches/s", steps=n_c,
+                                    ms_per_step=1e3 * dtc / n_c, latency_ms_median=lat_ms[len(lat_ms) // 2],
+                                    latency_ms_max=lat_ms[-1], bit_identical_to_sequential=bool(same))
+
+    if watchdog is not None:
+        watchdog.cancel()
+    line = build_line(concurrent) if rank == 0 else None
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        emit(line)
 
 
 if __name__ == "__main__":
