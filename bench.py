@@ -131,8 +131,10 @@ def main():
         one_batch(k=k)
     barrier()
     t0 = time.perf_counter()
+    step_marks = []
     for k in range(args.steps):
         idx, w = one_batch(k=k)
+        step_marks.append(time.perf_counter())                  # (host clock when call k returned: no extra synchronisation)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -316,6 +318,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
+            "ms_each_step": [round(1e3 * (b - a), 3) for a, b in zip([t0] + step_marks[:-1], step_marks)],
             "median_ms_per_seed": sorted(per_seed_ms)[len(per_seed_ms) // 2] if per_seed_ms else None,
             "ms_per_seed": [round(v, 3) for v in per_seed_ms],
             "higher_is_better": True,
