@@ -48,4 +48,8 @@ MAX_CLASSES = 16                 # classes at the start of an epoch (power of tw
 # Rounds driven by a device-resident descriptor, no host wait per round (any rank count; structured kernels except WSABI-M).
 ASYNC_ROUNDS = True
 
+# A synchronous batch waits for the GPU 5-6 times (range finder's SVD, the descriptor table, the last rounds): poll the event
+# instead of the runtime's blocking wait (A/B: tools/ab_engine.py SPIN_WAIT 0 1).
+SPIN_WAIT = False
+
 PSD_EIG_MAX_M = 4096             # _make_cov_psd: largest Gram whose spectrum is checked (SOBER/_utils.py:122-124)
