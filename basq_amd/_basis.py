@@ -243,17 +243,25 @@ class _ShardedProducts:
     level, far inside the stability margin of the selection (SURVEY finding 3); the gloo tests pin the indices.
     """
 
-    def __init__(self, ops, comm, A_rows, shards, m):
+    def __init__(self, ops, comm, A_rows, shards, m, drawer=0, lockstep=True):
+        """``drawer``: the rank that draws the Gaussian test matrix (broadcast from there).  ``lockstep``: the other ranks
+        advance their CPU generators by the same amount (the default: a loop that samples from the global generator on every
+        rank keeps seeing ONE stream).  ``run_many`` turns it off when every job carries its own seed -- every rank is then
+        re-seeded before every batch, ANY rank draws the same matrix, and the 2.2-ms draw of a headline batch is dealt
+        round-robin with the batch's owner instead of being repeated by all ranks (the generators are brought back in step once,
+        after the last job)."""
         self.ops, self.comm, self.rows, self.shards, self.m = ops, comm, A_rows, shards, m
         self.mb = max(n for _, n in shards)
+        self.drawer, self.lockstep = int(drawer) % comm.world, bool(lockstep)
 
     def draw(self, q, trace):
-        if self.comm.rank == 0:
+        if self.comm.rank == self.drawer:
             R = _gaussian_test_matrix(self.ops, self.m, q, trace).contiguous()
         else:
-            _skip_test_matrix_draw(self.ops, self.m, q)         # same generator consumption on every rank
+            if self.lockstep:
+                _skip_test_matrix_draw(self.ops, self.m, q)     # same generator consumption on every rank
             R = self.ops.empty(self.m, q)
-        return self.comm.broadcast(R)
+        return self.comm.broadcast(R, src=self.drawer)
 
     def a(self, Q):
         mr = self.rows.shape[0]

@@ -151,7 +151,8 @@ class Batch:
     """State of one recombination in flight; ``steps()`` is the generator the engine drives."""
 
     def __init__(self, ops, comm, pts_local, gid0: int, n_total: int, pts_nys, num_pts: int, kernel, trace=None,
-                 variant: str = "basq", init_weights=None, objective=None, pipelined: bool = False, owner: int | None = None):
+                 variant: str = "basq", init_weights=None, objective=None, pipelined: bool = False, owner: int | None = None,
+                 draw_on_owner: bool = False):
         """``pts_local`` = this rank's contiguous slice ``[gid0, gid0 + len)`` of the pool.
 
         ``variant="basq"`` follows ``BASQ/_rchq.py`` (uniform start weights, ``init_weights`` ignored);
@@ -192,6 +193,8 @@ class Batch:
         self.init_weights, self.objective = init_weights, objective
         self.pipelined = pipelined
         self.owner = None if (owner is None or comm.world == 1) else int(owner) % comm.world
+        # the Gaussian draw of the sharded range finder on the owner alone (run_many: every job carries a seed)
+        self.draw_on_owner = bool(draw_on_owner) and self.owner is not None
         m_nys = int(pts_nys.shape[0]) if pts_nys.dim() >= 1 else 0
         self.plan = Plan.of(kernel, variant, objective, comm, ops, trace, n_sets=2 * (min(int(num_pts) - 1, m_nys) + 1),
                             owner=self.owner)
@@ -213,7 +216,7 @@ class Batch:
         sums = self.__dict__.get("sums")
         if sums is not None:
             sums.b = None
-        keep = ("notes", "plan")
+        keep = ("notes", "plan", "drew_test_matrix")
         for k in list(self.__dict__):
             if k not in keep:
                 self.__dict__[k] = None
@@ -373,7 +376,10 @@ class Batch:
             with _Timer(ops, trace, "basis.gram"):
                 A_rows = kernel.dense(ops, pts_nys[r0:r0 + mr].contiguous(), pts_nys, self.center, diag_offset=r0) \
                     if mr else ops.zeros(0, m)
-            U = yield from nystrom_basis_steps(ops, _ShardedProducts(ops, comm, A_rows, shards, m), self.num_pts - 1, trace,
+            prod = _ShardedProducts(ops, comm, A_rows, shards, m, drawer=self.owner if self.draw_on_owner else 0,
+                                    lockstep=not self.draw_on_owner)
+            self.drew_test_matrix = comm.rank == prod.drawer or prod.lockstep
+            U = yield from nystrom_basis_steps(ops, prod, self.num_pts - 1, trace,
                                                overlap=late, notes=self.notes)
             return U
         if comm.rank == 0:

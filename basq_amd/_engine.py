@@ -171,6 +171,10 @@ class RecombinationEngine:
         # group of its own (``TorchDistComm.for_slot``).  Job k -> group k mod slots: the same on every rank by construction.
         owner_mode = cfg.OWNER_RANK_REDUCTION and self.comm.world > 1 and pipelined
         slot_comms = [self.comm.for_slot(i) for i in range(len(slot_ops))] if owner_mode else None
+        # every job re-seeds the generator: the Gaussian draw of a batch (2.2 ms of host time at the headline size) then runs
+        # on the batch's owner alone instead of on every rank; the generators are put back in step after the last job
+        draw_on_owner = owner_mode and bool(jobs) and all(j.seed is not None for j in jobs)
+        last_drew = True
 
         def advance(entry):
             """Resume a batch until its next wait (-> True) or its end (-> False, result stored, slot freed)."""
@@ -195,9 +199,12 @@ class RecombinationEngine:
                 comm = slot_comms[k % len(slot_comms)] if owner_mode else self.comm
                 batch = Batch(ops, comm, job.pts_local, job.gid0, job.n_total, job.pts_nys, job.num_pts, job.kernel,
                               job.trace, job.variant, job.init_weights, job.objective, pipelined=pipelined,
-                              owner=(k % self.comm.world) if owner_mode else None)
+                              owner=(k % self.comm.world) if owner_mode else None, draw_on_owner=draw_on_owner)
                 entry = [k, batch.steps(), ops, None]
-                if advance(entry):
+                alive = advance(entry)
+                if k == len(jobs) - 1:                           # (the draw belongs to a batch's first segment)
+                    last_drew = getattr(batch, "drew_test_matrix", True) is not False
+                if alive:
                     active.append(entry)
             if not active:
                 continue
@@ -212,6 +219,13 @@ class RecombinationEngine:
             entry[3].synchronize()
             if advance(entry):
                 active.append(entry)
+        if draw_on_owner and not last_drew:
+            # sequential calls would leave every rank's generator at "last seed + one draw": this rank skipped that draw
+            from ._basis import _skip_test_matrix_draw
+
+            last = jobs[-1]
+            torch.manual_seed(last.seed)
+            _skip_test_matrix_draw(slot_ops[0], int(last.pts_nys.shape[0]), int(last.num_pts) - 1)
         for ops in slot_ops:                                     # the results are valid for every stream once this returns
             sync = getattr(ops, "synchronize", None)
             if sync is not None:

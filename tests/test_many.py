@@ -142,9 +142,12 @@ def _worker(rank, world, port, q, opaque=(), owner_mode=True, n_slots=2, names=(
                             trace=EngineTrace(host_sync=False)))
         slots = [CpuStandInOps() for _ in range(n_slots)]
         res = RecombinationEngine(slots[0], TorchDistComm()).run_many(jobs, slots)
+        import hashlib
+
         q.put((rank, [(i.tolist(), w.tolist()) for i, w in res], slots[0].calls.get("round_next", 0),
                [[r["kept"] for r in j.trace.rounds] for j in jobs],
-               sum(sl.calls.get("car", 0) for sl in slots)))
+               sum(sl.calls.get("car", 0) for sl in slots),
+               hashlib.sha256(torch.get_rng_state().numpy().tobytes()).hexdigest()))
     finally:
         dist.destroy_process_group()
 
@@ -165,7 +168,7 @@ def test_run_many_sharded_matches_goldens(world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, out, n_next, _, _ in res:
+    for rank, out, n_next, _, _, _ in res:
         assert n_next > 0                                                     # descriptor-driven rounds on several ranks
         for nm, (idx, w) in zip(["rbf_ragged", "cfg1_posterior_1e4", "rbf_1e4"], out):
             fx = load_golden(nm)
@@ -199,7 +202,7 @@ def test_run_many_owner_rank_reductions(world, n_slots, owner_mode):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, out, n_next, kept, _ in res:
+    for rank, out, n_next, kept, _, _ in res:
         assert n_next > 0
         for nm, (idx, w), kr in zip(OWNER_NAMES, out, kept):
             fx = load_golden(nm)
@@ -208,6 +211,15 @@ def test_run_many_owner_rank_reductions(world, n_slots, owner_mode):
             assert ((torch.tensor(w, dtype=torch.float64) - gw).abs() / gw).max().item() <= 1e-6
             assert kr == [r["kept"] for r in fx["rounds"]], f"rank {rank} {nm}: per-round kept sets"
     assert all(r[1] == res[0][1] for r in res)
+    # the CPU global generator ends where sequential calls would leave it -- last job's seed + ONE draw of its test matrix -- on
+    # EVERY rank, although (owner mode, every job seeded) each draw was made by one rank only
+    import hashlib
+
+    c_last = BY_NAME[OWNER_NAMES[-1]]
+    torch.manual_seed(c_last["torch_seed"])
+    torch.randn(c_last["m"], c_last["n"] - 1, dtype=torch.float64)
+    want = hashlib.sha256(torch.get_rng_state().numpy().tobytes()).hexdigest()
+    assert all(r[5] == want for r in res)
     cars = sorted(r[4] for r in res)
     total_rounds = sum(load_golden(nm)["n_rounds"] for nm in OWNER_NAMES)
     if owner_mode:
@@ -235,7 +247,7 @@ def test_run_many_sharded_with_opaque_callables_and_more_jobs_than_slots(opaque)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, out, _, _, _ in res:
+    for rank, out, _, _, _, _ in res:
         for nm, (idx, w) in zip(["rbf_ragged", "cfg1_posterior_1e4", "rbf_1e4"], out):
             fx = load_golden(nm)
             assert idx == fx["idx"], f"rank {rank} {nm}"
