@@ -38,6 +38,10 @@ TUTORIAL_CASES = [
     _tut("sober_tut01_rbf_nobs902", "rbf", 2.0, 902),
     _tut("sober_tut02_matern52_nobs502", "matern52", 4.0, 502),
     _tut("sober_tut03_wsabim_nobs502", "rbf", 2.0, 502, warp="wsabim", diag_noise=1e-10),
+    # the SOBER variant at BASELINE config 2's size (N = 1e5, m = 1e3, n = 100, d = 10; its batched kernel call is a
+    # [500, 1000, 200] tensor on the reference's side -- config 3's would be 80 GB): the largest SOBER run this container can pin
+    dict(name="sober_cfg2_rbf_1e5", N=100_000, d=10, m=1_000, n=100, pool_seed=33, weights="none", separate_nys=True,
+         kernel=dict(family="rbf", lengthscale=2.0, outputscale=1.0, posterior=None, warp="none")),
 ]
 
 

@@ -130,7 +130,7 @@ def _tut_cases():
     return TUTORIAL_CASES
 
 
-@pytest.mark.parametrize("i", range(5))
+@pytest.mark.parametrize("i", range(6))
 def test_sober_tutorial_oracle_matches_golden(i):
     """n_cand = 20 000, n_nys = 500 (a separate sample), n = 100, d = 10 through ``SOBER/_rchq.py`` (``SOBER/BASQ/_basq.py:19-36``):
     RBF posterior with 2 / 502 / 902 observations (tutorial 01), Matern-5/2 (02), WSABI-M (03).  Oracle == imported reference."""
@@ -218,7 +218,7 @@ def test_sober_tutorial03_noise_placement_explains_the_weight_difference():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("i", range(5))
+@pytest.mark.parametrize("i", range(6))
 def test_sober_tutorial_gpu_matches_golden(i):
     from basq_amd import sober
     from oracle.make_golden_sober import tutorial_inputs
