@@ -332,62 +332,20 @@ class _ShardedProducts:
         return G1, G2, flags[0], i2, k
 
 
-def nystrom_basis_steps(ops, A, q_req: int, trace=None, overlap=None, notes=None):
-    """``ker_svd_sparsify`` as a step generator -> ``U [min(q, m), m]`` (see :func:`nystrom_basis`).
+class BasisResult:
+    """What the range finder hands to the batch: ``U [min(q, m), m]`` and -- when the basis was formed without waiting for the
+    host -- the pivot flag of its CholeskyQR passes (``bad``: a device int32 scalar, nonzero = a numerically rank-deficient
+    panel) with ``fallback()``, which recomputes the basis by host Householder QR from the same Gaussian draw.  ``bad is None``:
+    the basis is final."""
 
-    What the reference's result depends on is only (i) the Gaussian draw and (ii) the *range* of each intermediate
-    ``Q``: the rows of the returned ``U`` are the left singular vectors of ``Q Q^T A``, unique up to sign,
-    and the recombination is bit-for-bit invariant under row sign flips of ``U`` (tests/test_oracle.py).
-    So the five Householder QRs (host LAPACK in the reference) are replaced by CholeskyQR2 on the GPU and
-    the ``[k, m]`` SVD by an LQ reduction on the GPU + a ``k x k`` SVD on the host.  If a Cholesky pivot
-    signals a numerically rank-deficient panel (cond > ~1e6) the whole basis is recomputed with host
-    Householder QR, from the same Gaussian draw; ``notes`` (a list) receives a line saying so.
+    def __init__(self, U, bad=None, fallback=None):
+        self.U, self.bad, self.fallback = U, bad, fallback
 
-    ``A``: the Gram matrix (a tensor) or a products object (``_DenseProducts`` / ``_ShardedProducts``).
-    ``overlap``: optional callable that enqueues independent GPU work; it is called once, right after the copy of
-    the small ``L`` factor to the host has been enqueued, so that work runs while the host does the ``k x k`` SVD
-    (otherwise ~1 ms of GPU idle time per batch).
-    """
-    prod = _DenseProducts(ops, A) if torch.is_tensor(A) else A
-    m = prod.m
-    with _Timer(ops, trace, "basis.randn"):
-        R = prod.draw(q_req, trace)
-    if cfg.GPU_RANGE_FINDER and q_req <= m:
-        with _Timer(ops, trace, "basis.gpu_range"):
-            flags = []
-            Q = prod.qr_of_product(R, flags, 1)
-            Q = prod.qr_of_product(Q, flags, 1, transpose=True)
-            Q = prod.qr_of_product(Q, flags, 1)
-            Q = prod.qr_of_product(Q, flags, 1, transpose=True)
-            Q = prod.qr_of_product(Q, flags, 2)                  # the basis that is actually used
-            # LQ of B = Q^T A ([k, m]) by CholeskyQR2 on its rows, formed on Y = B^T = A^T Q ([m, k]: tall, row-parallel):
-            #   B = L1 L2 Qb^T  ->  the left singular vectors of B are those of L = L1 L2
-            G1, G2, i1, i2, k = prod.lq_factors(Q)
-            L = _mm_splitk(ops, torch.tril(G1), torch.tril(G2), 1)
-            bad = torch.stack([f.reshape(()) for f in flags + [i1, i2]]).max()
-            both, ready = ops.to_host_async(torch.cat([L.reshape(-1), bad.to(torch.float64).reshape(1)]), "basisL")
-        if overlap is not None:
-            overlap()
-            overlap = None
-        yield ready                                            # the ONE wait of the whole range finder
-        with _Timer(ops, trace, "basis.host_svd", sync=False):
-            Lh = both[:k * k].reshape(k, k)
-            ok = int(both[k * k].item()) == 0
-            if ok:
-                with _lapack_threads(cfg.HOST_SVD_THREADS):
-                    Ub = torch.linalg.svd(Lh)[0]
-        if ok:
-            with _Timer(ops, trace, "basis.gemm"):
-                U = _mm_splitk(ops, Q, ops.to_device(Ub), 1)   # [m, k]
-                return (-1 * U.t()).contiguous()               # :30
-        if trace is not None:
-            trace.timers["basis.fallback"] = trace.timers.get("basis.fallback", 0) + 1
-        if notes is not None:
-            notes.append("range finder: a Cholesky pivot flagged a numerically rank-deficient panel (cond > ~1e6); the basis "
-                         "was recomputed with host Householder QR from the same Gaussian draw")
-    if overlap is not None:
-        overlap()
-    A = prod.full()                                            # (sharded: gathered -- the rare path)
+
+def _host_range_finder(ops, prod, R, trace=None):
+    """``torch.svd_lowrank``'s own steps with host Householder QR (the rare path: a CholeskyQR pivot flagged a numerically
+    rank-deficient panel, or q exceeds m) -> ``U [k, m]``."""
+    A = prod.full()                                            # (sharded: gathered)
     At = A.t()
     with _Timer(ops, trace, "basis.gemm"):
         X = ops.matmul(A, R)
@@ -410,9 +368,91 @@ def nystrom_basis_steps(ops, A, q_req: int, trace=None, overlap=None, notes=None
         return (-1 * U.t()).contiguous()                       # :30
 
 
+FALLBACK_NOTE = ("range finder: a Cholesky pivot flagged a numerically rank-deficient panel (cond > ~1e6); the basis "
+                 "was recomputed with host Householder QR from the same Gaussian draw")
+
+
+def nystrom_basis_steps(ops, A, q_req: int, trace=None, overlap=None, notes=None):
+    """``ker_svd_sparsify`` as a step generator -> :class:`BasisResult` (see :func:`nystrom_basis`).
+
+    What the reference's result depends on is only (i) the Gaussian draw and (ii) the *range* of each intermediate
+    ``Q``.  Two invariances of the recombination make the rest free:
+
+    * row-sign flips of ``U`` change nothing, bit for bit, and more generally (round 4) ANY orthogonal rotation of the rows of
+      ``U`` changes nothing but rounding: it turns every round's matrix ``X = [1 ; features]`` into ``diag(1, R) X`` -- same
+      ``X^T X``, same first row -- so the Golub-Kahan right vectors, i.e. LAPACK's right Householder reflectors whose trailing
+      rows are the null-space basis the elimination pivots on, are the same (``dlarfg`` maps ``(alpha, x)`` and ``(-alpha, -x)`` to
+      the same ``tau, v``: even the signs uniqueness leaves open do not matter).  ``tests/test_oracle.py::
+      test_selection_invariant_under_basis_rotations`` pins this on the reference's own op sequence;
+    * so the five Householder QRs (host LAPACK in the reference) become CholeskyQR on the GPU, and the final ``[q, m]`` SVD of
+      ``torch.svd_lowrank`` -- whose only effect on ``U`` is such a rotation of the orthonormal basis ``Q`` of the range -- is
+      SKIPPED: ``U = -Q^T``.  That removes the sixth ``[m, m] x [m, q]`` product (``B^T = A^T Q``), its LQ reduction, the q x q host
+      SVD and the batch's first host wait (``_config.BASIS_SVD = True`` restores them: round 3's path).
+
+    Without a host wait the pivot flags of the CholeskyQR passes cannot be looked at here: they travel with the result
+    (``BasisResult.bad``) and the batch checks them at its first read-back; a flagged basis (cond > ~1e6 panel) is recomputed by
+    ``fallback()`` -- host Householder QR + the reference's SVD, from the same Gaussian draw.
+
+    ``A``: the Gram matrix (a tensor) or a products object (``_DenseProducts`` / ``_ShardedProducts``).
+    ``overlap``: optional callable that enqueues independent GPU work; it is called once, behind the range finder's launches.
+    """
+    prod = _DenseProducts(ops, A) if torch.is_tensor(A) else A
+    m = prod.m
+    with _Timer(ops, trace, "basis.randn"):
+        R = prod.draw(q_req, trace)
+
+    def fallback():
+        if trace is not None:
+            trace.timers["basis.fallback"] = trace.timers.get("basis.fallback", 0) + 1
+        if notes is not None:
+            notes.append(FALLBACK_NOTE)
+        return _host_range_finder(ops, prod, R, trace)
+
+    if cfg.GPU_RANGE_FINDER and q_req <= m:
+        with _Timer(ops, trace, "basis.gpu_range"):
+            flags = []
+            Q = prod.qr_of_product(R, flags, 1)
+            Q = prod.qr_of_product(Q, flags, 1, transpose=True)
+            Q = prod.qr_of_product(Q, flags, 1)
+            Q = prod.qr_of_product(Q, flags, 1, transpose=True)
+            Q = prod.qr_of_product(Q, flags, 2)                  # the basis that is actually used
+            if not cfg.BASIS_SVD:
+                bad = torch.stack([f.reshape(()) for f in flags]).max().reshape(1)
+                U = (-1 * Q.t()).contiguous()                    # :30 (the rotation by the SVD's left factor is immaterial)
+                if overlap is not None:
+                    overlap()
+                return BasisResult(U, bad, fallback)
+            # round 3's path: LQ of B = Q^T A ([k, m]) by CholeskyQR2 on its rows, formed on Y = B^T = A^T Q ([m, k]: tall,
+            # row-parallel):  B = L1 L2 Qb^T  ->  the left singular vectors of B are those of L = L1 L2
+            G1, G2, i1, i2, k = prod.lq_factors(Q)
+            L = _mm_splitk(ops, torch.tril(G1), torch.tril(G2), 1)
+            bad = torch.stack([f.reshape(()) for f in flags + [i1, i2]]).max()
+            both, ready = ops.to_host_async(torch.cat([L.reshape(-1), bad.to(torch.float64).reshape(1)]), "basisL")
+        if overlap is not None:
+            overlap()
+            overlap = None
+        yield ready                                            # the ONE wait of the whole range finder
+        with _Timer(ops, trace, "basis.host_svd", sync=False):
+            Lh = both[:k * k].reshape(k, k)
+            ok = int(both[k * k].item()) == 0
+            if ok:
+                with _lapack_threads(cfg.HOST_SVD_THREADS):
+                    Ub = torch.linalg.svd(Lh)[0]
+        if ok:
+            with _Timer(ops, trace, "basis.gemm"):
+                U = _mm_splitk(ops, Q, ops.to_device(Ub), 1)   # [m, k]
+                return BasisResult((-1 * U.t()).contiguous())  # :30
+    if overlap is not None:
+        overlap()
+    return BasisResult(fallback() if (cfg.GPU_RANGE_FINDER and q_req <= m) else _host_range_finder(ops, prod, R, trace))
+
+
 def nystrom_basis(ops, A, q_req: int, trace=None, overlap=None):
-    """Blocking form of :func:`nystrom_basis_steps`."""
-    return drive(nystrom_basis_steps(ops, A, q_req, trace, overlap))
+    """Blocking form of :func:`nystrom_basis_steps` -> ``U`` (the pivot flag is read back and honoured here)."""
+    res = drive(nystrom_basis_steps(ops, A, q_req, trace, overlap))
+    if res.bad is not None and int(res.bad.cpu()[0]) != 0:
+        return res.fallback()
+    return res.U
 
 
 def make_cov_psd(A, max_iter: int = 10):

@@ -6,7 +6,7 @@ per-round reduction is ``Tchernychova_Lyons_CAR`` (:133-175).  What runs where:
 =======================================  ==========================================================
 step (reference lines)                   here
 =======================================  ==========================================================
-Gram + ``torch.svd_lowrank`` (:29)       ``_basis.nystrom_basis_steps`` (own GEMMs, CholeskyQR, one q x q host SVD)
+Gram + ``torch.svd_lowrank`` (:29)       ``_basis.nystrom_basis_steps`` (own GEMMs, CholeskyQR; no SVD: U = -Q^T)
 hot loop + tail + tot (:79-99)           a *block-sum strategy* (below) -> the round's ``(q+1) x S`` message
 round geometry (:76-78, :107-130)        closed form: on the host (``_partition``) or on the device
                                          (``basq_round_next_i64`` + the ``*_geo`` entries: no host wait per round)
@@ -238,15 +238,27 @@ class Batch:
         self._extend_basis(U)
         self._trace_phase("setup", t0)
         if self.plan.async_rounds and self.R > self.S:
-            violated = yield from self._async_rounds(pre)
+            outcome = yield from self._async_rounds(pre)         # False | True (a round violated the plan) | "basis"
             pre = None
-            if violated:
+            if outcome == "basis":
+                # the range finder's pivot flag arrived with the descriptor table: the rounds ran on a basis that is not
+                # orthonormal to round-off -- recompute it on the host, from the same Gaussian draw, and start over
+                self._recover_basis()
+                self._init_candidates()
+            elif outcome:
                 # an elimination failed or did not keep half of the sets while regrouped class messages were already
                 # enqueued: repeat the ROUNDS one read-back at a time -- same basis (no second draw from the generator),
                 # same results as that loop alone
                 self.notes.append("descriptor-driven rounds hit a round that did not keep exactly half of the sets; the "
                                   "rounds were repeated one read-back at a time")
                 self._init_candidates()
+        if self._basis_bad is not None:
+            # (a batch without descriptor-driven rounds: the flag is read on its own, before the first round uses the basis)
+            flag, ready = ops.to_host_async(self._basis_bad, "basis_flag")
+            yield ready
+            if float(flag[0]) != 0.0:
+                self._recover_basis()                            # (the round-1 block sums in `pre` do not depend on the basis)
+            self._basis_bad = None
         idx, w = yield from self._sync_rounds(pre)
         self._trace_phase("total", t_all)
         for msg in self.notes:
@@ -366,9 +378,13 @@ class Batch:
         return None, None
 
     def _basis_steps(self, late):
-        """Nystrom Gram + range finder -> ``U [q, m]`` (identical on every rank)."""
+        """Nystrom Gram + range finder -> ``U [q, m]`` (identical on every rank).  The range finder does not wait for the host
+        (``_basis.nystrom_basis_steps``): its pivot flag -- ``self._basis_bad``, a device scalar, identical on every rank -- is
+        read at the batch's first read-back, and ``_recover_basis`` recomputes a flagged basis on the host."""
         ops, comm, kernel, trace = self.ops, self.comm, self.kernel, self.trace
         m, q, pts_nys = self.m, self.q, self.pts_nys
+        self._basis_bad = self._basis_fallback = None
+        self._basis_on_rank0 = False
         if cfg.SHARDED_BASIS and comm.world > 1 and not self.plan.sober and not self.plan.opaque:
             # every rank builds its row block of the Gram matrix and takes part in the range finder (no broadcast of U)
             shards = initial_shards(m, comm.world)
@@ -379,30 +395,61 @@ class Batch:
             prod = _ShardedProducts(ops, comm, A_rows, shards, m, drawer=self.owner if self.draw_on_owner else 0,
                                     lockstep=not self.draw_on_owner)
             self.drew_test_matrix = comm.rank == prod.drawer or prod.lockstep
-            U = yield from nystrom_basis_steps(ops, prod, self.num_pts - 1, trace,
-                                               overlap=late, notes=self.notes)
-            return U
+            res = yield from nystrom_basis_steps(ops, prod, self.num_pts - 1, trace, overlap=late, notes=self.notes)
+            if res.bad is not None:
+                self._basis_bad, self._basis_fallback = res.bad.to(torch.float64), res.fallback
+            return res.U
+        self._basis_on_rank0 = True
+        bad = None
         if comm.rank == 0:
             with _Timer(ops, trace, "basis.gram"):
                 A = kernel.dense(ops, pts_nys, pts_nys, self.center)
                 if self.plan.sober:
                     A = make_cov_psd(A)
-            U = yield from nystrom_basis_steps(ops, A, self.num_pts - 1, trace, overlap=late, notes=self.notes)
+            res = yield from nystrom_basis_steps(ops, A, self.num_pts - 1, trace, overlap=late, notes=self.notes)
             del A
+            U, bad, self._basis_fallback = res.U, res.bad, res.fallback
             assert U.shape[0] == q
         else:
             U = ops.empty(q, m)
             _skip_test_matrix_draw(ops, m, self.num_pts - 1)    # keep this rank's global generator in step with rank 0
             if late is not None:
                 late()                                          # runs while rank 0 finishes the basis
-            if cfg.GPU_RANGE_FINDER and self.num_pts - 1 <= m:
-                # rank 0 yields exactly once on this path (the range finder's q x q SVD): yield at the same point, so that
-                # ``run_many`` resumes the batches -- and every rank enqueues its collectives -- in ONE order (ADVICE r3:
-                # with more jobs than slots the ranks otherwise disagree on which batch issues the next all-gather)
+            if cfg.BASIS_SVD and cfg.GPU_RANGE_FINDER and self.num_pts - 1 <= m:
+                # (round 3's path only) rank 0 yields exactly once for the range finder's q x q SVD: yield at the same point,
+                # so that ``run_many`` resumes the batches -- and every rank enqueues its collectives -- in ONE order
                 yield _recorded_event(ops)
         if comm.world > 1:
-            comm.broadcast(U)
+            # U and the pivot flag in ONE broadcast: row q of the buffer carries the flag
+            buf = ops.empty(q + 1, m)
+            if comm.rank == 0:
+                buf[:q] = U
+                buf[q].zero_()
+                if bad is not None:
+                    buf[q, 0:1] = bad.to(torch.float64)
+            comm.broadcast(buf)
+            U = buf[:q]
+            self._basis_bad = buf[q, 0:1] if (cfg.GPU_RANGE_FINDER and not cfg.BASIS_SVD and self.num_pts - 1 <= m) else None
+        elif bad is not None:
+            self._basis_bad = bad.to(torch.float64)
         return U
+
+    def _recover_basis(self):
+        """The range finder's pivot flag was set (a numerically rank-deficient panel): the basis again, by host Householder QR
+        and the reference's SVD from the same Gaussian draw -- every rank takes part (the sharded products gather the Gram
+        matrix; a basis computed on rank 0 is broadcast again)."""
+        ops, comm = self.ops, self.comm
+        if not self._basis_on_rank0:
+            U = self._basis_fallback()
+        else:
+            U = self._basis_fallback() if comm.rank == 0 else ops.empty(self.q, self.m)
+            if comm.world > 1:
+                U = U.contiguous()
+                comm.broadcast(U)
+        if self.trace is not None and self.trace.keep_tensors:
+            self.trace.U = U.clone()
+        self._basis_bad = None
+        self._extend_basis(U)
 
     def _extend_basis(self, U):
         """Extended contraction matrix: posterior correction / warping folded in by linearity --
@@ -563,8 +610,14 @@ class Batch:
             # must agree on repeating the rounds -- the flag becomes the maximum over the ranks
             flags = comm.all_gather(geo_t[r, 3:4].to(torch.float64))
             geo_t[r, 3:4] = flags.max().to(torch.int64).reshape(1)
-        table, ready = ops.to_host_async(geo_t[:r + 1], "geo_table")
+        bad64 = (self._basis_bad != 0).to(torch.int64) if self._basis_bad is not None else geo_t[0, 3:4] * 0
+        flat, ready = ops.to_host_async(torch.cat([geo_t[:r + 1].reshape(-1), bad64.reshape(1)]), "geo_table")
         yield ready                                              # the ONE wait of the asynchronous rounds
+        table = flat[:-1].view(r + 1, 8)
+        if self._basis_bad is not None:
+            self._basis_bad = None
+            if int(flat[-1]) != 0:
+                return "basis"
         row = table[r].tolist()
         if row[3] != 0:
             return True

@@ -15,6 +15,10 @@ OWN_RANGE_GEMM = True
 # CholeskyQR's factor + triangular solve in ONE launch whose solvers start on a column panel as soon as the factor has
 # published it (basq_cholqr_f64; same bits as the two separate launches).  False: the two launches of round 2.
 FUSED_CHOLQR = True
+# The final [q, m] SVD of torch.svd_lowrank only rotates the orthonormal basis Q of the range, and the recombination is invariant
+# under such rotations (tests/test_oracle.py::test_selection_invariant_under_basis_rotations): False (default) stops at U = -Q^T --
+# one [m, m] x [m, q] product, an LQ reduction, the q x q host SVD and the batch's first host wait less; True: round 3's path.
+BASIS_SVD = False
 # The GPU range finder may be switched off (tests compare both paths).
 GPU_RANGE_FINDER = True
 # Per-round null space (:140-143) from the bidiagonalisation's right reflectors on the GPU (basq_nullspace_f64)

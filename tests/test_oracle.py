@@ -75,6 +75,37 @@ def test_selection_invariant_under_basis_sign_flips():
     assert torch.equal(i0, i1) and torch.equal(w0, w1)
 
 
+@pytest.mark.parametrize("name", ["rbf_ragged", "rbf_1e4", "matern32_8e3", "cfg1_posterior_1e4"])
+def test_selection_invariant_under_basis_rotations(name):
+    """Round 4: the selection does not depend on WHICH orthonormal basis of the Nystrom feature space the rows of U are.
+
+    Left-multiplying U by an orthogonal R turns every round's matrix X = [1 ; features] into diag(1, R) X: the same Gram X^T X and
+    the same first row (the ones), hence the same Golub-Kahan right vectors -- LAPACK's right Householder reflectors, whose trailing
+    rows are the null-space basis the elimination pivots on, are unchanged even by the sign flips that uniqueness leaves open
+    (dlarfg: (alpha, x) -> (-alpha, -x) gives the same tau and v).  So the reference's own op sequence (the oracle) returns the same points
+    and the same weights (to rounding) for U and for R U -- which is why the engine may stop at the range finder's orthonormal basis Q and
+    skip the [q, m] SVD of ``torch.svd_lowrank`` (``_rchq.py:29``) altogether."""
+    from oracle.rchq_oracle import divide_and_recombine, nystrom_basis
+    from tests.cases import build_oracle_kernel
+
+    c = BY_NAME[name]
+    pts, nys = build_pool(c)
+    k, _ = build_oracle_kernel(c)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        torch.manual_seed(c["torch_seed"])
+        _, U = nystrom_basis(nys, c["n"] - 1, k)
+        w0, i0 = divide_and_recombine(pts, U, nys, k)
+        g = torch.Generator().manual_seed(5)
+        R = torch.linalg.qr(torch.randn(U.shape[0], U.shape[0], generator=g, dtype=torch.float64)).Q
+        w1, i1 = divide_and_recombine(pts, R @ U, nys, k)
+    finally:
+        torch.set_default_dtype(prev)
+    assert torch.equal(i0, i1)
+    assert ((w0 - w1).abs() / w0).max().item() <= 1e-8
+
+
 def test_tie_margins_recorded():
     """Golden cases are well separated from pivot ties (fp64 stability margin, SURVEY finding 3)."""
     from oracle.kernels_oracle import StationaryOracle
