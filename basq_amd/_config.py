@@ -37,9 +37,12 @@ SHARDED_CHOLQR = True            # multi-rank range finder: Gram product + trian
                                  # own rows (q x q partial Grams all-gathered, the q x q factor replicated); False: on all m rows
 SHARDED_BASIS = True             # multi-rank: split the range finder's Gram products over the ranks (False: rank 0 only)
 
-LATE_CHUNKS = 1                  # chunks of the round-1 block sums deferred behind the range finder (0 = none)
-LATE_CLASSES = 2                 # the same in class mode: the deferred classes (2 of 16 = 1.1 ms of GPU work) run while the
-                                 # host does the range finder's q x q SVD; A/B on MI355X: 42.9 / 43.35 / 43.15 batches/s for 1 / 2 / 3
+# Round-1 block sums deferred behind the range finder's launches, to run while the host did the range finder's q x q SVD (rounds
+# 2-3: LATE_CHUNKS = 1, LATE_CLASSES = 2).  Round 4: the range finder no longer waits for the host (BASIS_SVD above), and the 14 + 2
+# split only costs the 2-class launch its tail efficiency: 19.99 ms per batch with 2 deferred classes, 19.77 with none
+# (profiles/r06_q_late_classes_ab.txt).  With BASIS_SVD = True the old values are the better ones.
+LATE_CHUNKS = 0                  # chunks of the round-1 block sums deferred behind the range finder (0 = none)
+LATE_CLASSES = 0                 # the same in class mode
 LATE_CLASSES_PIPELINED = 0       # with several batches in flight another batch's kernels fill that gap: nothing is deferred
 
 # Residue-class block sums: evaluate the pairwise kernel once per EPOCH of log2(C) + 1 rounds.  The chunks of the block
