@@ -238,7 +238,7 @@ class _ShardedProducts:
     ``A`` is a kernel Gram matrix -- symmetric up to the rounding of its entries -- so ``A^T Q`` and ``(Q^T A)^T`` are
     computed as ``A Q`` as well: every product is ``A_rows @ Q`` on each rank followed by ONE all-gather of the
     ``[mr, q]`` blocks (1 MB per rank at the headline size), after which all ranks hold the same ``[m, q]`` matrix and
-    run the small replicated steps (CholeskyQR, LQ, the q x q host SVD) identically.  Only rank 0 consumes the RNG: the
+    run the small replicated steps (the q x q Cholesky factors) identically.  Only rank 0 consumes the RNG: the
     Gaussian test matrix is broadcast.  The deviation from the single-GPU arithmetic (A for A^T) is at rounding
     level, far inside the stability margin of the selection (SURVEY finding 3); the gloo tests pin the indices.
     """
