@@ -25,6 +25,7 @@ job_configs()     { timeout -k 10 900 python tools/bench_configs.py > "$out/conf
 job_concurrent()  { timeout -k 10 600 python tools/exp_concurrent.py --threads 2 --launches > "$out/concurrent.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/concurrent.txt" | cut -c1-200; return $rc; }
 job_concurrent3() { timeout -k 10 600 python tools/exp_concurrent.py --threads 3 > "$out/concurrent3.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/concurrent3.txt" | cut -c1-200; return $rc; }
 job_many()        { timeout -k 10 600 python tools/bench_many.py > "$out/many.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/many.txt" | cut -c1-250; return $rc; }
+job_many_small()  { ( timeout -k 10 300 python tools/bench_many.py --case rbf_2e4_defaults --batches 48 --inflight 2,4,6 2>&1 | grep -v amdgpu.ids; timeout -k 10 300 python tools/bench_many.py --case cfg2_rbf_1e5 --batches 32 --inflight 2,4 2>&1 | grep -v amdgpu.ids ) > "$out/many_small.txt" 2>&1; rc=$?; cut -c1-250 "$out/many_small.txt"; return $rc; }
 job_many_cfg4()   { timeout -k 10 600 python tools/bench_many.py --case cfg4_matern52_1e6_d32 --batches 8 --inflight 2,3 > "$out/many_cfg4.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/many_cfg4.txt" | cut -c1-250; return $rc; }
 job_many_cfg5m()  { timeout -k 10 600 python tools/bench_many.py --case cfg5m_wsabim_5e5 --batches 8 --inflight 2 > "$out/many_cfg5m.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/many_cfg5m.txt" | cut -c1-250; return $rc; }
 # A/B of a tuning-variant build of the library (BASQ_HIP_LIB): block-sum micro-benchmark A B A B, then the golden parity tests on B
