@@ -167,7 +167,8 @@ def _gaussian_test_matrix(ops, m, q, trace=None):
         u = ops.host_uniform(n, "rand_u")                        # CPU global generator
         ut = ops.host_uniform(16, "rand_ut") if n % 16 else None
     with _Timer(ops, trace, "basis.rand_h2d", sync=False):
-        R = ops.box_muller(ops.from_pinned(u), None if ut is None else ops.from_pinned(ut))
+        h2d = ops.from_pinned_side if (cfg.RAND_COPY_STREAM and hasattr(ops, "from_pinned_side")) else ops.from_pinned
+        R = ops.box_muller(h2d(u), None if ut is None else ops.from_pinned(ut))
     return R.view(m, q)
 
 

@@ -624,6 +624,21 @@ class HipOps:
         """Pinned host tensor -> device (asynchronous on the current stream)."""
         return buf.to(self.device, non_blocking=True)
 
+    def from_pinned_side(self, buf):
+        """The same copy on a stream of its own (the copy engine then runs beside whatever the launch stream is busy with --
+        the round-1 block sums, for the range finder's 8 MB of uniforms); the launch stream waits for it on the device."""
+        side = self.__dict__.get("_copy_stream")
+        if side is None:
+            side = self.__dict__["_copy_stream"] = torch.cuda.Stream(device=self.device)
+        with torch.cuda.stream(side):
+            t = buf.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        main = self.torch_stream()
+        main.wait_event(ev)
+        t.record_stream(main)
+        return t
+
     def from_host(self, t, tag="h2d"):
         """Host tensor -> device through a pinned staging buffer (asynchronous on the current stream)."""
         buf = self._pinned(t.shape, t.dtype, tag)

@@ -36,6 +36,7 @@ job_ab_sqpf()     { for i in 1 2; do for lib in libbasq_hip.so libbasq_hip_pf2.s
 job_ab_idle()     { B=${AB_LIB:-basq_amd/csrc/libbasq_hip_bpf2.so}; for i in 1 2; do for lib in basq_amd/csrc/libbasq_hip.so $B; do echo "== $lib" >> "$out/ab_idle.txt"; BASQ_HIP_LIB=$PWD/$lib timeout -k 10 200 python tools/idle_probe.py 2>&1 | grep -v amdgpu.ids | cut -c1-200 >> "$out/ab_idle.txt" || return 1; done; done; cat "$out/ab_idle.txt"; }
 job_fuzz_more()   { timeout -k 10 1100 python tools/fuzz_more.py --seeds ${FUZZ_SEEDS:-1 2 3} --count ${FUZZ_COUNT:-100} > "$out/fuzz_more.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/fuzz_more.txt" | cut -c1-400 | tail -40; return $rc; }
 job_ab_spin()     { timeout -k 10 400 python tools/ab_engine.py SPIN_WAIT 0 1 --reps 10 --visits 3 2>&1 | grep -v amdgpu.ids > "$out/ab_spin_wait.txt"; rc=$?; cat "$out/ab_spin_wait.txt"; return $rc; }
+job_ab_copy()     { timeout -k 10 400 python tools/ab_engine.py RAND_COPY_STREAM 0 1 --reps 10 --visits 3 2>&1 | grep -v amdgpu.ids > "$out/ab_rand_copy_stream.txt"; rc=$?; cat "$out/ab_rand_copy_stream.txt"; return $rc; }
 job_ab_late()     { timeout -k 10 400 python tools/ab_engine.py LATE_CLASSES 2 3 0 4 5 --reps 8 --visits 3 2>&1 | grep -v amdgpu.ids > "$out/ab_late_classes.txt"; rc=$?; cat "$out/ab_late_classes.txt"; return $rc; }
 job_sober_tut()   { timeout -k 10 600 python tools/bench_sober_tutorial.py > "$out/sober_tutorial.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/sober_tutorial.txt" | cut -c1-330; return $rc; }
 job_dense_sweep() { for S in 400 200; do for ns in 0 1 2 3 4 5; do BASQ_DBS_NS=$ns timeout -k 10 120 python tools/bench_dense_blocksum.py --S $S 2>&1 | grep -v amdgpu.ids >> "$out/dense_sweep.txt" || return 1; done; done; cat "$out/dense_sweep.txt"; }
