@@ -57,7 +57,7 @@ ASYNC_ROUNDS = True
 
 # The range finder's uniforms (8 MB at the headline size) on a copy stream, so that the transfer runs beside the round-1 block
 # sums instead of behind them (A/B: tools/ab_engine.py RAND_COPY_STREAM 0 1).
-RAND_COPY_STREAM = False
+RAND_COPY_STREAM = True
 
 # A synchronous batch waits for the GPU 5-6 times (range finder's SVD, the descriptor table, the last rounds): poll the event
 # instead of the runtime's blocking wait (A/B: tools/ab_engine.py SPIN_WAIT 0 1).

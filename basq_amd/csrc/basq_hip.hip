@@ -9,6 +9,7 @@
 //     A operand: A[row = c][k = g]      B operand: B[k = g][col = c]
 //     C/D:       D[reg r] = D[row = g + 4 r][col = c]
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -2007,6 +2008,272 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) car_eliminate_cluster_kernel(co
         }
         if (lane == 0) { info[0] = total; info[1] = status; }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Caratheodory elimination (BASQ/_rchq.py:146-175), one work-group, null vectors in REGISTERS, handed over in BLOCKS
+// (round 4; M <= 256, M - s <= 16 NR, (M - s)(M + 4) doubles of LDS).  Same arithmetic, op for op, as the kernels above.
+//   * wave w owns the CONSECUTIVE null vectors NR w .. NR w + NR - 1 (lane l holds columns l, l + 64, l + 128, l + 192) and
+//     its own copy of the weights.  It first CONSUMES the pivots of the earlier blocks -- one rank-1 update of its NR rows
+//     per pivot, the pivot column's entry by v_readlane, nothing but the published row read from LDS -- and then PRODUCES
+//     its block: ratio test on its next row, publish {row, j, alpha, 1 / phi_j, phi_j}, update its remaining rows -- a
+//     dependent chain that stays inside one wave for NR steps; a wave whose block is done leaves;
+//   * every pivot row is published ONCE into a slot of its own (the ring is the whole sequence: no slot is ever
+//     reused, so there is no flow control) behind one monotone counter; 16 B x M per step of LDS traffic instead of the
+//     24 B x M x (live rows) of car_eliminate_lds_kernel, which that kernel is bound by;
+//   * the producer and the wave that produces next run at raised priority (s_setprio): the consumers' updates fill the
+//     fp64 pipe, the chain of ratio tests must not queue behind them.
+// ------------------------------------------------------------------------------------------------
+#ifndef BASQ_CAR_EXP
+#define BASQ_CAR_EXP 0           // timing experiment only (1: consumers skip their updates -- the chain of ratio tests alone;
+#endif                           // results are wrong for any value but 0)
+template <bool TIGHT>
+__device__ __forceinline__ int ring_wait_gt(int* cnt, int k) {
+    unsigned spins = 0;
+    int c;
+    for (;;) {
+        c = __hip_atomic_load(cnt, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c > k) break;
+        if (++spins > BASQ_SPIN_LIMIT) {                           // never in a healthy run: every wave of the group gives up
+            __hip_atomic_store(cnt, BASQ_ABORT_COUNT, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            c = BASQ_ABORT_COUNT;
+            break;
+        }
+        if (!TIGHT) __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return c;
+}
+
+// RN(1 / b) and RN(a / b) by the instruction sequence of the IEEE expansion WITHOUT its scaling steps (v_div_scale / v_div_fmas /
+// v_div_fixup): the same bits whenever no scaling is due, i.e. for operands and quotients far from the ends of the exponent
+// range -- the domain div_by_recip already assumes.  No VCC hand-over, so independent divisions interleave.
+__device__ __forceinline__ double rcp_newton(double b) {
+    double y = __builtin_amdgcn_rcp(b);
+    double e = __builtin_fma(-b, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-b, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+__device__ __forceinline__ double div_newton(double a, double b, double y) {   // y = rcp_newton(b)
+    const double q0 = a * y;
+    const double r = __builtin_fma(-b, q0, a);
+    return __builtin_fma(r, y, q0);
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    const int BIG = -1;
+    int x = (int)v;
+    x = (int)min((unsigned)x, (unsigned)__builtin_amdgcn_update_dpp(BIG, x, 0x111, 0xf, 0xf, false));
+    x = (int)min((unsigned)x, (unsigned)__builtin_amdgcn_update_dpp(BIG, x, 0x112, 0xf, 0xf, false));
+    x = (int)min((unsigned)x, (unsigned)__builtin_amdgcn_update_dpp(BIG, x, 0x114, 0xf, 0xf, false));
+    x = (int)min((unsigned)x, (unsigned)__builtin_amdgcn_update_dpp(BIG, x, 0x118, 0xf, 0xf, false));
+    x = (int)min((unsigned)x, (unsigned)__builtin_amdgcn_update_dpp(BIG, x, 0x142, 0xa, 0xf, false));
+    x = (int)min((unsigned)x, (unsigned)__builtin_amdgcn_update_dpp(BIG, x, 0x143, 0xc, 0xf, false));
+    return (unsigned)__builtin_amdgcn_readlane(x, 63);
+}
+// minimum of a wave's doubles (NaN = no candidate; all NaN -> NaN) through their order-preserving 64-bit keys: two 32-bit DPP
+// reductions (each a single v_min_u32 per stage) instead of six stages of 64-bit moves + v_min_f64
+__device__ __forceinline__ double wave_min_key_f64(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned long long key = b ^ (((long long)b >> 63) | 0x8000000000000000ull);   // a NaN (positive, quiet) sorts above +inf
+    const unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
+    const unsigned hmin = wave_min_u32(hi);
+    const unsigned lmin = wave_min_u32(hi == hmin ? lo : 0xffffffffu);
+    const unsigned long long kmin = ((unsigned long long)hmin << 32) | lmin;
+    const unsigned long long bmin = (kmin >> 63) ? (kmin ^ 0x8000000000000000ull) : ~kmin;
+    return __longlong_as_double((long long)bmin);
+}
+
+template <int NR>
+__global__ void __launch_bounds__(1024) car_eliminate_ring_kernel(const double* __restrict__ PhiT_g,
+                                                                  const double* __restrict__ mu_g, int M, int s,
+                                                                  int* __restrict__ keep_rank, int* __restrict__ kept,
+                                                                  double* __restrict__ w_star, int* __restrict__ info) {
+#pragma clang fp contract(off)   // plain operators: the reference rounds after every mul / sub / div
+    // A wave issues at most one instruction per 4 cycles, whatever its kind, and dependent fp64 operations wait for each other:
+    // the chain of ratio tests is bound by the instructions (and their latencies) between two publications.  Hence: no
+    // dead-column mask (an eliminated column's weight becomes NaN, which the minimum skips and `> 0` rejects); divisions
+    // without the scaling steps (they interleave); the wave minimum on 32-bit keys; the argmin's index from four ballots on the
+    // scalar unit; ONE wave-uniform branch per pivot (the v_readlane's of the pivot column); a row is published before the
+    // reciprocal of its pivot exists (every consumer computes its own); no guards inside the block, so that the updates of the
+    // producer's later rows fill the latency of its next test.
+    constexpr int NV = 4;
+    extern __shared__ __attribute__((aligned(16))) double ring[];   // [nrows][M + 4]: published rows + {alpha, phi_j, j, -}
+    __shared__ int count_l;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nrows = M - s, stride = M + 4;
+    const int row0 = wv * NR;
+    const int w_last = (nrows - 1) / NR;                            // owner of the last null vector: writes the outcome
+    const double INF = __builtin_huge_val(), DEAD = __builtin_nan("");
+    if (threadIdx.x == 0) count_l = 0;
+    double a[NR][NV], mu[NV];
+    bool valid[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        valid[k] = lane + 64 * k < M;
+        mu[k] = valid[k] ? mu_g[lane + 64 * k] : DEAD;              // padding: never chosen, never kept
+    }
+#pragma unroll
+    for (int jr = 0; jr < NR; ++jr)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int r = row0 + jr;
+            a[jr][k] = (r < nrows && valid[k]) ? PhiT_g[(size_t)r * M + lane + 64 * k] : 0.0;   // (rows past the end: zeros, updated
+        }                                                                                       //  like the others, never tested)
+    __syncthreads();
+    if (row0 >= nrows) return;                                      // no null vector of its own (no barrier below)
+    int* count = &count_l;
+    int status = 0;
+    const int my_rows = (nrows - row0 < NR) ? (nrows - row0) : NR;  // >= 1, wave-uniform
+    // the entries of rows FIRST.. in the pivot column lane_j + 64 kj: ONE wave-uniform branch per pivot
+    auto pivot_column = [&](auto FIRSTc, int kj, int lane_j, double (&pj)[NR]) {
+        constexpr int FIRST = decltype(FIRSTc)::value;
+        switch (kj) {
+            case 0:
+#pragma unroll
+                for (int jr = FIRST; jr < NR; ++jr) pj[jr] = readlane_f64(a[jr][0], lane_j);
+                break;
+            case 1:
+#pragma unroll
+                for (int jr = FIRST; jr < NR; ++jr) pj[jr] = readlane_f64(a[jr][1], lane_j);
+                break;
+            case 2:
+#pragma unroll
+                for (int jr = FIRST; jr < NR; ++jr) pj[jr] = readlane_f64(a[jr][2], lane_j);
+                break;
+            default:
+#pragma unroll
+                for (int jr = FIRST; jr < NR; ++jr) pj[jr] = readlane_f64(a[jr][3], lane_j);
+                break;
+        }
+    };
+    // one pivot applied to the weights and to rows FIRST.. of this wave (:158-171)
+    auto apply = [&](auto FIRSTc, const double (&phi)[NV], const double (&pj)[NR], double aj, int kj, int lane_j, double phij) {
+        constexpr int FIRST = decltype(FIRSTc)::value;
+        const double rphij = div_newton(1.0, phij, rcp_newton(phij));   // RN(1/phi_j): the pivot's reciprocal
+        const bool mine = lane == lane_j;
+#pragma unroll
+        for (int kk = 0; kk < NV; ++kk) {
+            const double step = aj * phi[kk];
+            mu[kk] = (mine && kk == kj) ? DEAD : (mu[kk] - step);   // (the reference: mu[j] = 0, Phi[j, :] = 0 -- never positive again)
+        }
+#pragma unroll
+        for (int jr = FIRST; jr < NR; ++jr)
+#pragma unroll
+            for (int kk = 0; kk < NV; ++kk) {
+                const double o = div_by_recip(pj[jr] * phi[kk], phij, rphij);           // == (pj * phi) / phij, bit for bit
+                a[jr][kk] = a[jr][kk] - o;
+            }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    // ---- consume the pivots of the earlier blocks ----
+    for (int k = 0; k < row0; ++k) {
+        const bool next = (k / NR) + 1 == wv;                      // this wave produces next: it must not fall behind
+        if (next) __builtin_amdgcn_s_setprio(2);
+        const int seen = next ? ring_wait_gt<true>(count, k) : ring_wait_gt<false>(count, k);
+        if (seen >= BASQ_ABORT_COUNT) { status = 2; break; }
+        BASQ_NS_STAMP(k, 5);
+        const double* slot = ring + (size_t)k * stride;
+        double phi[NV], hdr[3];
+#pragma unroll
+        for (int kk = 0; kk < NV; ++kk) phi[kk] = valid[kk] ? slot[lane + 64 * kk] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) hdr[u] = slot[M + u];
+        const double aj = hdr[0], phij = hdr[1];
+        const int j = __builtin_amdgcn_readfirstlane((int)__double_as_longlong(hdr[2]));
+        if (j == 0x7fffffff) { status = 1; break; }               // uniform: no positive entry (the reference raises)
+#if !(BASQ_CAR_EXP & 1)
+        double pj[NR];
+        pivot_column(I0(), j >> 6, j & 63, pj);
+        apply(I0(), phi, pj, aj, j >> 6, j & 63, phij);
+#endif
+        BASQ_NS_STAMP(k, 6);
+    }
+    // ---- produce this wave's block ----
+    if (status == 0) {
+        __builtin_amdgcn_s_setprio(3);
+        auto produce = [&](auto JRc) -> bool {                     // -> false: no positive entry (status 1)
+            constexpr int JR = decltype(JRc)::value;
+            const int kp = row0 + JR;
+            BASQ_NS_STAMP(kp, 0);
+            // ratio test (:148-152) on a[JR], which has every earlier pivot applied
+            double av[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const double q = div_newton(mu[k], a[JR][k], rcp_newton(a[JR][k]));    // NaN for an eliminated / padding column
+                av[k] = (a[JR][k] > 0.0) ? q : INF;
+            }
+            const double aj = wave_min_key_f64(fmin(fmin(av[0], av[1]), fmin(av[2], av[3])));
+            BASQ_NS_STAMP(kp, 1);
+            const bool found = aj < INF;
+            double* slot = ring + (size_t)kp * stride;
+            if (!found) {
+                if (lane < 3) slot[M + lane] = __longlong_as_double(0x7fffffffLL);
+                counter_publish(count, kp + 1, lane);
+                return false;
+            }
+            // first index of the minimum (torch.argmin, :152): column = lane + 64 k, so the lowest slot with a hit wins
+            const unsigned long long b0 = __ballot(av[0] == aj), b1 = __ballot(av[1] == aj), b2 = __ballot(av[2] == aj),
+                                     b3 = __ballot(av[3] == aj);
+            const int kj = b0 ? 0 : b1 ? 1 : b2 ? 2 : 3;
+            const unsigned long long bj = b0 ? b0 : b1 ? b1 : b2 ? b2 : b3;
+            const int lane_j = (int)__builtin_ctzll(bj);
+            const int j = 64 * kj + lane_j;
+            double pj[NR];
+            pivot_column(JRc, kj, lane_j, pj);                     // pj[JR] = the pivot itself
+            const double phij = pj[JR];
+            BASQ_NS_STAMP(kp, 2);
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+                if (valid[k]) slot[lane + 64 * k] = a[JR][k];
+            const double hv = (lane == 0) ? aj : (lane == 1) ? phij : __longlong_as_double((long long)j);
+            if (lane < 3) slot[M + lane] = hv;
+            counter_publish(count, kp + 1, lane);
+            BASQ_NS_STAMP(kp, 3);
+            double phic[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) phic[k] = a[JR][k];
+            apply(std::integral_constant<int, JR + 1>(), phic, pj, aj, kj, lane_j, phij);
+            BASQ_NS_STAMP(kp, 4);
+            return true;
+        };
+        bool ok = true;
+        if (ok && my_rows > 0) ok = produce(std::integral_constant<int, 0>());
+        if constexpr (NR > 1) { if (ok && my_rows > 1) ok = produce(std::integral_constant<int, 1>()); }
+        if constexpr (NR > 2) { if (ok && my_rows > 2) ok = produce(std::integral_constant<int, 2>()); }
+        if constexpr (NR > 3) { if (ok && my_rows > 3) ok = produce(std::integral_constant<int, 3>()); }
+        if constexpr (NR > 4) { if (ok && my_rows > 4) ok = produce(std::integral_constant<int, 4>()); }
+        if constexpr (NR > 5) { if (ok && my_rows > 5) ok = produce(std::integral_constant<int, 5>()); }
+        if constexpr (NR > 6) { if (ok && my_rows > 6) ok = produce(std::integral_constant<int, 6>()); }
+        static_assert(NR <= 7, "unrolled by hand up to 7 rows per wave");
+        if (!ok) status = 1;
+        __builtin_amdgcn_s_setprio(0);
+    }
+    if (wv != w_last) return;
+    // survivors: mu > 0 (:173-174), ascending column order (column = lane + 64 k)
+    unsigned long long bal[NV];
+    bool keep[NV];
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        keep[k] = mu[k] > 0.0;                                      // (false for NaN: eliminated and padding columns)
+        bal[k] = __ballot(keep[k]);
+        total += __popcll(bal[k]);
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int col = lane + 64 * k, rank = base + __popcll(bal[k] & below);
+        if (col < M) {
+            keep_rank[col] = keep[k] ? rank : -1;
+            if (keep[k]) { kept[rank] = col; w_star[rank] = mu[k]; }
+        }
+        base += __popcll(bal[k]);
+    }
+    if (lane == 0) { info[0] = total; info[1] = status; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -4486,6 +4753,28 @@ int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32
         return BASQ_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int nrows = M - s;
+    {
+        // one CU, null vectors in registers, handed over in blocks of NR rows (BASQ_CAR_RING=0: the LDS-resident kernel)
+        static const int ring_env = [] { const char* e = getenv("BASQ_CAR_RING"); return e ? atoi(e) : 1; }();
+        const size_t ring_lds = (size_t)nrows * (M + 4) * sizeof(double);
+        if (ring_env && nrows >= 1 && M <= 256 && nrows <= 16 * 7 && ring_lds <= 163328) {   // 163840 B per CU - static LDS
+            if (nrows <= 16 * 4) {
+                if (hipFuncSetAttribute((const void*)car_eliminate_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)ring_lds) != hipSuccess)
+                    return BASQ_ELAUNCH;
+                hipLaunchKernelGGL(car_eliminate_ring_kernel<4>, dim3(1), dim3(1024), ring_lds, st, PhiT, mu, M, s, keep_rank,
+                                   kept, w_star, info);
+            } else {
+                if (hipFuncSetAttribute((const void*)car_eliminate_ring_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)ring_lds) != hipSuccess)
+                    return BASQ_ELAUNCH;
+                hipLaunchKernelGGL(car_eliminate_ring_kernel<7>, dim3(1), dim3(1024), ring_lds, st, PhiT, mu, M, s, keep_rank,
+                                   kept, w_star, info);
+            }
+            BASQ_CHECK_LAUNCH();
+            return BASQ_OK;
+        }
+    }
 #if BASQ_CAR_CLUSTER
     constexpr int T = BASQ_WPG * 64;
     const bool fits_lds = (size_t)nrows * M * sizeof(double) <= 162560;
