@@ -2159,16 +2159,40 @@ __global__ void __launch_bounds__(1024) car_eliminate_ring_kernel(const double* 
             const double step = aj * phi[kk];
             mu[kk] = (mine && kk == kj) ? DEAD : (mu[kk] - step);   // (the reference: mu[j] = 0, Phi[j, :] = 0 -- never positive again)
         }
+        // stage by stage over two rows x four columns, the stages fenced for the scheduler: eight independent operations between
+        // two dependent ones (a wave issues one instruction per four cycles; an fp64 result takes longer than that to come back)
 #pragma unroll
-        for (int jr = FIRST; jr < NR; ++jr)
+        for (int j0 = FIRST; j0 < NR; j0 += 2) {
+            constexpr int G = 2 * NV;
+            double t[G], q0[G], rr[G];
 #pragma unroll
-            for (int kk = 0; kk < NV; ++kk) {
-                const double o = div_by_recip(pj[jr] * phi[kk], phij, rphij);           // == (pj * phi) / phij, bit for bit
-                a[jr][kk] = a[jr][kk] - o;
+            for (int g = 0; g < G; ++g) {
+                const int jr = j0 + g / NV;
+                if (jr < NR) t[g] = pj[jr] * phi[g % NV];
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                if (j0 + g / NV < NR) q0[g] = t[g] * rphij;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                if (j0 + g / NV < NR) rr[g] = __builtin_fma(-phij, q0[g], t[g]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+                if (j0 + g / NV < NR) q0[g] = __builtin_fma(rr[g], rphij, q0[g]);       // == (pj * phi) / phij, bit for bit (div_by_recip)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int jr = j0 + g / NV;
+                if (jr < NR) a[jr][g % NV] = a[jr][g % NV] - q0[g];
+            }
+        }
     };
     using I0 = std::integral_constant<int, 0>;
     // ---- consume the pivots of the earlier blocks ----
+    // (raising the later half of the waves -- the longer backlogs -- above the earlier half was tried: 123.2 vs 122.1 us)
     for (int k = 0; k < row0; ++k) {
         const bool next = (k / NR) + 1 == wv;                      // this wave produces next: it must not fall behind
         if (next) __builtin_amdgcn_s_setprio(2);

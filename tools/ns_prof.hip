@@ -27,7 +27,7 @@ int main(int argc, char** argv) {
     hipEventCreate(&e1);
     for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        int rc = basq_nullspace_f64(dX, m, n, dV, dtau, dP, nullptr, nullptr);
+        int rc = basq_nullspace_f64(dX, m, n, dV, dtau, dP, nullptr, nullptr, nullptr);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
@@ -94,7 +94,7 @@ int main(int argc, char** argv) {
         hipMalloc(&dkept, n * 4);
         hipMalloc(&dinfo, 8);
         hipMemcpy(dmu, mu.data(), n * 8, hipMemcpyHostToDevice);
-        basq_nullspace_f64(dX, m, n, dV, dtau, dP, nullptr, nullptr);
+        basq_nullspace_f64(dX, m, n, dV, dtau, dP, nullptr, nullptr, nullptr);
         hipEventRecord(e0);
         int rc = basq_car_eliminate_f64(dP, dmu, n, m, dkr, dkept, dw, dinfo, nullptr, nullptr);
         hipEventRecord(e1);
