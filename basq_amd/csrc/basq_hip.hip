@@ -2592,6 +2592,9 @@ __device__ __forceinline__ void wave_sum4(double& x0, double& x1, double& x2, do
 //       barrier): sum the 16 partials, w = u^T A, update row t+1 with H_t and form G_{t+1} from the result
 //       -> v_{t+1}, tau_{t+1}.
 // Same reflectors as dgebd2; only the association of the sums differs (agreement with LAPACK ~1e-14).
+#ifndef BASQ_NS_EXP
+#define BASQ_NS_EXP 0            // timing experiments only (bits: 1 = four of the sixteen partial rows summed, 2 = no norm / reflector
+#endif                           // parameters in make_right, 4 = no wave sums of the row dots, 8 = no partial-row accumulation)
 template <int NV, int NREG>
 __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const double* __restrict__ X, int m, int n,
                                                                      double* __restrict__ V,
@@ -2605,6 +2608,21 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
     __shared__ double sspart[NW];
     __shared__ double par[4];             // tau_t, tauq_{t-1}, u-scale_{t-1}, alpha of H_t
     __shared__ int hready;                // = t + 1 once wave 1 has published H_t's parameters
+#ifdef BASQ_NS_PROF
+    // phase clock of tools/ns_prof.hip: cycles per phase summed over all steps in SCALAR registers (the kernel sits at its VGPR
+    // ceiling: stamps that touch a vector register make it spill ~370 of them and run 7 x slower)
+    unsigned long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev));
+#define BASQ_NS_LSTAMP(t, slot)                                                                 \
+    do {                                                                                       \
+        unsigned long long now_;                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_));                      \
+        tacc[slot] += now_ - tprev;                                                            \
+        tprev = now_;                                                                          \
+    } while (0)
+#else
+#define BASQ_NS_LSTAMP(t, slot) do { } while (0)
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) hready = 0;
     // slot k of this lane holds column COL(k); column c sits in lane (c & 127) >> 1, slot (c & 1) + 2 (c >> 7)
@@ -2630,10 +2648,15 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
             if (c > t) ss += rn[k] * rn[k];
             if (k == tk) al = rn[k];
         }
+#if BASQ_NS_EXP & 2
+        const double alpha = al;
+        double tau = 1.5, scale = 0.1 + ss * 1e-30 + alpha * 1e-30;
+#else
         ss = wave_sum(ss);
         const double alpha = readlane_f64(al, tl);
         double tau, scale;
         householder_params_fast(alpha, ss, tau, scale);
+#endif
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             const int c = BASQ_COL(k);
@@ -2652,7 +2675,7 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
     __syncthreads();
     for (int t = 0; t + 1 < m; ++t) {
         const int tk = (t & 1) + 2 * (t >> 7), tl = (t & 127) >> 1;
-        BASQ_NS_STAMP(t, 0);
+        BASQ_NS_LSTAMP(t, 0);
         {   // ---- phase A ----
             const double tau = par[0], kappa = par[1] * par[2];     // tauq * u-scale of H_{t-1}
             double vr[NV], wc[NV], pw[NV];
@@ -2680,7 +2703,10 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
                         }
                     }
                 }
+#if !(BASQ_NS_EXP & 4)
                 wave_sum4(dot[0], dot[1], dot[2], dot[3]);
+#endif
+                if (g == 0) BASQ_NS_LSTAMP(t, 1);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int jr = 4 * g + j, r = wv + NW * jr;
@@ -2699,20 +2725,23 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
                             for (int k = 0; k < NV; ++k) r1sh[BASQ_COL(k)] = a[jr][k];
                             if (lane == 0) par[3] = cr;
                         } else {
+#if !(BASQ_NS_EXP & 8)
 #pragma unroll
                             for (int k = 0; k < NV; ++k) pw[k] += cr * a[jr][k];
                             ssp += cr * cr;
+#endif
                         }
                     }
                 }
             }
+            BASQ_NS_LSTAMP(t, 2);
 #pragma unroll
             for (int k = 0; k < NV; ++k) wpart[wv * NC + BASQ_COL(k)] = pw[k];
             if (lane == 0) sspart[wv] = ssp;
         }
-        BASQ_NS_STAMP(t, 1);
+        BASQ_NS_LSTAMP(t, 3);
         __syncthreads();
-        BASQ_NS_STAMP(t, 2);
+        BASQ_NS_LSTAMP(t, 4);
         if (wv == 1) {   // ---- phase B, wave 1: H_t's parameters, concurrently with wave 0's partial-row sum ----
             double ss2 = 0.0;
 #pragma unroll
@@ -2724,9 +2753,9 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
                 par[2] = uscale;
                 __hip_atomic_store(&hready, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+            BASQ_NS_LSTAMP(t, 5);
         }
         if (wv == 0) {   // ---- phase B, wave 0 ----
-            BASQ_NS_STAMP(t, 4);
             double rn[NV], accs[NV];
 #pragma unroll
             for (int k = 0; k < NV; ++k) accs[k] = 0.0;
@@ -2739,7 +2768,7 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
                 const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double*)wpart +
                                       (unsigned)lane * 16u;
 #pragma unroll
-                for (int w0 = 0; w0 < NW; w0 += 4) {
+                for (int w0 = 0; w0 < ((BASQ_NS_EXP & 1) ? 4 : NW); w0 += 4) {
                     d2_t v0, v1, v2, v3, v4, v5, v6, v7;
                     asm volatile(
                         "ds_read_b128 %0, %8 offset:%9\n\t"
@@ -2762,7 +2791,7 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
                     accs[0] += v6.x; accs[1] += v6.y; accs[2] += v7.x; accs[3] += v7.y;
                 }
             }
-            BASQ_NS_STAMP(t, 5);
+            BASQ_NS_LSTAMP(t, 6);
             {   // spin until wave 1 has published (it always gets there: same loop, same t).  One asm statement: a C++
                 // loop at this point makes the register allocator spill ~500 B per lane in the whole kernel.
                 int seen;
@@ -2777,6 +2806,7 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
                     : "v"(faddr), "s"(t + 1)
                     : "vcc", "memory");
             }
+            BASQ_NS_LSTAMP(t, 7);
             const double tauq = par[1], uscale = par[2];
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
@@ -2786,12 +2816,17 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
                 wsh[c] = wv_c;
                 rn[k] = r1 - tauq * wv_c;                                       // row t+1 after H_t
             }
-            BASQ_NS_STAMP(t, 6);
+            BASQ_NS_LSTAMP(t, 8);
             make_right(rn, t + 1);
+            BASQ_NS_LSTAMP(t, 9);
         }
-        BASQ_NS_STAMP(t, 3);
         __syncthreads();
     }
+#ifdef BASQ_NS_PROF
+    if (lane == 0)
+        for (int i = 0; i < 10; ++i) g_ns_prof[wv * 10 + i] = (long long)tacc[i];
+#endif
+#undef BASQ_NS_LSTAMP
 #undef BASQ_COL
 }
 

@@ -221,8 +221,14 @@ int64_t basq_reduction_ws_doubles(int32_t s, int32_t M);
  * in-place update of earlier versions cost every caller a copy per round -- the reduced weights are w_star).  Outputs: keep_rank[M] (rank among survivors
  * or -1), kept[<=s] ascending survivor ids, w_star[<=s], info[0] = n_keep, info[1] = status
  * (0 ok, 1 = a null vector had no positive entry: the reference would raise at :152; 2 = a cluster kernel's
- * bounded spin timed out -- never in a healthy run).  Null vectors live in registers (one work-group for M <= 256,
- * an 8-work-group cluster through `ws` for M <= 512, see basq_reduction_ws_doubles; ws may be NULL otherwise); M <= 1024.
+ * bounded spin timed out -- never in a healthy run).  Null vectors live in registers: for M <= 256 and M - s <= 112 one
+ * work-group whose 16 waves own CONSECUTIVE null vectors (seven each) -- a wave consumes the pivots published before its block
+ * (one rank-1 update of its rows per pivot) and then runs the ratio tests of its own block without leaving the wave; every pivot
+ * row is written to LDS once (car_eliminate_ring_kernel, round 4: 122 us against 174 at 100 x 200); an 8-work-group cluster
+ * through `ws` for M <= 512 (see basq_reduction_ws_doubles; ws may be NULL otherwise); M <= 1024.  The divisions of the ratio
+ * test are the IEEE expansion without its scaling steps (operands and quotients far from the ends of the exponent range -- what
+ * the Markstein quotient of the rank-1 update has always assumed); BASQ_CAR_RING=0 in the environment selects the LDS-resident
+ * kernel of rounds 1-3 (A/B).
  */
 int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32_t* keep_rank, int32_t* kept,
                            double* w_star, int32_t* info, double* ws, void* stream);
