@@ -2592,6 +2592,11 @@ __device__ __forceinline__ void wave_sum4(double& x0, double& x1, double& x2, do
 //       barrier): sum the 16 partials, w = u^T A, update row t+1 with H_t and form G_{t+1} from the result
 //       -> v_{t+1}, tau_{t+1}.
 // Same reflectors as dgebd2; only the association of the sums differs (agreement with LAPACK ~1e-14).
+#ifndef BASQ_NS_EARLY_H
+#define BASQ_NS_EARLY_H 0        // 1: every wave but wave 0 applies the left reflector H_t beside wave 0's make_right instead of at the
+#endif                           // head of the next phase A.  Measured (round 4, 100 x 200, null space per call): 280.0 us without,
+                                 // 292.6 with, 289.8 with s_sleep in the spin, 299.5 with the serial waves at raised priority; 9 spilled
+                                 // registers.  Phase A is not shortened by the FMAs it loses, the serial wave is slowed by its SIMD mates.
 #ifndef BASQ_NS_EXP
 #define BASQ_NS_EXP 0            // timing experiments only (bits: 1 = four of the sixteen partial rows summed, 2 = no norm / reflector
 #endif                           // parameters in make_right, 4 = no wave sums of the row dots, 8 = no partial-row accumulation)
@@ -2608,6 +2613,7 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
     __shared__ double sspart[NW];
     __shared__ double par[4];             // tau_t, tauq_{t-1}, u-scale_{t-1}, alpha of H_t
     __shared__ int hready;                // = t + 1 once wave 1 has published H_t's parameters
+    __shared__ int wready;                // = t + 1 once wave 0 has published w of H_t (BASQ_NS_EARLY_H)
 #ifdef BASQ_NS_PROF
     // phase clock of tools/ns_prof.hip: cycles per phase summed over all steps in SCALAR registers (the kernel sits at its VGPR
     // ceiling: stamps that touch a vector register make it spill ~370 of them and run 7 x slower)
@@ -2624,7 +2630,7 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
 #define BASQ_NS_LSTAMP(t, slot) do { } while (0)
 #endif
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) hready = 0;
+    if (tid == 0) { hready = 0; wready = 0; }
     // slot k of this lane holds column COL(k); column c sits in lane (c & 127) >> 1, slot (c & 1) + 2 (c >> 7)
 #define BASQ_COL(k) (2 * lane + ((k) & 1) + 128 * ((k) >> 1))
     double a[NG * 4][NV], cprev[NG * 4];
@@ -2695,12 +2701,22 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
                     const int jr = 4 * g + j, r = wv + NW * jr;
                     dot[j] = 0.0;
                     if (jr < NREG && r > t && r < m) {              // wave-uniform
+#if BASQ_NS_EARLY_H
+                        if (wv == 0) {                              // (the other waves applied H_{t-1} beside make_right)
+                            const double tu = kappa * cprev[jr];
+#pragma unroll
+                            for (int k = 0; k < NV; ++k) a[jr][k] -= tu * wc[k];
+                        }
+#pragma unroll
+                        for (int k = 0; k < NV; ++k) dot[j] += a[jr][k] * vr[k];
+#else
                         const double tu = kappa * cprev[jr];        // H_{t-1}: tauq u_r, u_r = column_{t-1}[r] * scale
 #pragma unroll
                         for (int k = 0; k < NV; ++k) {
                             a[jr][k] -= tu * wc[k];
                             dot[j] += a[jr][k] * vr[k];
                         }
+#endif
                     }
                 }
 #if !(BASQ_NS_EXP & 4)
@@ -2742,6 +2758,9 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
         BASQ_NS_LSTAMP(t, 3);
         __syncthreads();
         BASQ_NS_LSTAMP(t, 4);
+#if BASQ_NS_EARLY_H
+        if (wv <= 1) __builtin_amdgcn_s_setprio(3);             // the serial phase ahead of the other waves' early H update
+#endif
         if (wv == 1) {   // ---- phase B, wave 1: H_t's parameters, concurrently with wave 0's partial-row sum ----
             double ss2 = 0.0;
 #pragma unroll
@@ -2816,10 +2835,47 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
                 wsh[c] = wv_c;
                 rn[k] = r1 - tauq * wv_c;                                       // row t+1 after H_t
             }
+#if BASQ_NS_EARLY_H
+            if (lane == 0) __hip_atomic_store(&wready, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
             BASQ_NS_LSTAMP(t, 8);
             make_right(rn, t + 1);
             BASQ_NS_LSTAMP(t, 9);
         }
+#if BASQ_NS_EARLY_H
+        else {
+            // every other wave: H_t on its rows r > t + 1 NOW, beside wave 0's make_right, instead of at the head of the next
+            // phase A (w and the parameters are final once wready = t + 1)
+            {
+                int seen;
+                const unsigned faddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)&wready;
+                asm volatile(
+                    "BASQ_WREADY_SPIN_%=:\n\t"
+                    "s_sleep 1\n\t"
+                    "ds_read_b32 %0, %1\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    "v_cmp_ne_u32_e32 vcc, %2, %0\n\t"
+                    "s_cbranch_vccnz BASQ_WREADY_SPIN_%="
+                    : "=&v"(seen)
+                    : "v"(faddr), "s"(t + 1)
+                    : "vcc", "memory");
+            }
+            const double kap = par[1] * par[2];
+            double wc2[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) wc2[k] = wsh[BASQ_COL(k)];
+#pragma unroll
+            for (int jr = 0; jr < NREG; ++jr) {
+                const int r = wv + NW * jr;
+                if (r > t + 1 && r < m) {                           // wave-uniform
+                    const double tu = kap * cprev[jr];
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) a[jr][k] -= tu * wc2[k];
+                }
+            }
+        }
+        if (wv <= 1) __builtin_amdgcn_s_setprio(0);
+#endif
         __syncthreads();
     }
 #ifdef BASQ_NS_PROF
