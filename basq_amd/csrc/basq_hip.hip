@@ -2599,7 +2599,8 @@ __device__ __forceinline__ void wave_sum4(double& x0, double& x1, double& x2, do
                                  // registers.  Phase A is not shortened by the FMAs it loses, the serial wave is slowed by its SIMD mates.
 #ifndef BASQ_NS_EXP
 #define BASQ_NS_EXP 0            // timing experiments only (bits: 1 = four of the sixteen partial rows summed, 2 = no norm / reflector
-#endif                           // parameters in make_right, 4 = no wave sums of the row dots, 8 = no partial-row accumulation)
+#endif                           // parameters in make_right, 4 = no wave sums of the row dots, 8 = no partial-row accumulation, 16 = no left-reflector
+                                 // update, 32 = no right-reflector update / column read-back, 64 = a quarter of the dot product)
 template <int NV, int NREG>
 __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const double* __restrict__ X, int m, int n,
                                                                      double* __restrict__ V,
@@ -2713,8 +2714,14 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
                         const double tu = kappa * cprev[jr];        // H_{t-1}: tauq u_r, u_r = column_{t-1}[r] * scale
 #pragma unroll
                         for (int k = 0; k < NV; ++k) {
+#if !(BASQ_NS_EXP & 16)
                             a[jr][k] -= tu * wc[k];
+#endif
+#if BASQ_NS_EXP & 64
+                            if (k == 0) dot[j] += a[jr][k] * vr[k];
+#else
                             dot[j] += a[jr][k] * vr[k];
+#endif
                         }
 #endif
                     }
@@ -2731,10 +2738,16 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
                         double colv = 0.0;
 #pragma unroll
                         for (int k = 0; k < NV; ++k) {
+#if !(BASQ_NS_EXP & 32)
                             a[jr][k] -= td * vr[k];
+#endif
                             if (k == tk) colv = a[jr][k];
                         }
+#if BASQ_NS_EXP & 32
+                        const double cr = td * 1e-3;
+#else
                         const double cr = readlane_f64(colv, tl);   // A[r][t] after G_t
+#endif
                         cprev[jr] = cr;
                         if (r == t + 1) {
 #pragma unroll

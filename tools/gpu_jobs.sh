@@ -40,7 +40,7 @@ job_ab_car()      { ( for r in 1 0 1 0; do echo "== BASQ_CAR_RING=$r"; BASQ_CAR_
 job_car_exp()     { ( for e in "" _carexp1; do echo "== lib$e"; BASQ_HIP_LIB=$PWD/basq_amd/csrc/libbasq_hip$e.so timeout -k 10 120 python tools/bench_reduction.py 100 200 --reps 200 2>&1 | grep -E "car_eliminate"; done ) > "$out/car_exp.txt" 2>&1; rc=$?; cat "$out/car_exp.txt"; return $rc; }
 job_car_prof()    { /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -Wno-unused-function -DBASQ_NS_PROF tools/car_prof.hip -o /tmp/car_prof > "$out/car_prof_build.log" 2>&1 && timeout -k 10 120 /tmp/car_prof 100 200 > "$out/car_prof.txt" 2>&1; rc=$?; cat "$out/car_prof.txt" | cut -c1-200; return $rc; }
 job_ns_prof()     { /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -Wno-unused-function -DBASQ_NS_PROF tools/ns_prof.hip -o /tmp/ns_prof > "$out/ns_prof_build.log" 2>&1 && timeout -k 10 120 /tmp/ns_prof 100 200 > "$out/ns_prof.txt" 2>&1; rc=$?; head -40 "$out/ns_prof.txt" | cut -c1-200; return $rc; }
-job_ns_exp()      { ( for e in "" _nsexp1 _nsexp2 _nsexp4 _nsexp8 _nsexp15; do echo "== lib$e"; BASQ_HIP_LIB=$PWD/basq_amd/csrc/libbasq_hip$e.so timeout -k 10 120 python tools/bench_reduction.py 100 200 --reps 200 2>&1 | grep -E "^nullspace"; done ) > "$out/ns_exp.txt" 2>&1; rc=$?; cat "$out/ns_exp.txt"; return $rc; }
+job_ns_exp()      { ( for e in "" _nsexp16 _nsexp32 _nsexp64 _nsexp124; do echo "== lib$e"; BASQ_HIP_LIB=$PWD/basq_amd/csrc/libbasq_hip$e.so timeout -k 10 120 python tools/bench_reduction.py 100 200 --reps 200 2>&1 | grep -E "^nullspace"; done ) > "$out/ns_exp.txt" 2>&1; rc=$?; cat "$out/ns_exp.txt"; return $rc; }
 job_ab_copy_small() { ( for r in 1 2; do for v in 0 1; do for c in cfg2_rbf_1e5 rbf_2e4_defaults; do timeout -k 10 200 python tools/bench_many.py --case $c --batches 24 --inflight 4 --set RAND_COPY_STREAM=$v 2>&1 | grep -v amdgpu.ids; done; done; done ) > "$out/ab_copy_small.txt" 2>&1; rc=$?; cat "$out/ab_copy_small.txt" | cut -c1-150; return $rc; }
 job_tests_ns()    { timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "nullspace or car_eliminate" > "$out/gpu_tests_ns.log" 2>&1; rc=$?; tail -6 "$out/gpu_tests_ns.log" | cut -c1-300; return $rc; }
 job_bench_red()   { ( for sh in "100 200" "50 100" "31 62"; do timeout -k 10 120 python tools/bench_reduction.py $sh --reps 200 2>&1 | grep -E "nullspace|car_eliminate"; done ) > "$out/bench_reduction.txt" 2>&1; rc=$?; cat "$out/bench_reduction.txt"; return $rc; }
