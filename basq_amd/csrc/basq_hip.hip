@@ -2072,11 +2072,11 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
     x = (int)min((unsigned)x, (unsigned)__builtin_amdgcn_update_dpp(BIG, x, 0x143, 0xc, 0xf, false));
     return (unsigned)__builtin_amdgcn_readlane(x, 63);
 }
-// minimum of a wave's doubles (NaN = no candidate; all NaN -> NaN) through their order-preserving 64-bit keys: two 32-bit DPP
-// reductions (each a single v_min_u32 per stage) instead of six stages of 64-bit moves + v_min_f64
+// minimum of a wave's doubles (no NaNs) through their order-preserving 64-bit keys: two 32-bit DPP reductions (each a single
+// v_min_u32 per stage) instead of six stages of 64-bit moves + v_min_f64
 __device__ __forceinline__ double wave_min_key_f64(double v) {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    const unsigned long long key = b ^ (((long long)b >> 63) | 0x8000000000000000ull);   // a NaN (positive, quiet) sorts above +inf
+    const unsigned long long key = b ^ (((long long)b >> 63) | 0x8000000000000000ull);
     const unsigned hi = (unsigned)(key >> 32), lo = (unsigned)key;
     const unsigned hmin = wave_min_u32(hi);
     const unsigned lmin = wave_min_u32(hi == hmin ? lo : 0xffffffffu);
@@ -2232,7 +2232,9 @@ __global__ void __launch_bounds__(1024) car_eliminate_ring_kernel(const double* 
                 const double q = div_newton(mu[k], a[JR][k], rcp_newton(a[JR][k]));    // NaN for an eliminated / padding column
                 av[k] = (a[JR][k] > 0.0) ? q : INF;
             }
-            const double aj = wave_min_key_f64(fmin(fmin(av[0], av[1]), fmin(av[2], av[3])));
+            double best = fmin(fmin(av[0], av[1]), fmin(av[2], av[3]));
+            best = (best == best) ? best : INF;                     // four eliminated columns: keep NaNs (of either sign) out of the keys
+            const double aj = wave_min_key_f64(best);
             BASQ_NS_STAMP(kp, 1);
             const bool found = aj < INF;
             double* slot = ring + (size_t)kp * stride;
@@ -2286,6 +2288,205 @@ __global__ void __launch_bounds__(1024) car_eliminate_ring_kernel(const double* 
 #pragma unroll
     for (int k = 0; k < NV; ++k) {
         keep[k] = mu[k] > 0.0;                                      // (false for NaN: eliminated and padding columns)
+        bal[k] = __ballot(keep[k]);
+        total += __popcll(bal[k]);
+    }
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int base = 0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int col = lane + 64 * k, rank = base + __popcll(bal[k] & below);
+        if (col < M) {
+            keep_rank[col] = keep[k] ? rank : -1;
+            if (keep[k]) { kept[rank] = col; w_star[rank] = mu[k]; }
+        }
+        base += __popcll(bal[k]);
+    }
+    if (lane == 0) { info[0] = total; info[1] = status; }
+}
+
+// The same elimination for null vectors that one CU cannot hold (256 < M <= 448, M - s <= 256; n = 200: 200 x 400): several
+// work-groups of 8 waves (two per SIMD, 256 registers each), wave g of the grid owns the consecutive rows 4 g .. 4 g + 3, and
+// the pivot rows travel as tagged 16-byte granules in GLOBAL memory, one slot per pivot (no reuse: a launch zeroes the words
+// once and a tag is its pivot's number + 1).  The chain of ratio tests stays inside a wave for four steps and crosses to the
+// next wave through L2 -- where car_eliminate_cluster_kernel pays a trip through L2 on EVERY step; a consumer only ever waits
+// for EARLIER blocks, so the work-groups need not be co-resident.  Same arithmetic, op for op.
+template <int NV, int NR>
+__global__ void __launch_bounds__(512) car_eliminate_gring_kernel(const double* __restrict__ PhiT_g,
+                                                                  const double* __restrict__ mu_g, int M, int s,
+                                                                  int* __restrict__ keep_rank, int* __restrict__ kept,
+                                                                  double* __restrict__ w_star, int* __restrict__ info, double* ws,
+                                                                  int n_groups, int cluster_stride) {
+#pragma clang fp contract(off)   // plain operators: the reference rounds after every mul / sub / div
+    constexpr int NC = NV * 64, SLOT = NC + 4, WPG = 8;
+    if (blockIdx.x % cluster_stride) return;          // members share `blockIdx.x % 8`: one XCD under round-robin placement
+    const int cu = blockIdx.x / cluster_stride;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gw = cu * WPG + wv;
+    const int nrows = M - s;
+    const int row0 = gw * NR;
+    const int w_last = (nrows - 1) / NR;
+    const double INF = __builtin_huge_val(), DEAD = __builtin_nan("");
+    // placement check (speed only): members on one XCD hand granules over with plain stores, which stay in that XCD's L2
+    __shared__ int local_l;
+    // (an LDS mailbox for the hand-over inside a work-group -- the next producer reading its predecessor's pivots from LDS
+    //  instead of L2 -- was built and measured: 334 us against 307 at 200 x 400; the hand-over is not what the step waits for)
+    if (threadIdx.x < 64) {
+        const unsigned mine = 0x100u | (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xfu);   // HW_REG_XCC_ID[3:0]
+        unsigned* words = (unsigned*)ws;
+        if (lane == 0) __hip_atomic_store((basq_gu32*)(words + cu), mine, BASQ_RLX_AGENT);
+        unsigned f = mine, spins = 0;
+        for (;;) {
+            f = (lane < n_groups) ? __hip_atomic_load((basq_gu32*)(words + lane), BASQ_RLX_AGENT) : mine;
+            if (__all(f != 0u) || ++spins > (1u << 12)) break;    // (a member that is not running yet counts as elsewhere)
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane == 0) local_l = __all(f == mine) ? 1 : 0;
+    }
+    __syncthreads();
+    const bool local = local_l != 0;
+    __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc((void*)(ws + 16), 0, (int)((size_t)nrows * SLOT * 16), 0x00020000);
+    double a[NR][NV], mu[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) mu[k] = (lane + 64 * k < M) ? mu_g[lane + 64 * k] : DEAD;     // padding: never chosen, never kept
+#pragma unroll
+    for (int jr = 0; jr < NR; ++jr)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int r = row0 + jr, col = lane + 64 * k;
+            a[jr][k] = (r < nrows && col < M) ? PhiT_g[(size_t)r * M + col] : 0.0;
+        }
+    if (row0 >= nrows) return;
+    int status = 0;
+    const int my_rows = (nrows - row0 < NR) ? (nrows - row0) : NR;
+    auto pivot_column = [&](auto FIRSTc, int kj, int lane_j, double (&pj)[NR]) {
+        constexpr int FIRST = decltype(FIRSTc)::value;
+#pragma unroll
+        for (int kc = 0; kc < NV; ++kc)
+            if (kj == kc) {                                        // wave-uniform
+#pragma unroll
+                for (int jr = FIRST; jr < NR; ++jr) pj[jr] = readlane_f64(a[jr][kc], lane_j);
+            }
+    };
+    auto apply = [&](auto FIRSTc, const double (&phi)[NV], const double (&pj)[NR], double aj, int kj, int lane_j, double phij) {
+        constexpr int FIRST = decltype(FIRSTc)::value;
+        const double rphij = div_newton(1.0, phij, rcp_newton(phij));   // RN(1/phi_j): the pivot's reciprocal
+        const bool mine = lane == lane_j;
+#pragma unroll
+        for (int kk = 0; kk < NV; ++kk) {
+            const double step = aj * phi[kk];
+            mu[kk] = (mine && kk == kj) ? DEAD : (mu[kk] - step);
+        }
+#pragma unroll
+        for (int jr = FIRST; jr < NR; ++jr)
+#pragma unroll
+            for (int kk = 0; kk < NV; ++kk) {
+                const double o = div_by_recip(pj[jr] * phi[kk], phij, rphij);           // == (pj * phi) / phij, bit for bit
+                a[jr][kk] = a[jr][kk] - o;
+            }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    // ---- consume the pivots of the earlier blocks ----
+    for (int k = 0; k < row0; ++k) {
+        const bool next = (k / NR) + 1 == gw;                      // this wave produces next
+        if (next) __builtin_amdgcn_s_setprio(2);
+        double phi[NV], aj, phij;
+        int j;
+        const unsigned gbase = (unsigned)k * SLOT, tag = (unsigned)(k + 1);
+        basq_v4u g[NV], gh;
+        unsigned spins = 0;
+        bool bad = false;
+        if (!next) {                                               // far from its turn: watch the header only (one 64-byte request)
+            for (;;) {
+                gh = granule_load(grs, gbase + NC + (lane & 3));
+                if (__all(granule_ok(gh, tag))) break;
+                if (++spins > BASQ_GRANULE_SPIN_LIMIT) { bad = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        for (; !bad;) {
+#pragma unroll
+            for (int kk = 0; kk < NV; ++kk) g[kk] = granule_load(grs, gbase + lane + 64 * kk);
+            gh = granule_load(grs, gbase + NC + (lane & 3));
+            bool ok = granule_ok(gh, tag);
+#pragma unroll
+            for (int kk = 0; kk < NV; ++kk) ok = ok && granule_ok(g[kk], tag);
+            if (__all(ok)) break;
+            if (++spins > BASQ_GRANULE_SPIN_LIMIT) { bad = true; break; }   // never in a healthy run (wave-uniform)
+            if (spins > 64) __builtin_amdgcn_s_sleep(1);
+        }
+        if (bad) { status = 2; break; }
+#pragma unroll
+        for (int kk = 0; kk < NV; ++kk) phi[kk] = granule_value(g[kk]);
+        const double hv = granule_value(gh);
+        aj = readlane_f64(hv, 0);
+        phij = readlane_f64(hv, 1);
+        j = __builtin_amdgcn_readfirstlane((int)__double_as_longlong(readlane_f64(hv, 2)));
+        if (j == 0x7fffffff) { status = 1; break; }               // uniform: no positive entry (the reference raises)
+        double pj[NR];
+        pivot_column(I0(), j >> 6, j & 63, pj);
+        apply(I0(), phi, pj, aj, j >> 6, j & 63, phij);
+    }
+    // ---- produce this wave's block ----
+    if (status == 0) {
+        __builtin_amdgcn_s_setprio(3);
+        auto produce = [&](auto JRc) -> bool {
+            constexpr int JR = decltype(JRc)::value;
+            const int kp = row0 + JR;
+            const unsigned gbase = (unsigned)kp * SLOT, tag = (unsigned)(kp + 1);
+            double av[NV], best = INF;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const double q = div_newton(mu[k], a[JR][k], rcp_newton(a[JR][k]));    // NaN for an eliminated / padding column
+                av[k] = (a[JR][k] > 0.0) ? q : INF;
+                best = fmin(best, av[k]);
+            }
+            best = (best == best) ? best : INF;
+            const double aj = wave_min_key_f64(best);
+            if (!(aj < INF)) {
+                if (lane < 4) granule_store(grs, gbase + NC + lane, tag, __longlong_as_double(0x7fffffffLL), local);
+                return false;
+            }
+            int kj = -1;
+            unsigned long long bj = 0;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {                         // first index of the minimum: the lowest slot with a hit
+                const unsigned long long b = __ballot(av[k] == aj);
+                if (kj < 0 && b) { kj = k; bj = b; }
+            }
+            const int lane_j = (int)__builtin_ctzll(bj);
+            const int j = 64 * kj + lane_j;
+            double pj[NR];
+            pivot_column(JRc, kj, lane_j, pj);                     // pj[JR] = the pivot itself
+            const double phij = pj[JR];
+            const double hv = (lane == 0) ? aj : (lane == 1) ? phij : __longlong_as_double((long long)j);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) granule_store(grs, gbase + lane + 64 * k, tag, a[JR][k], local);
+            if (lane < 4) granule_store(grs, gbase + NC + lane, tag, hv, local);
+            double phic[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) phic[k] = a[JR][k];
+            apply(std::integral_constant<int, JR + 1>(), phic, pj, aj, kj, lane_j, phij);
+            return true;
+        };
+        bool ok = true;
+        if (ok && my_rows > 0) ok = produce(std::integral_constant<int, 0>());
+        if constexpr (NR > 1) { if (ok && my_rows > 1) ok = produce(std::integral_constant<int, 1>()); }
+        if constexpr (NR > 2) { if (ok && my_rows > 2) ok = produce(std::integral_constant<int, 2>()); }
+        if constexpr (NR > 3) { if (ok && my_rows > 3) ok = produce(std::integral_constant<int, 3>()); }
+        static_assert(NR <= 4, "unrolled by hand up to 4 rows per wave");
+        if (!ok) status = 1;
+        __builtin_amdgcn_s_setprio(0);
+    }
+    if (gw != w_last) return;
+    // survivors: mu > 0 (:173-174), ascending column order (column = lane + 64 k)
+    unsigned long long bal[NV];
+    bool keep[NV];
+    int total = 0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        keep[k] = mu[k] > 0.0;
         bal[k] = __ballot(keep[k]);
         total += __popcll(bal[k]);
     }
@@ -4864,6 +5065,7 @@ static int cluster_stride() {
     return spread ? 1 : 8;
 }
 static inline size_t bidiag_ws_doubles(int nv, int ncu) { return 16 + 2 * (size_t)(2 * (ncu + 1)) * (nv * 64 + 8); }
+static inline size_t gring_ws_doubles(int M, int nrows) { return 16 + 2 * (size_t)nrows * (((M + 63) / 64) * 64 + 4); }
 static inline size_t cluster_ws_doubles(int nv, int ncu) { return 16 + 2 * (size_t)(2 * BASQ_WPG * ncu) * (nv * 64 + 8); }
 
 #ifndef BASQ_CAR_CLUSTER
@@ -4875,6 +5077,11 @@ int64_t basq_reduction_ws_doubles(int32_t s, int32_t M) {
     size_t need = 0;
     // clusters of BASQ_CLUSTER_NCU work-groups (elimination ring: 2 W slots; bidiagonalisation: 2 x (NCU + 1) messages -- the ring is the larger)
     if (M > 256 && M <= 512 && (s <= 256 || (M - s) <= 256)) need = cluster_ws_doubles(8, BASQ_CLUSTER_NCU);
+    // the elimination's global ring (car_eliminate_gring_kernel): one slot of tagged granules per pivot
+    if (M > 256 && M <= 448 && (M - s) <= 256) {
+        const size_t ring = gring_ws_doubles(M, M - s);
+        if (ring > need) need = ring;
+    }
     return (int64_t)need;
 }
 
@@ -4918,6 +5125,24 @@ int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32
                                keep_rank, kept, w_star, info, (double*)nullptr, 1);
         BASQ_CHECK_LAUNCH();
         return BASQ_OK;
+    }
+    {
+        // rows in registers over several work-groups, pivots through a global ring (BASQ_CAR_GRING=0: the cluster kernel)
+        static const int gring_env = [] { const char* e = getenv("BASQ_CAR_GRING"); return e ? atoi(e) : 1; }();
+        if (gring_env && nrows >= 1 && M > 256 && M <= 448 && nrows <= 256 && ws) {
+            const int nv = (M + 63) / 64, n_groups = (nrows + 31) / 32;       // 8 waves x 4 rows per work-group
+            if (hipMemsetAsync(ws, 0, gring_ws_doubles(M, nrows) * sizeof(double), st) != hipSuccess) return BASQ_ELAUNCH;
+            const dim3 grid((unsigned)(n_groups * cluster_stride()));
+#define BASQ_GRING_LAUNCH(NVV)                                                                                                  \
+    hipLaunchKernelGGL((car_eliminate_gring_kernel<NVV, 4>), grid, dim3(512), 0, st, PhiT, mu, M, s, keep_rank, kept, w_star, \
+                       info, ws, n_groups, cluster_stride())
+            if (nv == 5) BASQ_GRING_LAUNCH(5);
+            else if (nv == 6) BASQ_GRING_LAUNCH(6);
+            else BASQ_GRING_LAUNCH(7);
+#undef BASQ_GRING_LAUNCH
+            BASQ_CHECK_LAUNCH();
+            return BASQ_OK;
+        }
     }
     if (nrows >= 1 && !fits_lds && M <= 512 && nrows <= 4 * BASQ_WPG * 8 && ws) {   // cluster of BASQ_CLUSTER_NCU CUs (n = 200: M = 400)
         // every granule word zeroed: tags are the step numbers of THIS launch

@@ -205,7 +205,8 @@ int basq_nullspace_f64(const double* XcarT, int32_t s, int32_t M, double* V, dou
 
 /*
  * Workspace (in doubles) that basq_nullspace_f64 / basq_car_eliminate_f64 need in `ws` for an [s, M] reduction:
- * 0 when the shape runs on one compute unit (M <= 256: ws may be NULL), otherwise the message ring of the
+ * 0 when the shape runs on one compute unit (M <= 256: ws may be NULL), otherwise the larger of the elimination's ring of
+ * pivot rows (256 < M <= 448: 16 + 2 (M - s)(64 ceil(M / 64) + 4) doubles, 1.4 MB at 200 x 400) and the message ring of the
  * 8-work-group cluster kernels (M = 2n = 400 at n = 200: the 200 x 400 matrix does not fit one CU's registers): tagged
  * 16-byte granules {tag, low word, tag, high word} -- the data is its own flag.  The caller owns the buffer (the library
  * allocates nothing); the entries zero its words themselves before every launch (tags count the steps of ONE launch).  Without a
@@ -224,8 +225,12 @@ int64_t basq_reduction_ws_doubles(int32_t s, int32_t M);
  * bounded spin timed out -- never in a healthy run).  Null vectors live in registers: for M <= 256 and M - s <= 112 one
  * work-group whose 16 waves own CONSECUTIVE null vectors (seven each) -- a wave consumes the pivots published before its block
  * (one rank-1 update of its rows per pivot) and then runs the ratio tests of its own block without leaving the wave; every pivot
- * row is written to LDS once (car_eliminate_ring_kernel, round 4: 122 us against 174 at 100 x 200); an 8-work-group cluster
- * through `ws` for M <= 512 (see basq_reduction_ws_doubles; ws may be NULL otherwise); M <= 1024.  The divisions of the ratio
+ * row is written to LDS once (car_eliminate_ring_kernel, round 4: 122 us against 174 at 100 x 200); for 256 < M <= 448 the same
+ * block scheme over several work-groups of 8 waves (4 rows per wave), the pivot rows as tagged granules in `ws`, one slot per
+ * pivot, zeroed by this entry before the launch (car_eliminate_gring_kernel, round 4: 307 us against 520 at 200 x 400; a wave
+ * only ever waits for EARLIER blocks, so the work-groups need not be co-resident; BASQ_CAR_GRING=0: the cluster kernel); an
+ * 8-work-group cluster exchanging one message per step through `ws` for the remaining M <= 512 (see basq_reduction_ws_doubles;
+ * ws may be NULL otherwise); M <= 1024.  The divisions of the ratio
  * test are the IEEE expansion without its scaling steps (operands and quotients far from the ends of the exponent range -- what
  * the Markstein quotient of the rank-1 update has always assumed); BASQ_CAR_RING=0 in the environment selects the LDS-resident
  * kernel of rounds 1-3 (A/B).

@@ -122,10 +122,13 @@ def test_project_finalize_vs_standin(hip_ops, q, m, S, n_chunks):
 
 
 # (dispatch of basq_car_eliminate_f64: rows in registers handed over in blocks of 7 -- 200/100, 180/80, 130/20, 70/5 -- or of
-# 4 -- 150/100, 65/1, 62/31, 20/10, 101/100; the cluster of work-groups -- 400/200; rows in LDS -- 256/144, 230/130)
+# 4 -- 150/100, 65/1, 62/31, 20/10, 101/100; several work-groups and a global ring -- 400/200 ...; rows in LDS -- 256/144, 230/130)
 @pytest.mark.parametrize("M,s,seed", [(200, 100, 0), (200, 100, 1), (400, 200, 2), (150, 100, 3), (20, 10, 4),
                                       (62, 31, 5), (101, 100, 6), (180, 80, 7), (130, 20, 8), (70, 5, 9), (65, 1, 10),
-                                      (256, 144, 11), (230, 130, 12), (256, 156, 13)])
+                                      (256, 144, 11), (230, 130, 12), (256, 156, 13),
+                                      # several work-groups, pivots through a ring of tagged granules in global memory
+                                      (300, 150, 14), (320, 100, 15), (448, 248, 16), (260, 259, 17), (400, 150, 18),
+                                      (512, 256, 19)])                                    # (8 column slots: the cluster kernel)
 def test_car_eliminate_bit_exact(hip_ops, M, s, seed):
     """Same null-space basis in -> same pivots, and bit-identical weights (reference op order)."""
     cpu = CpuStandInOps()
