@@ -214,6 +214,25 @@ def test_car_eliminate_degenerate_flag(hip_ops):
     assert int(info.cpu()[1]) == 1
 
 
+@pytest.mark.parametrize("M,s", [(200, 100), (300, 150), (400, 200)])
+def test_car_eliminate_degenerate_flag_in_a_later_block(hip_ops, M, s):
+    """The same flag when the null vector without a positive entry belongs to a LATER block of the register kernels (one
+    work-group: M = 200; several work-groups and the global ring: M = 300, 400): the waves that only consume must see the
+    producer's give-up and stop, and the wave that writes the outcome must report status 1."""
+    g = torch.Generator().manual_seed(M)
+    X = torch.randn(s, M, generator=g, dtype=torch.float64)
+    X[0] = 1.0
+    PhiT = torch.linalg.svd(X)[2][-(M - s):, :].contiguous()
+    bad_row = (M - s) // 2 + 3
+    PhiT[bad_row:] = -PhiT[bad_row:].abs() - 1.0         # (every later row: whichever of them the updates leave negative trips)
+    mu = torch.full((M,), 1.0 / M, dtype=torch.float64)
+    cpu = CpuStandInOps()
+    _, _, _, info_c = cpu.car_eliminate(PhiT.clone(), mu.clone(), M, s)
+    _, _, _, info = hip_ops.car_eliminate(hip_ops.to_device(PhiT), hip_ops.to_device(mu), M, s)
+    assert int(info_c[1]) == 1
+    assert info.cpu().tolist() == info_c.tolist()        # status 1 and the same number of positive weights at the stop
+
+
 @pytest.mark.parametrize("Rl,off,n_full,S,kept", [
     (5000, 0, 5000, 200, list(range(0, 200, 2))),
     (5077, 0, 5000, 200, list(range(1, 200, 2))),            # last set kept -> tail survives
