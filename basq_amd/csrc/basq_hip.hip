@@ -2396,7 +2396,7 @@ __global__ void __launch_bounds__(512) car_eliminate_gring_kernel(const double* 
         const unsigned gbase = (unsigned)k * SLOT, tag = (unsigned)(k + 1);
         basq_v4u g[NV], gh;
         unsigned spins = 0;
-        bool bad = false;
+        bool bad = false, gave_up = false;
         if (!next) {                                               // far from its turn: watch the header only (one 64-byte request)
             for (;;) {
                 gh = granule_load(grs, gbase + NC + (lane & 3));
@@ -2410,6 +2410,10 @@ __global__ void __launch_bounds__(512) car_eliminate_gring_kernel(const double* 
             for (int kk = 0; kk < NV; ++kk) g[kk] = granule_load(grs, gbase + lane + 64 * kk);
             gh = granule_load(grs, gbase + NC + (lane & 3));
             bool ok = granule_ok(gh, tag);
+            if (__all(ok)) {                                        // a producer that found no positive entry publishes the header only
+                const int jh = __builtin_amdgcn_readfirstlane((int)__double_as_longlong(readlane_f64(granule_value(gh), 2)));
+                if (jh == 0x7fffffff) { gave_up = true; break; }
+            }
 #pragma unroll
             for (int kk = 0; kk < NV; ++kk) ok = ok && granule_ok(g[kk], tag);
             if (__all(ok)) break;
@@ -2417,6 +2421,7 @@ __global__ void __launch_bounds__(512) car_eliminate_gring_kernel(const double* 
             if (spins > 64) __builtin_amdgcn_s_sleep(1);
         }
         if (bad) { status = 2; break; }
+        if (gave_up) { status = 1; break; }                       // uniform: no positive entry (the reference raises)
 #pragma unroll
         for (int kk = 0; kk < NV; ++kk) phi[kk] = granule_value(g[kk]);
         const double hv = granule_value(gh);
