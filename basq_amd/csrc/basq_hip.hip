@@ -2311,14 +2311,20 @@ __global__ void __launch_bounds__(1024) car_eliminate_ring_kernel(const double* 
 // once and a tag is its pivot's number + 1).  The chain of ratio tests stays inside a wave for four steps and crosses to the
 // next wave through L2 -- where car_eliminate_cluster_kernel pays a trip through L2 on EVERY step; a consumer only ever waits
 // for EARLIER blocks, so the work-groups need not be co-resident.  Same arithmetic, op for op.
-template <int NV, int NR>
-__global__ void __launch_bounds__(512) car_eliminate_gring_kernel(const double* __restrict__ PhiT_g,
+#ifndef BASQ_GRING_NR
+#define BASQ_GRING_NR 4          // rows per wave and waves per work-group of car_eliminate_gring_kernel (A/B builds)
+#endif
+#ifndef BASQ_GRING_WPG
+#define BASQ_GRING_WPG 8
+#endif
+template <int NV, int NR, int WPG>
+__global__ void __launch_bounds__(WPG * 64) car_eliminate_gring_kernel(const double* __restrict__ PhiT_g,
                                                                   const double* __restrict__ mu_g, int M, int s,
                                                                   int* __restrict__ keep_rank, int* __restrict__ kept,
                                                                   double* __restrict__ w_star, int* __restrict__ info, double* ws,
                                                                   int n_groups, int cluster_stride) {
 #pragma clang fp contract(off)   // plain operators: the reference rounds after every mul / sub / div
-    constexpr int NC = NV * 64, SLOT = NC + 4, WPG = 8;
+    constexpr int NC = NV * 64, SLOT = NC + 4;
     if (blockIdx.x % cluster_stride) return;          // members share `blockIdx.x % 8`: one XCD under round-robin placement
     const int cu = blockIdx.x / cluster_stride;
     const int lane = threadIdx.x & 63;
@@ -2480,7 +2486,11 @@ __global__ void __launch_bounds__(512) car_eliminate_gring_kernel(const double* 
         if constexpr (NR > 1) { if (ok && my_rows > 1) ok = produce(std::integral_constant<int, 1>()); }
         if constexpr (NR > 2) { if (ok && my_rows > 2) ok = produce(std::integral_constant<int, 2>()); }
         if constexpr (NR > 3) { if (ok && my_rows > 3) ok = produce(std::integral_constant<int, 3>()); }
-        static_assert(NR <= 4, "unrolled by hand up to 4 rows per wave");
+        if constexpr (NR > 4) { if (ok && my_rows > 4) ok = produce(std::integral_constant<int, 4>()); }
+        if constexpr (NR > 5) { if (ok && my_rows > 5) ok = produce(std::integral_constant<int, 5>()); }
+        if constexpr (NR > 6) { if (ok && my_rows > 6) ok = produce(std::integral_constant<int, 6>()); }
+        if constexpr (NR > 7) { if (ok && my_rows > 7) ok = produce(std::integral_constant<int, 7>()); }
+        static_assert(NR <= 8, "unrolled by hand up to 8 rows per wave");
         if (!ok) status = 1;
         __builtin_amdgcn_s_setprio(0);
     }
@@ -2823,7 +2833,9 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
     __shared__ double sspart[NW];
     __shared__ double par[4];             // tau_t, tauq_{t-1}, u-scale_{t-1}, alpha of H_t
     __shared__ int hready;                // = t + 1 once wave 1 has published H_t's parameters
-    __shared__ int wready;                // = t + 1 once wave 0 has published w of H_t (BASQ_NS_EARLY_H)
+#if BASQ_NS_EARLY_H
+    __shared__ int wready;                // = t + 1 once wave 0 has published w of H_t
+#endif
 #ifdef BASQ_NS_PROF
     // phase clock of tools/ns_prof.hip: cycles per phase summed over all steps in SCALAR registers (the kernel sits at its VGPR
     // ceiling: stamps that touch a vector register make it spill ~370 of them and run 7 x slower)
@@ -2840,7 +2852,10 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
 #define BASQ_NS_LSTAMP(t, slot) do { } while (0)
 #endif
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) { hready = 0; wready = 0; }
+    if (tid == 0) hready = 0;
+#if BASQ_NS_EARLY_H
+    if (tid == 0) wready = 0;
+#endif
     // slot k of this lane holds column COL(k); column c sits in lane (c & 127) >> 1, slot (c & 1) + 2 (c >> 7)
 #define BASQ_COL(k) (2 * lane + ((k) & 1) + 128 * ((k) >> 1))
     double a[NG * 4][NV], cprev[NG * 4];
@@ -5135,12 +5150,13 @@ int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32
         // rows in registers over several work-groups, pivots through a global ring (BASQ_CAR_GRING=0: the cluster kernel)
         static const int gring_env = [] { const char* e = getenv("BASQ_CAR_GRING"); return e ? atoi(e) : 1; }();
         if (gring_env && nrows >= 1 && M > 256 && M <= 448 && nrows <= 256 && ws) {
-            const int nv = (M + 63) / 64, n_groups = (nrows + 31) / 32;       // 8 waves x 4 rows per work-group
+            constexpr int RPG = BASQ_GRING_NR * BASQ_GRING_WPG;               // rows per work-group (8 waves x 4 rows)
+            const int nv = (M + 63) / 64, n_groups = (nrows + RPG - 1) / RPG;
             if (hipMemsetAsync(ws, 0, gring_ws_doubles(M, nrows) * sizeof(double), st) != hipSuccess) return BASQ_ELAUNCH;
             const dim3 grid((unsigned)(n_groups * cluster_stride()));
-#define BASQ_GRING_LAUNCH(NVV)                                                                                                  \
-    hipLaunchKernelGGL((car_eliminate_gring_kernel<NVV, 4>), grid, dim3(512), 0, st, PhiT, mu, M, s, keep_rank, kept, w_star, \
-                       info, ws, n_groups, cluster_stride())
+#define BASQ_GRING_LAUNCH(NVV)                                                                                              \
+    hipLaunchKernelGGL((car_eliminate_gring_kernel<NVV, BASQ_GRING_NR, BASQ_GRING_WPG>), grid, dim3(BASQ_GRING_WPG * 64), 0, st, \
+                       PhiT, mu, M, s, keep_rank, kept, w_star, info, ws, n_groups, cluster_stride())
             if (nv == 5) BASQ_GRING_LAUNCH(5);
             else if (nv == 6) BASQ_GRING_LAUNCH(6);
             else BASQ_GRING_LAUNCH(7);
