@@ -2337,7 +2337,9 @@ __global__ void __launch_bounds__(WPG * 64) car_eliminate_gring_kernel(const dou
     // placement check (speed only): members on one XCD hand granules over with plain stores, which stay in that XCD's L2
     __shared__ int local_l;
     // (an LDS mailbox for the hand-over inside a work-group -- the next producer reading its predecessor's pivots from LDS
-    //  instead of L2 -- was built and measured: 334 us against 307 at 200 x 400; the hand-over is not what the step waits for)
+    //  instead of L2 -- was built twice and measured: 334 us against 307 at 200 x 400 with a release store of its counter, 341
+    //  with a relaxed one; the hand-over is not what the step waits for.  The same kernel at 100 x 200, where one work-group
+    //  can hold the null vectors: 118.8 us against car_eliminate_ring_kernel's 122.3 -- not worth a workspace and a memset there)
     if (threadIdx.x < 64) {
         const unsigned mine = 0x100u | (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xfu);   // HW_REG_XCC_ID[3:0]
         unsigned* words = (unsigned*)ws;
