@@ -2024,6 +2024,12 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) car_eliminate_cluster_kernel(co
 //   * the producer and the wave that produces next run at raised priority (s_setprio): the consumers' updates fill the
 //     fp64 pipe, the chain of ratio tests must not queue behind them.
 // ------------------------------------------------------------------------------------------------
+#ifndef BASQ_RING_NR
+#define BASQ_RING_NR 7           // rows per wave x waves of car_eliminate_ring_kernel's larger form (A/B builds: 9 x 12, 13 x 8, ...)
+#endif
+#ifndef BASQ_RING_WPG
+#define BASQ_RING_WPG 16
+#endif
 #ifndef BASQ_CAR_EXP
 #define BASQ_CAR_EXP 0           // timing experiment only (1: consumers skip their updates -- the chain of ratio tests alone;
 #endif                           // results are wrong for any value but 0)
@@ -2085,8 +2091,17 @@ __device__ __forceinline__ double wave_min_key_f64(double v) {
     return __longlong_as_double((long long)bmin);
 }
 
-template <int NR>
-__global__ void __launch_bounds__(1024) car_eliminate_ring_kernel(const double* __restrict__ PhiT_g,
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>()), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>());
+}
+
+template <int NR, int WPG>
+__global__ void __launch_bounds__(WPG * 64) car_eliminate_ring_kernel(const double* __restrict__ PhiT_g,
                                                                   const double* __restrict__ mu_g, int M, int s,
                                                                   int* __restrict__ keep_rank, int* __restrict__ kept,
                                                                   double* __restrict__ w_star, int* __restrict__ info) {
@@ -2269,14 +2284,9 @@ __global__ void __launch_bounds__(1024) car_eliminate_ring_kernel(const double* 
             return true;
         };
         bool ok = true;
-        if (ok && my_rows > 0) ok = produce(std::integral_constant<int, 0>());
-        if constexpr (NR > 1) { if (ok && my_rows > 1) ok = produce(std::integral_constant<int, 1>()); }
-        if constexpr (NR > 2) { if (ok && my_rows > 2) ok = produce(std::integral_constant<int, 2>()); }
-        if constexpr (NR > 3) { if (ok && my_rows > 3) ok = produce(std::integral_constant<int, 3>()); }
-        if constexpr (NR > 4) { if (ok && my_rows > 4) ok = produce(std::integral_constant<int, 4>()); }
-        if constexpr (NR > 5) { if (ok && my_rows > 5) ok = produce(std::integral_constant<int, 5>()); }
-        if constexpr (NR > 6) { if (ok && my_rows > 6) ok = produce(std::integral_constant<int, 6>()); }
-        static_assert(NR <= 7, "unrolled by hand up to 7 rows per wave");
+        static_for<NR>([&](auto JRc) {
+            if (ok && my_rows > decltype(JRc)::value) ok = produce(JRc);
+        });
         if (!ok) status = 1;
         __builtin_amdgcn_s_setprio(0);
     }
@@ -5117,19 +5127,19 @@ int basq_car_eliminate_f64(double* PhiT, double* mu, int32_t M, int32_t s, int32
         // one CU, null vectors in registers, handed over in blocks of NR rows (BASQ_CAR_RING=0: the LDS-resident kernel)
         static const int ring_env = [] { const char* e = getenv("BASQ_CAR_RING"); return e ? atoi(e) : 1; }();
         const size_t ring_lds = (size_t)nrows * (M + 4) * sizeof(double);
-        if (ring_env && nrows >= 1 && M <= 256 && nrows <= 16 * 7 && ring_lds <= 163328) {   // 163840 B per CU - static LDS
+        if (ring_env && nrows >= 1 && M <= 256 && nrows <= BASQ_RING_WPG * BASQ_RING_NR && ring_lds <= 163328) {   // 163840 B per CU - static LDS
             if (nrows <= 16 * 4) {
-                if (hipFuncSetAttribute((const void*)car_eliminate_ring_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                if (hipFuncSetAttribute((const void*)car_eliminate_ring_kernel<4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)ring_lds) != hipSuccess)
                     return BASQ_ELAUNCH;
-                hipLaunchKernelGGL(car_eliminate_ring_kernel<4>, dim3(1), dim3(1024), ring_lds, st, PhiT, mu, M, s, keep_rank,
+                hipLaunchKernelGGL((car_eliminate_ring_kernel<4, 16>), dim3(1), dim3(1024), ring_lds, st, PhiT, mu, M, s, keep_rank,
                                    kept, w_star, info);
             } else {
-                if (hipFuncSetAttribute((const void*)car_eliminate_ring_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)ring_lds) != hipSuccess)
+                if (hipFuncSetAttribute((const void*)car_eliminate_ring_kernel<BASQ_RING_NR, BASQ_RING_WPG>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)ring_lds) != hipSuccess)
                     return BASQ_ELAUNCH;
-                hipLaunchKernelGGL(car_eliminate_ring_kernel<7>, dim3(1), dim3(1024), ring_lds, st, PhiT, mu, M, s, keep_rank,
-                                   kept, w_star, info);
+                hipLaunchKernelGGL((car_eliminate_ring_kernel<BASQ_RING_NR, BASQ_RING_WPG>), dim3(1), dim3(BASQ_RING_WPG * 64), ring_lds, st,
+                                   PhiT, mu, M, s, keep_rank, kept, w_star, info);
             }
             BASQ_CHECK_LAUNCH();
             return BASQ_OK;

@@ -52,8 +52,8 @@ WORKLOAD = dict(N=1_000_000, d=10, n=100, nys_ratio=1e-2, family="rbf", lengthsc
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--N", type=int, default=WORKLOAD["N"])
     ap.add_argument("--d", type=int, default=WORKLOAD["d"])
     ap.add_argument("--n", type=int, default=WORKLOAD["n"])

@@ -64,18 +64,21 @@ def main():
             if same and rel <= 1e-5:
                 ok += 1
                 continue
-            moved, ref_rel = False, 0.0
-            for s in (1, 2, 3, 4, 5):
-                torch.manual_seed(c["torch_seed"])
+            moved, ref_rel, explained, n_pat = False, 0.0, False, 0
+            for s in range(1, 41):                                  # five patterns as in the committed tests; up to forty before a case
+                torch.manual_seed(c["torch_seed"])                   # is called unexplained (seed 8 case 33: 4 of 40 move the indices)
                 ip, wp = recombination_oracle(pts, nys, c["n"], build_perturbed_oracle_kernel(c, s))
                 sp, rp = dev(ip, wp, io, wo)
                 moved = moved or not sp
                 ref_rel = max(ref_rel, rp if sp else 0.0)
-            explained = moved or (same and rel <= 4 * ref_rel)
+                n_pat = s
+                explained = moved or (same and rel <= 4 * ref_rel)
+                if s >= 5 and explained:
+                    break
             unstable += explained
             bugs += not explained
             print(f"  structured seed {seed} case {i}: idx equal {same} rel {rel:.2e} | reference vs itself: idx moves {moved} rel {ref_rel:.2e} "
-                  f"| cond {observation_gram_condition(c, state):.1e} | {'explained' if explained else 'BUG?'} | N={c['N']} d={c['d']} n={c['n']} m={c['m']} {c['kernel']}")
+                  f"| cond {observation_gram_condition(c, state):.1e} | {'explained' if explained else 'BUG?'} ({n_pat} patterns) | N={c['N']} d={c['d']} n={c['n']} m={c['m']} {c['kernel']}")
         print(f"structured seed {seed}: ok={ok} unstable(explained)={unstable} unexplained={bugs} skipped={skipped}", flush=True)
         ok = bugs = skipped = 0
         for c, w0 in _sober_fuzz_cases(a.count, seed=seed + 100):

@@ -47,6 +47,7 @@ job_bench_red()   { ( for sh in "100 200" "50 100" "31 62"; do timeout -k 10 120
 job_ab_gring()    { ( for sh in "200 400" "150 300"; do for r in 1 0 1 0; do echo "== $sh BASQ_CAR_GRING=$r"; BASQ_CAR_GRING=$r timeout -k 10 120 python tools/bench_reduction.py $sh --reps 100 2>&1 | grep -E "car_eliminate"; done; done ) > "$out/ab_car_gring.txt" 2>&1; rc=$?; cat "$out/ab_car_gring.txt"; return $rc; }
 job_cfg2_reps()   { timeout -k 10 300 python tools/bench_configs.py --only cfg2_rbf_1e5 --reps 30 2>&1 | grep -v amdgpu.ids > "$out/cfg2_reps.txt"; rc=$?; cut -c1-200 "$out/cfg2_reps.txt"; return $rc; }
 job_gring_variants() { ( for e in "" _gr8x8 _gr4x16 _gr3x8 _gr2x8; do echo "== lib$e"; for sh in "200 400"; do BASQ_HIP_LIB=$PWD/basq_amd/csrc/libbasq_hip$e.so timeout -k 10 120 python tools/bench_reduction.py $sh --reps 100 2>&1 | grep -E "car_eliminate"; done; done ) > "$out/gring_variants.txt" 2>&1; rc=$?; cat "$out/gring_variants.txt"; return $rc; }
+job_ring_variants() { ( for e in "" _rg9x12 _rg10x10 _rg13x8 _rg8x13; do echo "== lib$e"; BASQ_HIP_LIB=$PWD/basq_amd/csrc/libbasq_hip$e.so timeout -k 10 120 python tools/bench_reduction.py 100 200 --reps 200 2>&1 | grep -E "car_eliminate"; done ) > "$out/ring_variants.txt" 2>&1; rc=$?; cat "$out/ring_variants.txt"; return $rc; }
 job_tests_car()   { timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "car_eliminate or nullspace_then" > "$out/gpu_tests_car.log" 2>&1; rc=$?; tail -15 "$out/gpu_tests_car.log" | cut -c1-300; return $rc; }
 job_ab_copy()     { timeout -k 10 400 python tools/ab_engine.py RAND_COPY_STREAM 0 1 --reps 10 --visits 3 2>&1 | grep -v amdgpu.ids > "$out/ab_rand_copy_stream.txt"; rc=$?; cat "$out/ab_rand_copy_stream.txt"; return $rc; }
 job_ab_late()     { timeout -k 10 400 python tools/ab_engine.py LATE_CLASSES 2 3 0 4 5 --reps 8 --visits 3 2>&1 | grep -v amdgpu.ids > "$out/ab_late_classes.txt"; rc=$?; cat "$out/ab_late_classes.txt"; return $rc; }
