@@ -214,6 +214,27 @@ def test_car_eliminate_degenerate_flag(hip_ops):
     assert int(info.cpu()[1]) == 1
 
 
+@pytest.mark.parametrize("M,s", [(200, 100), (150, 100), (400, 200), (256, 144)])
+def test_car_eliminate_zero_and_negative_weights_bit_exact(hip_ops, M, s):
+    """Weights that are exactly zero (ratio +0: ties resolved by the first index) or slightly negative (a ratio below zero wins
+    the test, as in the reference) -- the order keys of the register kernels' wave minimum must sort them like the IEEE compare."""
+    cpu = CpuStandInOps()
+    g = torch.Generator().manual_seed(1000 + M)
+    X = torch.randn(s, M, generator=g, dtype=torch.float64)
+    X[0] = 1.0
+    PhiT = torch.linalg.svd(X)[2][-(M - s):, :].contiguous()
+    mu = torch.rand(M, generator=g, dtype=torch.float64) + 0.05
+    mu[torch.randperm(M, generator=g)[:M // 8]] = 0.0
+    mu[torch.randperm(M, generator=g)[:M // 16]] = -1e-18
+    kr_c, kept_c, w_c, info_c = cpu.car_eliminate(PhiT.clone(), mu.clone(), M, s)
+    kr_g, kept_g, w_g, info_g = hip_ops.car_eliminate(hip_ops.to_device(PhiT.clone()), hip_ops.to_device(mu.clone()), M, s)
+    n = int(info_c[0])
+    assert info_g.cpu().tolist() == info_c.tolist()
+    assert torch.equal(kr_g.cpu(), kr_c)
+    assert torch.equal(kept_g.cpu()[:n], kept_c[:n])
+    assert torch.equal(w_g.cpu()[:n], w_c[:n])
+
+
 @pytest.mark.parametrize("M,s", [(200, 100), (300, 150), (400, 200)])
 def test_car_eliminate_degenerate_flag_in_a_later_block(hip_ops, M, s):
     """The same flag when the null vector without a positive entry belongs to a LATER block of the register kernels (one
