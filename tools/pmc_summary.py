@@ -49,20 +49,22 @@ def per_dispatch(path):
     return [acc[k] for k in sorted(acc)]
 
 
-def batches(disp, per_batch=17):
-    """Block-sum launches grouped per batch: ``per_batch`` consecutive launches in dispatch order (17 at the headline size:
-    14 + 2 classes and the irregular blocks of round 1, the fresh evaluations of rounds 6 and 11, the irregular blocks of
-    the eleven rounds in between)."""
+def batches(disp, n_batches=4):
+    """Block-sum launches grouped per batch: consecutive launches in dispatch order, ``n_batches`` batches per pass (warm-up + two
+    steps + the parity batch).  At the headline size 16 per batch since the end of round 4 (one 16-class launch with the irregular
+    blocks of round 1, the fresh evaluations of rounds 6 and 11, the irregular blocks of the rounds in between); 17 before
+    (14 + 2 classes in round 1)."""
     bs = [d for d in disp if KERNEL in d["name"]]
-    if not bs or len(bs) % per_batch:
-        raise SystemExit(f"{len(bs)} block-sum launches: not a multiple of {per_batch} per batch")
+    if not bs or len(bs) % n_batches:
+        raise SystemExit(f"{len(bs)} block-sum launches: not a multiple of {n_batches} batches")
+    per_batch = len(bs) // n_batches
     return [bs[i:i + per_batch] for i in range(0, len(bs), per_batch)]
 
 
 def main():
     out = sys.argv[1]
     res = {"kernel": "blocksum_kernel<3,0,4> -- all launches of one headline batch (N=1e6, d=10, n=100, m=1e4): 16 residue "
-                     "classes in round 1 (14 + 2 launches), fresh evaluations in rounds 6 and 11, the irregular blocks of every round"}
+                     "classes in round 1 (one launch since the end of round 4; 14 + 2 before), fresh evaluations in rounds 6 and 11, the irregular blocks of every round"}
     res["commit"] = sys.argv[2] if len(sys.argv) > 2 else None      # (the GPU box has no .git: pass `git rev-parse --short HEAD`)
     if res["commit"] is None:
         try:
@@ -78,7 +80,7 @@ def main():
         return sum(vals) / len(vals) if vals else None
 
     def mean_big(groups, ctr):
-        vals = [max(grp, key=lambda d: d["grid"] if d["grid"] < 2_000_000 else 0)["c"].get(ctr, 0.0) for grp in groups]
+        vals = [max(grp, key=lambda d: d["grid"])["c"].get(ctr, 0.0) for grp in groups]
         return sum(vals) / len(vals) if vals else None
 
     fetch_kib, write_kib = mean_sum(per["fetch"], "FETCH_SIZE"), mean_sum(per["write"], "WRITE_SIZE")
@@ -89,14 +91,16 @@ def main():
     res["fetch_KiB_per_batch"] = fetch_kib
     res["write_KiB_per_batch"] = write_kib
     res["hbm_bytes_per_batch"] = int((fetch_kib + write_kib) * 1024)
-    # calibration on the largest launch: 14 of 16 classes of the regular region (873 600 candidates x 96 B packed rows +
-    # mu 8 B) + the Nystrom rows (10 048 x 96 B), fetched once when the XCD map keeps a candidate slice in ONE L2
+    # calibration on the largest launch: the 16 classes of round 1's regular region (4 992 blocks x 200 candidates x 96 B packed
+    # rows + mu 8 B; 14 of the 16 -- 873 600 candidates -- while the round was launched as 14 + 2) + the Nystrom rows
+    # (10 048 x 96 B), fetched once when the XCD map keeps a candidate slice in ONE L2
     big_fetch = mean_big(per["fetch"], "FETCH_SIZE")
-    compulsory = 873_600 * (96 + 8) + 10_048 * 96
+    n_big = 998_400 if res["launches_per_batch"] == 16 else 873_600
+    compulsory = n_big * (96 + 8) + 10_048 * 96
     res["largest_launch"] = {"fetch_KiB": big_fetch, "write_KiB": mean_big(per["write"], "WRITE_SIZE"),
                              "compulsory_fetch_bytes": compulsory,
                              "fetch_over_compulsory": big_fetch * 1024 / compulsory if big_fetch else None,
-                             "note": "14 of 16 residue classes of round 1; part of the packed rows is still cached from "
+                             "note": "the residue classes of round 1 in one launch; part of the packed rows is still cached from "
                                      "pack_points_kernel; cold inputs: 1.0x (profiles/r02_traffic.json)"}
     # algorithmic bytes per batch by SURVEY 8d ((8d + 16) per candidate of every evaluated launch + 8 m d per launch) and what
     # the epoch formulation adds on purpose: the class partials [C + 1, m_ext, S] written once (then read once by the projection)
