@@ -576,9 +576,12 @@ class Batch:
                 fin = (parts, parts.shape[0], rows, q, S, None, m, min(m, S), 0.0, 0, 0, 0, None)
             res, rv = ops.reduction_result(S) if owner is not None else (None, None)
             if owner is None or comm.rank == owner:
+                ev_c = ops.record_event() if self.sums._timing() else None
                 XcarT, tot = ops.finalize(*fin, tot_out=None if rv is None else rv["tot"])
                 PhiT = ops.nullspace(XcarT, s, S)
                 keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, tot, S, s, out=rv)
+                if ev_c is not None:                             # the round's chain of single-work-group kernels
+                    trace.chain_events.append((ev_c, ops.record_event()))
             if owner is not None:
                 # the outcome of the owner's reduction (w_star | tot | info, kept, keep_rank: 3 S + 1 doubles), stream-ordered
                 comm.broadcast(res, src=owner)
@@ -706,12 +709,15 @@ class Batch:
             cluster = not getattr(self, "_no_cluster", False)
             res, rv = ops.reduction_result(M) if shared else (None, None)
             if not shared or comm.rank == red_rank:
+                ev_c = ops.record_event() if (trace is not None and trace.time_kernels and self._gpu_nullspace(M)) else None
                 XcarT, tot = ops.finalize(parts, parts.shape[0], parts.shape[1], q, S_r, self.diagU, m, min(m, S_r),
                                           self.diag_noise, self.wrow, tail_row, n_tail_diag,
                                           tot_out=None if rv is None else rv["tot"])
                 PhiT = yield from self._nullspace(XcarT, s, M, cluster)      # :140-143 (rows = null-space vectors)
                 with _Timer(ops, trace, "eliminate"):
                     keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, tot, M, s, cluster, out=rv)
+                if ev_c is not None:
+                    trace.chain_events.append((ev_c, ops.record_event()))
             elif not self._gpu_nullspace(M):
                 yield _recorded_event(ops)                       # the reducing rank waits for its host SVD here: same yield count
             if shared:
@@ -916,7 +922,8 @@ class FusedSums:
         if ev0 is not None and p_hi > p_lo:
             # pairs this launch evaluates: one class launch covers n_ch of class_mod classes of its range
             frac = (n_ch / class_mod) if class_mod else 1.0
-            info = dict(pairs=float(p_hi - p_lo) * b.m_ext * frac, R=(p_hi - p_lo) * frac, m=b.m_ext, S=S_, chunks=n_ch)
+            info = dict(pairs=float(p_hi - p_lo) * b.m_ext * frac, R=(p_hi - p_lo) * frac, m=b.m_ext, S=S_, chunks=n_ch,
+                        class_mod=class_mod)
             b.trace.kernel_events.append((ev0, ops.record_event(), info))
             if clk is not None:
                 info["clock_mhz"] = clk

@@ -72,16 +72,40 @@ class TorchDistComm:
         ask for the slots in the same order -- ``run_many`` does, up front).  Collectives of one process group execute in
         issue order on one internal stream: with owner-rank reductions a batch's broadcast waits for the owner's chain of
         single-work-group kernels, and on a shared group every other batch's all-gather would queue behind it.  One group
-        (= one RCCL communicator) per batch in flight keeps the batches' exchanges independent."""
-        key = (id(self.group), i)
-        comm = _SLOT_COMMS.get(key)
-        if comm is None:
-            ranks = list(range(self.dist.get_world_size())) if self.group is None else self.dist.get_process_group_ranks(self.group)
-            comm = _SLOT_COMMS[key] = TorchDistComm(self.dist.new_group(ranks=ranks))
+        (= one RCCL communicator) per batch in flight keeps the batches' exchanges independent.
+
+        The cache is keyed on the parent process-group OBJECT (held by the entry, so its id cannot be reused while the entry
+        lives; the default group resolves to the object of the CURRENT initialisation) and an entry whose sub-group no longer
+        answers -- ``destroy_process_group()`` + re-init in one process: test suites, long-lived services -- is rebuilt."""
+        parent = self.group if self.group is not None else self.dist.group.WORLD
+        key = (id(parent), i)
+        hit = _SLOT_COMMS.get(key)
+        if hit is not None and hit[0] is parent:
+            try:
+                self.dist.get_rank(hit[1].group)                 # raises once the sub-group has been destroyed
+                return hit[1]
+            except Exception:
+                pass
+        ranks = list(range(self.dist.get_world_size())) if self.group is None else self.dist.get_process_group_ranks(self.group)
+        comm = TorchDistComm(self.dist.new_group(ranks=ranks))
+        _SLOT_COMMS[key] = (parent, comm)
         return comm
 
 
-_SLOT_COMMS = {}                 # (id of the parent group, slot) -> TorchDistComm on its own process group
+_SLOT_COMMS = {}                 # (id of the parent group, slot) -> (parent group, TorchDistComm on its own process group)
+
+
+def release_slot_comms():
+    """Destroy the per-slot process groups ``TorchDistComm.for_slot`` created (collective: every rank calls it) and forget them."""
+    import torch.distributed as dist
+
+    for _, comm in list(_SLOT_COMMS.values()):
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group(comm.group)
+        except Exception:
+            pass                                                 # (already gone with its parent)
+    _SLOT_COMMS.clear()
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -98,6 +122,7 @@ class EngineTrace:
     keep_tensors: bool = False
     time_kernels: bool = False                      # record HIP events around every block-sum launch
     kernel_events: list = field(default_factory=list)   # (start_evt, end_evt, dict(pairs=, R=, m=, S=))
+    chain_events: list = field(default_factory=list)    # time_kernels: (start_evt, end_evt) around each round's null space + elimination
     sample_clock: object = None                     # time_kernels: a HipOps on a SECOND stream -> shader clock beside each class launch
     host_sync: bool = True                          # synchronise around phases to attribute host timers
 
@@ -163,14 +188,15 @@ class RecombinationEngine:
             ordered = self.comm.world > 1
         results = [None] * len(jobs)
         pending = deque(enumerate(jobs))
-        free = deque(slot_ops)
-        active = deque()                                        # [job index, generator, ops, event it waits for]
+        active = deque()                                        # [job index, generator, (ops, comm), event it waits for]
         pipelined = len(slot_ops) > 1
         # Several ranks, several batches in flight: batch k's per-round reductions run on rank k mod G only (the outcome is
         # broadcast), so every GPU carries 1/G of the chains instead of all of them; each batch in flight talks on a process
-        # group of its own (``TorchDistComm.for_slot``).  Job k -> group k mod slots: the same on every rank by construction.
+        # group of its own (``TorchDistComm.for_slot``).
         owner_mode = cfg.OWNER_RANK_REDUCTION and self.comm.world > 1 and pipelined
-        slot_comms = [self.comm.for_slot(i) for i in range(len(slot_ops))] if owner_mode else None
+        # (ops, communicator) PAIRS: the process group belongs to the slot a batch actually takes -- "one group per batch in
+        # flight" holds whichever batch finishes first (with FIFO resumption the slots free up in one order on every rank)
+        free = deque((ops, self.comm.for_slot(i) if owner_mode else self.comm) for i, ops in enumerate(slot_ops))
         # every job re-seeds the generator: the Gaussian draw of a batch (2.2 ms of host time at the headline size) then runs
         # on the batch's owner alone instead of on every rank; the generators are put back in step after the last job
         draw_on_owner = owner_mode and bool(jobs) and all(j.seed is not None for j in jobs)
@@ -178,29 +204,29 @@ class RecombinationEngine:
 
         def advance(entry):
             """Resume a batch until its next wait (-> True) or its end (-> False, result stored, slot freed)."""
-            k, gen, ops, _ = entry
-            with _stream_of(ops):
+            k, gen, slot, _ = entry
+            with _stream_of(slot[0]):
                 try:
                     entry[3] = next(gen)
                     return True
                 except StopIteration as stop:
                     results[k] = stop.value
                     jobs[k].times["done"] = time.perf_counter()
-                    free.append(ops)
+                    free.append(slot)
                     return False
 
         while pending or active:
             while pending and free:
                 k, job = pending.popleft()
-                ops = free.popleft()
+                slot = free.popleft()
+                ops, comm = slot
                 if job.seed is not None:
                     torch.manual_seed(job.seed)
                 job.times["start"] = time.perf_counter()
-                comm = slot_comms[k % len(slot_comms)] if owner_mode else self.comm
                 batch = Batch(ops, comm, job.pts_local, job.gid0, job.n_total, job.pts_nys, job.num_pts, job.kernel,
                               job.trace, job.variant, job.init_weights, job.objective, pipelined=pipelined,
                               owner=(k % self.comm.world) if owner_mode else None, draw_on_owner=draw_on_owner)
-                entry = [k, batch.steps(), ops, None]
+                entry = [k, batch.steps(), slot, None]
                 alive = advance(entry)
                 if k == len(jobs) - 1:                           # (the draw belongs to a batch's first segment)
                     last_drew = getattr(batch, "drew_test_matrix", True) is not False

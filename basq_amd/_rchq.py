@@ -120,8 +120,12 @@ _DEFAULT_POOL = SlotPool()
 
 
 def release_slots():
-    """Free the streams and cached buffers ``recombination_many`` / ``recombination_many_sharded`` keep between calls."""
+    """Free the streams and cached buffers ``recombination_many`` / ``recombination_many_sharded`` keep between calls, and the
+    per-slot process groups of the latter (collective on several ranks: every rank calls it)."""
+    from ._engine import release_slot_comms
+
     _DEFAULT_POOL.release()
+    release_slot_comms()
 
 
 def _run_many(jobs, device, comm, in_flight, timings=None, pool: SlotPool | None = None):

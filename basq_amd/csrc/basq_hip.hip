@@ -2360,7 +2360,8 @@ __global__ void __launch_bounds__(WPG * 64) car_eliminate_gring_kernel(const dou
             if (__all(f != 0u) || ++spins > (1u << 12)) break;    // (a member that is not running yet counts as elsewhere)
             __builtin_amdgcn_s_sleep(1);
         }
-        if (lane == 0) local_l = __all(f == mine) ? 1 : 0;
+        const bool same = __all(f == mine);                       // voted by all 64 lanes, OUTSIDE the lane-0 branch
+        if (lane == 0) local_l = same ? 1 : 0;
     }
     __syncthreads();
     const bool local = local_l != 0;

@@ -168,40 +168,60 @@ def main():
             parity["indices_identical"] = bool(parity["indices_identical"] and same)
             parity["max_rel_weight_error"] = max(parity["max_rel_weight_error"], rel) if same else float("nan")
 
-    # ---- kernel-level roofline: one extra traced batch (HIP events on the launch stream, no host syncs: the batch stays on
-    #      the code path the timed steps take -- descriptor-driven rounds -- and reports its launches after the fact) ----
+    # ---- kernel-level roofline: traced batches (HIP events on the launch stream, no host syncs: the batch stays on the code
+    #      path the timed steps take -- descriptor-driven rounds -- and reports its launches after the fact).  The roofline
+    #      numbers come from a batch WITHOUT the clock sampler; the shader clock is sampled in a batch of its own, and its
+    #      samples are only kept if the sampled launches took what the unsampled ones took (round 4's driver run: the sampler's
+    #      stream landed on the hardware queue of the launch stream, the 8-ms sampler ran IN FRONT of the block sums instead of
+    #      beside them, and its time was booked as the kernel's: frac 0.255 instead of 0.488) ----
     from basq_amd._ops import HipOps
 
-    clock_ops = HipOps(dev, stream=torch.cuda.Stream(device=dev))
-    # (one rank only: with RCCL's streams in the process the sampler's stream can land on the hardware queue of the launch
-    #  stream, and the 8-ms sampler then runs IN FRONT of the block sums instead of beside them)
-    sample = None if (args.plain or world > 1 or force_dist) else clock_ops
-    tr = basq_amd.EngineTrace(time_kernels=not args.no_roofline_batch, sample_clock=sample, host_sync=False)
-    one_batch(tr)
-    torch.cuda.synchronize()
+    def traced_batch(sampler=None):
+        t = basq_amd.EngineTrace(time_kernels=not args.no_roofline_batch, sample_clock=sampler, host_sync=False)
+        one_batch(t)
+        torch.cuda.synchronize()
+        return t
+
+    def launch_figures(t):
+        """-> block-sum ms, pairs, launches, ms of the chains (null space + elimination), ms of each class launch."""
+        ms = sum(a.elapsed_time(b) for a, b, _ in t.kernel_events)
+        pairs = sum(info["pairs"] for _, _, info in t.kernel_events)
+        chain = sum(a.elapsed_time(b) for a, b in t.chain_events)
+        cls_ms = [a.elapsed_time(b) for a, b, info in t.kernel_events if info.get("chunks", 0) >= 2 and info.get("class_mod", 0) > 0]
+        return ms, pairs, len(t.kernel_events), chain, cls_ms
+
+    tr = traced_batch()
+    k_ms, k_pairs, k_launches, chain_ms, class_ms = launch_figures(tr)
+
     # the shader clock the class launches ran at: one wave on a second stream samples it every 250 us while the launch runs.
     # A full fp64 load that follows the previous batch's chain of single-work-group reductions opens at ~2.05 GHz and gains
     # only ~20 MHz per ms (tools/clock_probe.hip, profiles/r04_l_shader_clock_after_idle.txt)
-    clk, clk_w = [], 0.0
-    for a, b, info in tr.kernel_events:
-        if "clock_mhz" in info:
-            w_ms = a.elapsed_time(b)
-            series = info.pop("clock_mhz").tolist()[: max(1, min(32, int(w_ms / 0.25)))]      # the samples inside the launch
-            mean = sum(series) / len(series)
-            clk.append(dict(classes=info["chunks"], ms=round(w_ms, 3), mhz_mean=round(mean), mhz_first=round(series[0]),
-                            mhz_last=round(series[-1])))
-            clk_w += mean * w_ms
+    clock_ops = HipOps(dev, stream=torch.cuda.Stream(device=dev))
+    clk, clk_w, clock_note = [], 0.0, None
+    if not (args.plain or args.no_roofline_batch or world > 1 or force_dist):
+        tr_clk = traced_batch(clock_ops)
+        sampled_ms = launch_figures(tr_clk)[4]
+        # the sampler must have run BESIDE the launches: each sampled class launch within 15 % of its unsampled twin
+        beside = len(sampled_ms) == len(class_ms) and all(b <= 1.15 * a + 0.05 for a, b in zip(class_ms, sampled_ms))
+        if beside:
+            for a, b, info in tr_clk.kernel_events:
+                if "clock_mhz" in info:
+                    w_ms = a.elapsed_time(b)
+                    series = info.pop("clock_mhz").tolist()[: max(1, min(32, int(w_ms / 0.25)))]  # the samples inside the launch
+                    mean = sum(series) / len(series)
+                    clk.append(dict(classes=info["chunks"], ms=round(w_ms, 3), mhz_mean=round(mean), mhz_first=round(series[0]),
+                                    mhz_last=round(series[-1])))
+                    clk_w += mean * w_ms
+        else:
+            clock_note = ("clock samples DISCARDED: the sampler's stream was serialised with the launch stream on this box "
+                          f"(class launches {[round(v, 3) for v in class_ms]} ms unsampled, {[round(v, 3) for v in sampled_ms]} ms "
+                          "with the sampler); the roofline figures are from the unsampled batch and unaffected")
     clk_ms = sum(c["ms"] for c in clk)
     clock_in_situ = clk_w / clk_ms if clk_ms > 0 else None              # MHz, time-weighted over the class launches
-    k_ms = sum(a.elapsed_time(b) for a, b, _ in tr.kernel_events)
-    k_pairs = sum(info["pairs"] for _, _, info in tr.kernel_events)
-    k_launches = len(tr.kernel_events)
     # what the REFERENCE's loop evaluates for the same batch (SURVEY §8d: m * sum_r R_r + m^2): the residue-class block sums
     # evaluate about half of it (rounds inside an epoch regroup the previous sums instead)
     ref_pairs = float(m) * sum(r["R"] for r in tr.rounds) + float(m) * m
-    flops = k_pairs * (3 * d + 3)
     bytes_alg = sum(info["R"] * (8 * d + 16) + 8 * info["m"] * d for _, _, info in tr.kernel_events)
-    achieved_tf = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
 
     # ---- the same kernel in STEADY STATE: the round-1 class launch repeated back to back.  Inside a batch that launch opens on
     #      a chip that clocked down during the previous batch's chain of single-work-group reductions (tools/idle_probe.py:
@@ -229,21 +249,56 @@ def main():
                 run()
             e1.record()
             torch.cuda.synchronize()
-            # one more launch with the clock sampled beside it
+            ms = e0.elapsed_time(e1) / 4
+            # one more launch with the clock sampled beside it (kept only if the sampler did run BESIDE the launch)
             ev = ops.record_event()
             clock_ops.wait_event(ev)
-            clk_s = clock_ops.shader_clock_mhz(max(1, int(e0.elapsed_time(e1) / 4 / 0.25)), 250)
+            clk_s = clock_ops.shader_clock_mhz(max(1, int(ms / 0.25)), 250)
             run()
+            e2 = ops.record_event()
             torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 4
+            clk_steady = float(clk_s.mean().item()) if ev.elapsed_time(e2) <= 1.15 * ms + 0.05 else None
             tf = float(Rr) * m * (3 * d + 3) / (ms * 1e-3) / 1e12
             steady = dict(achieved=tf, frac=tf / PEAK_FP64_VECTOR_TFLOPS, ms_per_launch=ms, pairs_per_launch=float(Rr) * m,
-                          shader_clock_MHz=float(clk_s.mean().item()),
+                          shader_clock_MHz=clk_steady,
                           note="the 16-class round-1 launch repeated back to back (chip at its sustained clock); inside a batch "
                                "the same launch starts on a chip that clocked down during the preceding chain of "
                                "single-work-group reductions: profiles/r04_h_block_sums_after_idle_or_chain.txt, "
                                "profiles/r04_l_shader_clock_after_idle.txt")
         del pa, pb, mu0
+
+    # ---- self-check of the roofline figures before they are printed (review r04: 17 ms of block sums inside an 18.6-ms batch
+    #      went out unnoticed).  (1) everything the traced batch timed runs on ONE stream, one after the other: block sums + the
+    #      chains of null space + elimination must fit into a synchronised batch; (2) the round-1 class launch cannot take more
+    #      than 1.25 x its back-to-back time scaled by the clock it was given (2.4 GHz nominal when no sample exists: the ramp
+    #      after a chain costs ~18 %).  A violated check retakes the traced batch once; a second violation marks the line.
+    def roofline_checks(k_ms_, chain_ms_, class_ms_):
+        out = {}
+        med = sorted(per_seed_ms)[len(per_seed_ms) // 2] if per_seed_ms else None
+        if med is not None and k_ms_ > 0:
+            out["blocksum_plus_chain_ms"] = round(k_ms_ + chain_ms_, 3)
+            out["median_ms_per_seed"] = round(med, 3)
+            out["fits_in_batch"] = bool(k_ms_ + chain_ms_ <= 1.02 * med)
+        if steady is not None and class_ms_:
+            clock = clock_in_situ or 2030.0                      # (no sample: the in-situ clock of every builder run, r04)
+            bound = 1.25 * steady["ms_per_launch"] * (2400.0 / clock)
+            out["class_launch_ms"] = round(max(class_ms_), 3)
+            out["class_launch_bound_ms"] = round(bound, 3)
+            out["class_launch_plausible"] = bool(max(class_ms_) <= bound)
+        out["ok"] = all(v for k_, v in out.items() if isinstance(v, bool))
+        return out
+
+    check = roofline_checks(k_ms, chain_ms, class_ms) if not args.no_roofline_batch else {"ok": True}
+    roofline_suspect = False
+    if not check["ok"]:
+        first = dict(check, kernel_ms_per_batch=k_ms, chain_ms_per_batch=chain_ms)
+        tr = traced_batch()
+        k_ms, k_pairs, k_launches, chain_ms, class_ms = launch_figures(tr)
+        check = roofline_checks(k_ms, chain_ms, class_ms)
+        check["first_attempt"] = first
+        roofline_suspect = not check["ok"]
+    flops = k_pairs * (3 * d + 3)
+    achieved_tf = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
 
     # Hardware counters of the block-sum launches of one batch: rocprofv3 --pmc passes of THIS bench command (one counter
     # group per pass, tools/gpu_jobs.sh pmc -> tools/pmc_summary.py), committed with the commit they were taken on.
@@ -301,7 +356,17 @@ def main():
     if dist is not None:
         import basq_amd._config as bcfg
 
-        rccl_info = {"world": dist.get_world_size(), "backend": dist.get_backend(),
+        # proof that the N ranks sat on N DISTINCT GPUs: every rank's device identity, gathered
+        prop = torch.cuda.get_device_properties(dev)
+        ident = {"rank": rank, "local_rank": local_rank, "name": prop.name,
+                 "uuid": str(getattr(prop, "uuid", "")) or None,
+                 "pci": "%04x:%02x:%02x" % (getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", 0),
+                                            getattr(prop, "pci_device_id", 0)),
+                 "hip_visible": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")}
+        idents = [None] * dist.get_world_size()
+        dist.all_gather_object(idents, ident)
+        rccl_info = {"world": dist.get_world_size(), "backend": dist.get_backend(), "devices": idents,
+                     "distinct_devices": len({(i["uuid"], i["pci"]) for i in idents}),
                      "sequential_batch": "reduction replicated on every rank (one all-gather of the (q+1) x 2n message per round)",
                      "batches_in_flight": ("owner-rank reductions: batch k's null space + elimination on rank k mod world, outcome "
                                            "broadcast (3*2n+1 doubles) on the batch's own process group"
@@ -362,9 +427,12 @@ def main():
                 "steady_state": steady,
                 # the clock the class launches (most of kernel_ms_per_batch) actually had, and the fraction against the fp64
                 # peak AT that clock: what the kernel leaves on the table, as opposed to what the power manager withholds
-                "shader_clock_MHz_in_situ": clock_in_situ, "shader_clock_samples": clk or None,
+                "shader_clock_MHz_in_situ": clock_in_situ, "shader_clock_samples": clk or None, "shader_clock_note": clock_note,
                 "frac_at_in_situ_clock": (achieved_tf / (PEAK_FP64_VECTOR_TFLOPS * clock_in_situ / 2400.0)) if clock_in_situ else None,
                 "launches_per_batch": k_launches, "kernel_ms_per_batch": k_ms, "pairs_per_batch": k_pairs,
+                # the chains of single-work-group kernels (finalize + null space + elimination per round) of the same traced batch
+                "chain_ms_per_batch": chain_ms, "chain_rounds": len(tr.chain_events),
+                "self_check": check, "roofline_suspect": roofline_suspect,
                 "reference_pairs_per_batch": ref_pairs,
                 "whole_batch_TFLOPs_by_reference_count": ref_pairs * (3 * d + 3) / (dt / args.steps) / 1e12,
                 "flops_per_pair": 3 * d + 3,
@@ -377,12 +445,14 @@ def main():
                 "hbm_algorithmic_GBs": bytes_alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0,
                 "hbm_peak_GBs": PEAK_HBM_GBS,
                 "note": "33 flop per pair by SURVEY's count (3d + 3); launch durations by HIP events on the launch stream over "
-                        "one traced batch that takes the timed code path (descriptor-driven rounds), rank 0",
+                        "one traced batch that takes the timed code path (descriptor-driven rounds), rank 0, NO clock sampler in "
+                        "that batch (the clock is sampled in a second traced batch and kept only if its launches took the same time)",
             },
             "cpu_baseline": cpu,
             "result_digest": {"n_selected": int(idx.numel()), "w_sum": float(w.sum().item())},
             "parity_vs_golden": parity,
         }
+        out["concurrent_timed_out"] = bool(note)                 # machine-readable twin of `concurrent_note`
         if note:
             out["concurrent_note"] = note
         return json.dumps(out)
@@ -413,6 +483,8 @@ def main():
                 emit(build_line(dict(concurrent), note="the runs with batches in flight did not ALL finish within the watchdog's limit "
                                                        "on this machine (those that did are reported): value and roofline are from "
                                                        "the sequential path, completed before"))
+            # (exit code 0 on purpose: `value` and the roofline were measured before, on the sequential path, and a driver that
+            #  drops the line of a non-zero exit would lose them; the time-out itself is in `concurrent_timed_out`)
             os._exit(0)
 
         watchdog = threading.Timer(float(os.environ.get("BASQ_BENCH_CONCURRENT_LIMIT_S", "240")), give_up)

@@ -355,7 +355,10 @@ def divide_and_recombine_sober(samp, U, pt, kernel, mu=None, trace: Trace | None
             w, sub = objective_thinning(feat_raw[keep].T, obj_sets[keep], w)
             keep = keep[sub]
         if trace is not None:
-            trace.rounds.append(RoundTrace(R, nb, len(tail), kept_sets=keep.clone(), kept_weights=w.clone()))
+            rt = RoundTrace(R, nb, len(tail), kept_sets=keep.clone(), kept_weights=w.clone())
+            if trace.keep_tensors and obj is None:
+                rt.bary, rt.tot_weights = feat.clone(), tot.clone()
+            trace.rounds.append(rt)
         survivors = grid[:, keep].reshape(-1)
         drop = torch.ones(grid.shape[1]).to(torch.bool)
         drop[keep] = 0

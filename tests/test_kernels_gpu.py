@@ -977,7 +977,7 @@ def test_shader_clock_sampler(hip_ops):
 
 
 _SPREAD_CHILD = r"""
-import sys, torch
+import sys, time, torch
 sys.path.insert(0, sys.argv[1])
 from basq_amd._ops import HipOps
 ops = HipOps(torch.device("cuda:0"))
@@ -987,9 +987,11 @@ for s, M in ((200, 400), (150, 400)):
     X = torch.randn(s, M, generator=g, dtype=torch.float64); X[0] = 1.0
     mu = torch.rand(M, generator=g, dtype=torch.float64) + 0.05; mu = mu / mu.sum()
     for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
         P = ops.nullspace(ops.to_device(X), s, M)
         kr, kept, w, info = ops.car_eliminate(P.clone(), ops.to_device(mu), M, s)
-        out[(s, M, rep)] = (P.cpu(), kr.cpu(), w.cpu(), info.cpu())
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        out[(s, M, rep)] = (P.cpu(), kr.cpu(), w.cpu(), info.cpu(), dt)
 torch.save(out, sys.argv[2])
 """
 
@@ -997,7 +999,10 @@ torch.save(out, sys.argv[2])
 def test_cluster_reductions_members_on_different_xcds(tmp_path):
     """The clusters write their granules with plain stores when all members share an XCD and write-through otherwise
     (``cluster_shares_xcd``).  ``BASQ_CLUSTER_SPREAD=1`` deals the members to eight DIFFERENT XCDs: the fall-back path must
-    return the same bits as the same-XCD path (both sum in cluster order), three times in a row."""
+    return the same bits as the same-XCD path (both sum in cluster order), three times in a row -- with status 0 (no member hit
+    its spin limit: status 2) and within a fraction of the time a spin-limit hit takes (``BASQ_GRANULE_SPIN_LIMIT`` sweeps of
+    ~1 us: 0.5 s).  The elimination's placement vote is taken by all 64 lanes of wave 0 (it used to run inside the
+    lane-0 branch, so group 0 always chose plain stores)."""
     import subprocess
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1014,6 +1019,8 @@ def test_cluster_reductions_members_on_different_xcds(tmp_path):
         assert a[3].tolist()[1] == 0 and b[3].tolist()[1] == 0, (key, a[3].tolist(), b[3].tolist())
         assert torch.equal(a[0], b[0]), f"{key}: null space differs between the same-XCD and the spread cluster"
         assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+        if key[2] > 0:                                          # (rep 0 pays the library load and the first launches)
+            assert a[4] < 0.1 and b[4] < 0.1, f"{key}: {a[4]:.3f} s / {b[4]:.3f} s -- a granule spin ran into its limit?"
 
 
 @pytest.mark.parametrize("rows,q", [(10048, 99), (10000, 100), (1000, 30), (130, 7), (5000, 112), (64, 40), (10048, 199), (3000, 113), (700, 200)])
