@@ -23,6 +23,7 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+_COPY_STREAMS = {}               # device index -> the copy stream of ``HipOps.from_pinned_side``
 PROJECT_KSPLIT_MAX = 64          # K slices of the projection GEMM (A/B: tools/ab_engine.py --module _ops)
 
 
@@ -627,9 +628,12 @@ class HipOps:
     def from_pinned_side(self, buf):
         """The same copy on a stream of its own (the copy engine then runs beside whatever the launch stream is busy with --
         the round-1 block sums, for the range finder's 8 MB of uniforms); the launch stream waits for it on the device."""
-        side = self.__dict__.get("_copy_stream")
+        # ONE copy stream per device for the life of the process: the caching allocator keeps a block pool per stream, and
+        # ``recombination()`` builds a fresh HipOps per call -- a stream per call left a 20-MB segment behind on each of torch's 32
+        # pooled streams before they came round again (tools/stall_probe.py: one hipMalloc per batch for the first 32 batches)
+        side = _COPY_STREAMS.get(self.device.index)
         if side is None:
-            side = self.__dict__["_copy_stream"] = torch.cuda.Stream(device=self.device)
+            side = _COPY_STREAMS[self.device.index] = torch.cuda.Stream(device=self.device)
         with torch.cuda.stream(side):
             t = buf.to(self.device, non_blocking=True)
             ev = torch.cuda.Event()

@@ -61,16 +61,19 @@ def recombination(
 
 
 def recombination_sharded(pts_local, gid0, n_total, pts_nys, num_pts, kernel, device, group=None,
-                          trace: EngineTrace | None = None):
+                          trace: EngineTrace | None = None, comm=None):
     """Multi-GPU entry: every rank passes its contiguous slice ``pts_rec[gid0 : gid0 + len(pts_local)]``.
 
     One process per GPU, ``torch.distributed`` initialised by the caller (backend ``nccl`` = RCCL).
     Slices must tile ``0..n_total`` in rank order; ``pts_nys`` identical on all ranks.  The result is
     identical on every rank and equal (indices) to the single-GPU result.
+
+    ``comm``: a communicator object to use instead of ``TorchDistComm(group)`` -- anything with its interface (``rank``,
+    ``world``, ``all_gather``, ``broadcast``, ``for_slot``); the two-processes-on-one-GPU test passes a host-staged one.
     """
     kernel = _as_kernel_object(kernel)
     ops = HipOps(device)
-    eng = RecombinationEngine(ops, TorchDistComm(group))
+    eng = RecombinationEngine(ops, comm if comm is not None else TorchDistComm(group))
     return eng.run(pts_local, int(gid0), int(n_total), pts_nys, int(num_pts), kernel, trace)
 
 
@@ -171,7 +174,7 @@ def recombination_many(calls, device, in_flight: int = 2, seeds=None, traces=Non
     return _run_many(jobs, device, LocalComm(), in_flight, timings, pool)
 
 
-def recombination_many_sharded(calls, device, group=None, in_flight: int = 4, seeds=None, timings=None):
+def recombination_many_sharded(calls, device, group=None, in_flight: int = 4, seeds=None, timings=None, comm=None):
     """``recombination_many`` with every pool sharded over the ranks of ``group``: ``calls`` holds
     ``(pts_local, gid0, n_total, pts_nys, num_pts, kernel)`` per recombination (see ``recombination_sharded``).
 
@@ -180,7 +183,7 @@ def recombination_many_sharded(calls, device, group=None, in_flight: int = 4, se
     same number of calls; the scheduler resumes batches in a fixed order, so the ranks issue their collectives in the
     same sequence.
     """
-    comm = TorchDistComm(group)
+    comm = comm if comm is not None else TorchDistComm(group)     # (``comm``: see ``recombination_sharded``)
     jobs = []
     for k, (pts_local, gid0, n_total, pts_nys, num_pts, kernel) in enumerate(calls):
         jobs.append(Job(pts_local, int(gid0), int(n_total), pts_nys, int(num_pts), _as_kernel_object(kernel),

@@ -438,3 +438,56 @@ def test_sharded_descriptor_driven_rounds(name, world):
         assert kept == [r["kept"] for r in fx["rounds"]]
         assert ((torch.tensor(w, dtype=torch.float64) - gw).abs() / gw).max().item() <= 1e-6
     assert all(r[1] == res[0][1] and r[2] == res[0][2] for r in res)
+
+
+# ---- the test-only host-staged communicator (tests/host_staged_comm.py) itself, on the CPU --------------------------------
+def _host_staged_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from basq_amd._engine import Job, RecombinationEngine
+        from basq_amd._partition import initial_shards
+        from tests.cpu_stand_in import CpuStandInOps
+        from tests.host_staged_comm import HostStagedComm
+
+        comm = HostStagedComm()
+        names = ["rbf_ragged", "cfg1_posterior_1e4"]
+        out, jobs = [], []
+        for name in names:
+            c = BY_NAME[name]
+            pts, nys = build_pool(c)
+            off, n = initial_shards(c["N"], world)[rank]
+            torch.manual_seed(c["torch_seed"])
+            idx, w = RecombinationEngine(CpuStandInOps(), comm).run(pts[off:off + n].clone(), off, c["N"], nys, c["n"],
+                                                                    build_product_kernel(c))
+            out.append((idx.tolist(), w.tolist()))
+            jobs.append(Job(pts[off:off + n].clone(), off, c["N"], nys, c["n"], build_product_kernel(c), seed=c["torch_seed"]))
+        many = RecombinationEngine(CpuStandInOps(), comm).run_many(jobs + jobs, [CpuStandInOps(), CpuStandInOps()])
+        q.put((rank, out, [(i.tolist(), w.tolist()) for i, w in many], sorted((k, s.calls["broadcast"]) for k, s in comm._slots.items())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_host_staged_comm_drives_the_engine():
+    """The communicator the two-processes-on-one-GPU test uses (``tests/test_two_ranks_one_gpu.py``) against the goldens on the CPU
+    stand-in: sequential sharded calls and four batches on two slots (owner-rank reductions, one gloo group per slot)."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_host_staged_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, many, slot_b in res:
+        for nm, (idx, w) in zip(["rbf_ragged", "cfg1_posterior_1e4"], out):
+            assert idx == load_golden(nm)["idx"], f"rank {rank} {nm}"
+        for nm, (idx, w) in zip(["rbf_ragged", "cfg1_posterior_1e4"] * 2, many):
+            assert idx == load_golden(nm)["idx"], f"rank {rank} {nm} (in flight)"
+        assert len(slot_b) == 2 and all(n > 0 for _, n in slot_b)
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]

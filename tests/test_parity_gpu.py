@@ -190,7 +190,7 @@ def test_differential_fuzz_gpu():
 
 # the cases of ``structured_fuzz_cases(11, 150)`` outside the 1e-5 bar, each explained by the reference's own sensitivity (the
 # first four are the ones of round 3's builder-run log, profiles/r06_x_fuzz_more_seeds_9_10_11.txt)
-STRUCTURED_FUZZ_UNSTABLE = [2, 19, 21, 93]
+STRUCTURED_FUZZ_UNSTABLE = [2, 19, 21, 93, 135]
 
 
 def test_structured_differential_fuzz_gpu():
