@@ -2816,23 +2816,18 @@ __device__ __forceinline__ void wave_sum4(double& x0, double& x1, double& x2, do
 
 // Register-resident form for m <= 16*NREG rows, n <= 64*NV columns (the headline 100 x 200 fits NREG = 7, NV = 4):
 // the whole matrix lives in VGPRs (row r -> wave r % 16, slot r / 16; lanes own column PAIRS, so the broadcast
-// vectors move as 16-byte LDS accesses), LDS carries only those vectors.  Two barriers per step t:
+// vectors move as 16-byte LDS accesses), LDS carries only those vectors.  Three barriers per step t:
 //   phase A (all waves, live rows r > t only): apply the PREVIOUS left reflector H_{t-1} (deferred), apply G_t
 //       (row dots reduced four at a time, rank-1 update), read column t of the updated rows back through SGPRs,
 //       accumulate this wave's share of column_t^T A and |column_t|^2; the owner of row t+1 publishes that row;
-//   phase B (wave 0, with wave 1 working out H_t's tauq / u scale beside it -- handed over through an LDS flag, no
-//       barrier): sum the 16 partials, w = u^T A, update row t+1 with H_t and form G_{t+1} from the result
-//       -> v_{t+1}, tau_{t+1}.
+//   phase B, spread over NV waves (one per SIMD) with ONE COLUMN PER LANE (round 5; rounds 2-4 ran it on wave 0 alone, four
+//       columns per lane: 2 400 of a step's 8 000 cycles with fifteen waves parked, profiles/r06_v_bidiag_phase_clock_100x200.txt):
+//       B1: every B wave sums the 16 partial rows of ITS 64 columns in one LDS pass, works out H_t's tauq / u scale from the 16
+//           partial norms (redundantly: no hand-over), forms w = u^T A and row t+1 after H_t on its columns, and reduces its share of
+//           the new row's norm;
+//       B2 (behind a barrier that carries the NV partial norms and alpha): G_{t+1}'s parameters (redundantly, bit-identical in
+//           every B wave), v_{t+1} on its columns -> LDS and V.
 // Same reflectors as dgebd2; only the association of the sums differs (agreement with LAPACK ~1e-14).
-#ifndef BASQ_NS_EARLY_H
-#define BASQ_NS_EARLY_H 0        // 1: every wave but wave 0 applies the left reflector H_t beside wave 0's make_right instead of at the
-#endif                           // head of the next phase A.  Measured (round 4, 100 x 200, null space per call): 280.0 us without,
-                                 // 292.6 with, 289.8 with s_sleep in the spin, 299.5 with the serial waves at raised priority; 9 spilled
-                                 // registers.  Phase A is not shortened by the FMAs it loses, the serial wave is slowed by its SIMD mates.
-#ifndef BASQ_NS_EXP
-#define BASQ_NS_EXP 0            // timing experiments only (bits: 1 = four of the sixteen partial rows summed, 2 = no norm / reflector
-#endif                           // parameters in make_right, 4 = no wave sums of the row dots, 8 = no partial-row accumulation, 16 = no left-reflector
-                                 // update, 32 = no right-reflector update / column read-back, 64 = a quarter of the dot product)
 template <int NV, int NREG>
 __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const double* __restrict__ X, int m, int n,
                                                                      double* __restrict__ V,
@@ -2843,12 +2838,9 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
     __shared__ __attribute__((aligned(16))) double wsh[NC];          // w of H_{t-1}, zero for c < t
     __shared__ __attribute__((aligned(16))) double r1sh[NC];         // row t+1 after G_t
     __shared__ __attribute__((aligned(16))) double wpart[NW * NC];   // per-wave partials of column_t^T A
-    __shared__ double sspart[NW];
+    __shared__ __attribute__((aligned(16))) double sspart[NW];
     __shared__ double par[4];             // tau_t, tauq_{t-1}, u-scale_{t-1}, alpha of H_t
-    __shared__ int hready;                // = t + 1 once wave 1 has published H_t's parameters
-#if BASQ_NS_EARLY_H
-    __shared__ int wready;                // = t + 1 once wave 0 has published w of H_t
-#endif
+    __shared__ double ssb[NV + 1];        // phase B: the B waves' shares of |row t+1|^2 beyond its pivot, and the pivot itself
 #ifdef BASQ_NS_PROF
     // phase clock of tools/ns_prof.hip: cycles per phase summed over all steps in SCALAR registers (the kernel sits at its VGPR
     // ceiling: stamps that touch a vector register make it spill ~370 of them and run 7 x slower)
@@ -2864,11 +2856,7 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
 #else
 #define BASQ_NS_LSTAMP(t, slot) do { } while (0)
 #endif
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) hready = 0;
-#if BASQ_NS_EARLY_H
-    if (tid == 0) wready = 0;
-#endif
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: a scalar)
     // slot k of this lane holds column COL(k); column c sits in lane (c & 127) >> 1, slot (c & 1) + 2 (c >> 7)
 #define BASQ_COL(k) (2 * lane + ((k) & 1) + 128 * ((k) >> 1))
     double a[NG * 4][NV], cprev[NG * 4];
@@ -2882,40 +2870,44 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
             a[jr][k] = (jr < NREG && r < m && c < n) ? X[(size_t)r * n + c] : 0.0;
         }
     }
-    // right reflector G_t from the row held in rn[] (lanes own columns); publishes v_t, tau_t
-    auto make_right = [&](const double (&rn)[NV], int t) {
-        const int tk = (t & 1) + 2 * (t >> 7), tl = (t & 127) >> 1;
-        double ss = 0.0, al = 0.0;
+    // G_t's second half, on the B waves (column cb = 64 wv + lane each): parameters from the NV partial norms + the pivot in
+    // ssb[] (summed in index order: the same bits in every B wave), then v_t on the wave's columns -> vsh, V; tau -> par[0], tau_g
+    auto publish_right = [&](double rn, int t) {
+        const int cb = 64 * wv + lane;
+        double ss = ssb[0];
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int c = BASQ_COL(k);
-            if (c > t) ss += rn[k] * rn[k];
-            if (k == tk) al = rn[k];
-        }
-#if BASQ_NS_EXP & 2
-        const double alpha = al;
-        double tau = 1.5, scale = 0.1 + ss * 1e-30 + alpha * 1e-30;
-#else
-        ss = wave_sum(ss);
-        const double alpha = readlane_f64(al, tl);
+        for (int w = 1; w < NV; ++w) ss += ssb[w];
         double tau, scale;
-        householder_params_fast(alpha, ss, tau, scale);
-#endif
+        householder_params_fast(ssb[NV], ss, tau, scale);
+        const double v = (cb < t) ? 0.0 : ((cb == t) ? 1.0 : rn * scale);
+        vsh[cb] = v;
+        if (cb < n) V[(size_t)t * n + cb] = v;
+        if (tid == 0) { par[0] = tau; tau_g[t] = tau; }
+    };
+    // ... and its first half: this wave's share of |row[t+1:]|^2 and the pivot row[t] -> ssb[]
+    auto norm_share = [&](double rn, int t) {
+        const int cb = 64 * wv + lane;
+        const double ssl = wave_sum((cb > t) ? rn * rn : 0.0);
+        if (lane == 0) ssb[wv] = ssl;
+        if (cb == t) ssb[NV] = rn;
+    };
+    // prologue: G_0 from row 0 (wave 0's slot 0), through the same two halves
+    if (wv == 0) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            const int c = BASQ_COL(k);
-            const double v = (c < t) ? 0.0 : ((c == t) ? 1.0 : rn[k] * scale);
-            vsh[c] = v;
-            if (c < n) V[(size_t)t * n + c] = v;
+            r1sh[BASQ_COL(k)] = a[0][k];
+            wsh[BASQ_COL(k)] = 0.0;
         }
-        if (lane == 0) { par[0] = tau; tau_g[t] = tau; }
-    };
-    if (wv == 0) {
-        make_right(a[0], 0);
-#pragma unroll
-        for (int k = 0; k < NV; ++k) wsh[BASQ_COL(k)] = 0.0;
         if (lane == 0) { par[1] = 0.0; par[2] = 0.0; }
     }
+    __syncthreads();
+    double rn0 = 0.0;
+    if (wv < NV) {
+        rn0 = r1sh[64 * wv + lane];
+        norm_share(rn0, 0);
+    }
+    __syncthreads();
+    if (wv < NV) publish_right(rn0, 0);
     __syncthreads();
     for (int t = 0; t + 1 < m; ++t) {
         const int tk = (t & 1) + 2 * (t >> 7), tl = (t & 127) >> 1;
@@ -2939,63 +2931,42 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
                     const int jr = 4 * g + j, r = wv + NW * jr;
                     dot[j] = 0.0;
                     if (jr < NREG && r > t && r < m) {              // wave-uniform
-#if BASQ_NS_EARLY_H
-                        if (wv == 0) {                              // (the other waves applied H_{t-1} beside make_right)
-                            const double tu = kappa * cprev[jr];
-#pragma unroll
-                            for (int k = 0; k < NV; ++k) a[jr][k] -= tu * wc[k];
-                        }
-#pragma unroll
-                        for (int k = 0; k < NV; ++k) dot[j] += a[jr][k] * vr[k];
-#else
                         const double tu = kappa * cprev[jr];        // H_{t-1}: tauq u_r, u_r = column_{t-1}[r] * scale
 #pragma unroll
                         for (int k = 0; k < NV; ++k) {
-#if !(BASQ_NS_EXP & 16)
                             a[jr][k] -= tu * wc[k];
-#endif
-#if BASQ_NS_EXP & 64
-                            if (k == 0) dot[j] += a[jr][k] * vr[k];
-#else
                             dot[j] += a[jr][k] * vr[k];
-#endif
                         }
-#endif
                     }
                 }
-#if !(BASQ_NS_EXP & 4)
                 wave_sum4(dot[0], dot[1], dot[2], dot[3]);
-#endif
                 if (g == 0) BASQ_NS_LSTAMP(t, 1);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int jr = 4 * g + j, r = wv + NW * jr;
                     if (jr < NREG && r > t && r < m) {
                         const double td = tau * dot[j];             // G_t
-                        double colv = 0.0;
 #pragma unroll
-                        for (int k = 0; k < NV; ++k) {
-#if !(BASQ_NS_EXP & 32)
-                            a[jr][k] -= td * vr[k];
-#endif
-                            if (k == tk) colv = a[jr][k];
-                        }
-#if BASQ_NS_EXP & 32
-                        const double cr = td * 1e-3;
-#else
-                        const double cr = readlane_f64(colv, tl);   // A[r][t] after G_t
-#endif
+                        for (int k = 0; k < NV; ++k) a[jr][k] -= td * vr[k];
+                        // A[r][t] after G_t: slot tk (wave-uniform) of lane tl.  A scalar BRANCH per slot, not a select chain: eight
+                        // v_cndmask per row were a fifth of this phase's vector instructions (the empty volatile asm keeps the
+                        // compiler from converting the branches back into selects)
+                        double cr = 0.0;
+#pragma unroll
+                        for (int k = 0; k < NV; ++k)
+                            if (k == tk) {
+                                cr = readlane_f64(a[jr][k], tl);
+                                asm volatile("");
+                            }
                         cprev[jr] = cr;
                         if (r == t + 1) {
 #pragma unroll
                             for (int k = 0; k < NV; ++k) r1sh[BASQ_COL(k)] = a[jr][k];
                             if (lane == 0) par[3] = cr;
                         } else {
-#if !(BASQ_NS_EXP & 8)
 #pragma unroll
                             for (int k = 0; k < NV; ++k) pw[k] += cr * a[jr][k];
                             ssp += cr * cr;
-#endif
                         }
                     }
                 }
@@ -3008,124 +2979,48 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
         BASQ_NS_LSTAMP(t, 3);
         __syncthreads();
         BASQ_NS_LSTAMP(t, 4);
-#if BASQ_NS_EARLY_H
-        if (wv <= 1) __builtin_amdgcn_s_setprio(3);             // the serial phase ahead of the other waves' early H update
-#endif
-        if (wv == 1) {   // ---- phase B, wave 1: H_t's parameters, concurrently with wave 0's partial-row sum ----
-            double ss2 = 0.0;
+        double rn = 0.0;
+        if (wv < NV) {   // ---- phase B1: one column per lane ----
+            const int cb = 64 * wv + lane;
+            // the 16 partial rows of this column, wave order 0..15 (conflict-free: consecutive lanes, consecutive doubles); two
+            // chains so that the adds do not wait for one another
+            // |column_t|^2 from the 16 partial norms: lane l reads partial l & 15, prefix sums inside the rows of 16 lanes (row_shr
+            // 1, 2, 4, 8), lane 15 read back -- one LDS trip + four DPP steps instead of sixteen dependent adds
+            double ss2 = sspart[lane & 15];
+            ss2 += dpp_shift_f64<0x111, 0xf>(ss2);
+            ss2 += dpp_shift_f64<0x112, 0xf>(ss2);
+            ss2 += dpp_shift_f64<0x114, 0xf>(ss2);
+            ss2 += dpp_shift_f64<0x118, 0xf>(ss2);
+            ss2 = readlane_f64(ss2, 15);
+            // the 16 partial rows of this column (read in groups of four behind compiler fences: left alone, the scheduler hoists all
+            // reads above the sums and spills a dozen registers of the matrix, which lives in this wave's VGPRs throughout); they are
+            // in flight while H_t's parameters go through their chain of dependent operations
+            double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) ss2 += sspart[w];
+            for (int w = 0; w < NW; w += 4) {
+                acc0 += wpart[w * NC + cb];
+                acc1 += wpart[(w + 1) * NC + cb];
+                acc0 += wpart[(w + 2) * NC + cb];
+                acc1 += wpart[(w + 3) * NC + cb];
+                if (w + 4 < NW) asm volatile("" ::: "memory");
+            }
             double tauq, uscale;
-            householder_params_fast(par[3], ss2, tauq, uscale);
-            if (lane == 0) {
-                par[1] = tauq;
-                par[2] = uscale;
-                __hip_atomic_store(&hready, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            householder_params_fast(par[3], ss2, tauq, uscale);     // H_t (every B wave: the same bits, nothing handed over)
             BASQ_NS_LSTAMP(t, 5);
-        }
-        if (wv == 0) {   // ---- phase B, wave 0 ----
-            double rn[NV], accs[NV];
-#pragma unroll
-            for (int k = 0; k < NV; ++k) accs[k] = 0.0;
-            // 16 partial rows x two 16-byte reads per lane.  Left to the compiler these become 32 serialised LDS round
-            // trips (the kernel sits at its VGPR ceiling, so every read reuses one register quad: ~2700 clocks of the
-            // ~5000 of this serial phase, tools/ns_prof.hip); issue them eight at a time instead.
-            static_assert(NV == 4, "the batched read below assumes two column pairs per lane");
-            {
-                typedef double d2_t __attribute__((ext_vector_type(2)));
-                const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) double*)wpart +
-                                      (unsigned)lane * 16u;
-#pragma unroll
-                for (int w0 = 0; w0 < ((BASQ_NS_EXP & 1) ? 4 : NW); w0 += 4) {
-                    d2_t v0, v1, v2, v3, v4, v5, v6, v7;
-                    asm volatile(
-                        "ds_read_b128 %0, %8 offset:%9\n\t"
-                        "ds_read_b128 %1, %8 offset:%10\n\t"
-                        "ds_read_b128 %2, %8 offset:%11\n\t"
-                        "ds_read_b128 %3, %8 offset:%12\n\t"
-                        "ds_read_b128 %4, %8 offset:%13\n\t"
-                        "ds_read_b128 %5, %8 offset:%14\n\t"
-                        "ds_read_b128 %6, %8 offset:%15\n\t"
-                        "ds_read_b128 %7, %8 offset:%16\n\t"
-                        "s_waitcnt lgkmcnt(0)"
-                        : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
-                        : "v"(base), "n"((w0 + 0) * NC * 8), "n"((w0 + 0) * NC * 8 + 1024), "n"((w0 + 1) * NC * 8),
-                          "n"((w0 + 1) * NC * 8 + 1024), "n"((w0 + 2) * NC * 8), "n"((w0 + 2) * NC * 8 + 1024),
-                          "n"((w0 + 3) * NC * 8), "n"((w0 + 3) * NC * 8 + 1024)
-                        : "memory");
-                    accs[0] += v0.x; accs[1] += v0.y; accs[2] += v1.x; accs[3] += v1.y;      // wave order 0..15 kept
-                    accs[0] += v2.x; accs[1] += v2.y; accs[2] += v3.x; accs[3] += v3.y;
-                    accs[0] += v4.x; accs[1] += v4.y; accs[2] += v5.x; accs[3] += v5.y;
-                    accs[0] += v6.x; accs[1] += v6.y; accs[2] += v7.x; accs[3] += v7.y;
-                }
-            }
+            const double r1 = r1sh[cb];
+            const double w_c = (cb > t) ? __builtin_fma(uscale, acc0 + acc1, r1) : 0.0;   // u^T A with u = [1, column * scale]
+            wsh[cb] = w_c;
+            rn = r1 - tauq * w_c;                                                          // row t+1 after H_t
+            norm_share(rn, t + 1);
+            if (tid == 0) { par[1] = tauq; par[2] = uscale; }
             BASQ_NS_LSTAMP(t, 6);
-            {   // spin until wave 1 has published (it always gets there: same loop, same t).  One asm statement: a C++
-                // loop at this point makes the register allocator spill ~500 B per lane in the whole kernel.
-                int seen;
-                const unsigned faddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)&hready;
-                asm volatile(
-                    "BASQ_HREADY_SPIN_%=:\n\t"
-                    "ds_read_b32 %0, %1\n\t"
-                    "s_waitcnt lgkmcnt(0)\n\t"
-                    "v_cmp_ne_u32_e32 vcc, %2, %0\n\t"
-                    "s_cbranch_vccnz BASQ_HREADY_SPIN_%="
-                    : "=&v"(seen)
-                    : "v"(faddr), "s"(t + 1)
-                    : "vcc", "memory");
-            }
-            BASQ_NS_LSTAMP(t, 7);
-            const double tauq = par[1], uscale = par[2];
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                const int c = BASQ_COL(k);
-                const double r1 = r1sh[c];
-                const double wv_c = (c > t) ? (r1 + uscale * accs[k]) : 0.0;   // u^T A with u = [1, column * scale]
-                wsh[c] = wv_c;
-                rn[k] = r1 - tauq * wv_c;                                       // row t+1 after H_t
-            }
-#if BASQ_NS_EARLY_H
-            if (lane == 0) __hip_atomic_store(&wready, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
+        }
+        __syncthreads();
+        BASQ_NS_LSTAMP(t, 7);
+        if (wv < NV) {   // ---- phase B2 ----
+            publish_right(rn, t + 1);
             BASQ_NS_LSTAMP(t, 8);
-            make_right(rn, t + 1);
-            BASQ_NS_LSTAMP(t, 9);
         }
-#if BASQ_NS_EARLY_H
-        else {
-            // every other wave: H_t on its rows r > t + 1 NOW, beside wave 0's make_right, instead of at the head of the next
-            // phase A (w and the parameters are final once wready = t + 1)
-            {
-                int seen;
-                const unsigned faddr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)&wready;
-                asm volatile(
-                    "BASQ_WREADY_SPIN_%=:\n\t"
-                    "s_sleep 1\n\t"
-                    "ds_read_b32 %0, %1\n\t"
-                    "s_waitcnt lgkmcnt(0)\n\t"
-                    "v_cmp_ne_u32_e32 vcc, %2, %0\n\t"
-                    "s_cbranch_vccnz BASQ_WREADY_SPIN_%="
-                    : "=&v"(seen)
-                    : "v"(faddr), "s"(t + 1)
-                    : "vcc", "memory");
-            }
-            const double kap = par[1] * par[2];
-            double wc2[NV];
-#pragma unroll
-            for (int k = 0; k < NV; ++k) wc2[k] = wsh[BASQ_COL(k)];
-#pragma unroll
-            for (int jr = 0; jr < NREG; ++jr) {
-                const int r = wv + NW * jr;
-                if (r > t + 1 && r < m) {                           // wave-uniform
-                    const double tu = kap * cprev[jr];
-#pragma unroll
-                    for (int k = 0; k < NV; ++k) a[jr][k] -= tu * wc2[k];
-                }
-            }
-        }
-        if (wv <= 1) __builtin_amdgcn_s_setprio(0);
-#endif
         __syncthreads();
     }
 #ifdef BASQ_NS_PROF

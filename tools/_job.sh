@@ -1,5 +1,5 @@
 set -u
-out=gpurun_out/r5b; mkdir -p $out
-for i in 1 2 3; do timeout -k 10 300 python tools/stall_probe.py --steps 60 > $out/stall_paused_$i.txt 2>&1 || exit 1; grep -v amdgpu.ids $out/stall_paused_$i.txt | cut -c1-330 | head -8; done
-timeout -k 10 300 python tools/stall_probe.py --steps 60 --pause-gc 0 > $out/stall_unpaused.txt 2>&1; grep -v amdgpu.ids $out/stall_unpaused.txt | cut -c1-330 | head -6
-timeout -k 10 900 python -m pytest tests -x -q -m gpu -k "two_ranks or structured_differential" > $out/new_tests.log 2>&1; echo "new tests rc=$?"; tail -3 $out/new_tests.log | cut -c1-300
+out=gpurun_out/r5e; mkdir -p $out
+timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "nullspace or fuzz_single" > $out/ns_tests.log 2>&1; rc=$?; tail -2 $out/ns_tests.log | cut -c1-300; [ $rc -eq 0 ] || exit 1
+for sh in "100 200" "50 100" "31 62" "64 128"; do timeout -k 10 120 python tools/bench_reduction.py $sh 2>&1 | grep -E "nullspace" | sed "s/^/[$sh] /"; done | tee $out/reduction.txt
+timeout -k 10 120 tools/ns_prof 100 200 > $out/ns_prof.txt 2>&1; cat $out/ns_prof.txt | cut -c1-200

@@ -37,9 +37,9 @@ int main(int argc, char** argv) {
     std::vector<long long> prof((size_t)m * 8 * 16);
     hipMemcpy(prof.data(), dprof, prof.size() * 8, hipMemcpyDeviceToHost);
     {   // bidiag_reflectors_reg_kernel: cycles per phase, summed over the steps, per wave ([wave][slot])
-        const char* name[10] = {"barrier 2 -> loop top", "A: loads .. first wave_sum4", "A: other rows", "A: partial-row store", "wait at barrier 1",
-                                "B wave 1: H parameters", "B wave 0: sum of 16 partial rows", "B wave 0: wait for wave 1", "B wave 0: row t+1, w",
-                                "B wave 0: make_right"};
+        const char* name[10] = {"barrier 3 -> loop top", "A: loads .. first wave_sum4", "A: other rows", "A: partial-row store", "wait at barrier 1",
+                                "B1: norms, H parameters", "B1: 16 partial rows, w, row t+1, norm share", "wait at barrier 2",
+                                "B2: G parameters, v", "(unused)"};
         printf("%-36s", "cycles per step (mean over steps)");
         for (int w = 0; w < 16; w += (w < 3 ? 1 : 4)) printf("   wave %2d", w);
         printf("\n");
