@@ -2735,20 +2735,24 @@ __global__ void __launch_bounds__(NW * 64) bidiag_reflectors_kernel(const double
 #undef BASQ_ROW_LD
 }
 
+// Newton steps behind v_rcp_f64 / v_rsq_f64.  The seeds are good to 2^-24 (measured: 2.5e8 ulp), so TWO steps reach the rounding
+// floor -- sqrt 1.4 ulp, 1/sqrt 1.6 ulp, 1/d 0.5 ulp over 4M values; a third changes nothing (1.9 / 1.8 / 0.5:
+// tools/newton_probe.hip, profiles/r07_b_newton_steps_after_rsq_rcp.txt) and sits on the serial chain of every reflector.
+#define BASQ_NEWTON_STEPS 2
 // 1/d to ~1 ulp without the scaling / fix-up of an IEEE divide (d is a normal, finite reflector norm here)
 __device__ __forceinline__ double recip_nr(double d) {
     double y = __builtin_amdgcn_rcp(d);
 #pragma unroll
-    for (int it = 0; it < 3; ++it) y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
+    for (int it = 0; it < BASQ_NEWTON_STEPS; ++it) y = __builtin_fma(__builtin_fma(-d, y, 1.0), y, y);
     return y;
 }
 
-// sqrt(d) and 1/sqrt(d) to ~1 ulp: v_rsq_f64 seed + three coupled Newton steps (g -> sqrt(d), h -> 1/(2 sqrt(d))).
+// sqrt(d) and 1/sqrt(d) to ~1.5 ulp: v_rsq_f64 seed + coupled Newton steps (g -> sqrt(d), h -> 1/(2 sqrt(d))).
 __device__ __forceinline__ void sqrt_rsqrt_nr(double d, double& root, double& rroot) {
     const double y = __builtin_amdgcn_rsq(d);
     double g = d * y, h = 0.5 * y;
 #pragma unroll
-    for (int it = 0; it < 3; ++it) {
+    for (int it = 0; it < BASQ_NEWTON_STEPS; ++it) {
         const double r = __builtin_fma(-h, g, 0.5);
         g = __builtin_fma(g, r, g);
         h = __builtin_fma(h, r, h);
@@ -2765,14 +2769,17 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
 // householder_params for the serial section of the kernel below, as one short dependency chain: with
 // n = |(alpha, x)| and s = sign(alpha):  beta = -s n,  tau = (beta - alpha)/beta = 1 + |alpha| / n,
 // scale = 1/(alpha - beta) = s / (|alpha| + n)   (n and 1/n from one Newton iteration, one reciprocal).
+// Branch-free (a zero tail selects tau = scale = 0 at the end: the callers' serial chains carry no jump, and the loads behind the
+// call are not held back by one).
 __device__ __forceinline__ void householder_params_fast(double alpha, double ss, double& tau, double& scale) {
-    if (ss == 0.0) { tau = 0.0; scale = 0.0; return; }
     double nrm, rnrm;
     sqrt_rsqrt_nr(__builtin_fma(alpha, alpha, ss), nrm, rnrm);
     const double aa = __builtin_fabs(alpha);
-    tau = __builtin_fma(aa, rnrm, 1.0);
+    const double t = __builtin_fma(aa, rnrm, 1.0);
     const double r = recip_nr(aa + nrm);
-    scale = (alpha >= 0.0) ? r : -r;
+    const bool none = ss == 0.0;
+    tau = none ? 0.0 : t;
+    scale = none ? 0.0 : ((alpha >= 0.0) ? r : -r);
 }
 
 template <int CTRL>
@@ -2874,11 +2881,12 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
     // ssb[] (summed in index order: the same bits in every B wave), then v_t on the wave's columns -> vsh, V; tau -> par[0], tau_g
     auto publish_right = [&](double rn, int t) {
         const int cb = 64 * wv + lane;
+        const double alpha = ssb[NV];
         double ss = ssb[0];
 #pragma unroll
         for (int w = 1; w < NV; ++w) ss += ssb[w];
         double tau, scale;
-        householder_params_fast(ssb[NV], ss, tau, scale);
+        householder_params_fast(alpha, ss, tau, scale);
         const double v = (cb < t) ? 0.0 : ((cb == t) ? 1.0 : rn * scale);
         vsh[cb] = v;
         if (cb < n) V[(size_t)t * n + cb] = v;
@@ -2986,6 +2994,7 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
             // chains so that the adds do not wait for one another
             // |column_t|^2 from the 16 partial norms: lane l reads partial l & 15, prefix sums inside the rows of 16 lanes (row_shr
             // 1, 2, 4, 8), lane 15 read back -- one LDS trip + four DPP steps instead of sixteen dependent adds
+            const double alphaH = par[3];
             double ss2 = sspart[lane & 15];
             ss2 += dpp_shift_f64<0x111, 0xf>(ss2);
             ss2 += dpp_shift_f64<0x112, 0xf>(ss2);
@@ -3005,7 +3014,7 @@ __global__ void __launch_bounds__(1024) bidiag_reflectors_reg_kernel(const doubl
                 if (w + 4 < NW) asm volatile("" ::: "memory");
             }
             double tauq, uscale;
-            householder_params_fast(par[3], ss2, tauq, uscale);     // H_t (every B wave: the same bits, nothing handed over)
+            householder_params_fast(alphaH, ss2, tauq, uscale);     // H_t (every B wave: the same bits, nothing handed over)
             BASQ_NS_LSTAMP(t, 5);
             const double r1 = r1sh[cb];
             const double w_c = (cb > t) ? __builtin_fma(uscale, acc0 + acc1, r1) : 0.0;   // u^T A with u = [1, column * scale]
