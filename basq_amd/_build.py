@@ -35,6 +35,9 @@ def needs_build() -> bool:
 
 def build(force: bool = False, verbose: bool = True, defines: dict | None = None, out: str | None = None) -> str:
     """Build the library.  ``defines``/``out`` build a tuning variant (tools/ only; e.g. BASQ_ST, BASQ_TJ)."""
+    if defines and out is None:
+        raise ValueError("tuning variants (defines=...) must be written to their own file (out=...): the in-tree product library "
+                         "is always built from the sources' defaults")
     target = out or LIB
     if not force and out is None and not needs_build():
         return LIB

@@ -2030,9 +2030,6 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) car_eliminate_cluster_kernel(co
 #ifndef BASQ_RING_WPG
 #define BASQ_RING_WPG 16
 #endif
-#ifndef BASQ_CAR_EXP
-#define BASQ_CAR_EXP 0           // timing experiment only (1: consumers skip their updates -- the chain of ratio tests alone;
-#endif                           // results are wrong for any value but 0)
 template <bool TIGHT>
 __device__ __forceinline__ int ring_wait_gt(int* cnt, int k) {
     unsigned spins = 0;
@@ -2226,11 +2223,9 @@ __global__ void __launch_bounds__(WPG * 64) car_eliminate_ring_kernel(const doub
         const double aj = hdr[0], phij = hdr[1];
         const int j = __builtin_amdgcn_readfirstlane((int)__double_as_longlong(hdr[2]));
         if (j == 0x7fffffff) { status = 1; break; }               // uniform: no positive entry (the reference raises)
-#if !(BASQ_CAR_EXP & 1)
         double pj[NR];
         pivot_column(I0(), j >> 6, j & 63, pj);
         apply(I0(), phi, pj, aj, j >> 6, j & 63, phij);
-#endif
         BASQ_NS_STAMP(k, 6);
     }
     // ---- produce this wave's block ----
