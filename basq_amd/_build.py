@@ -1,8 +1,8 @@
 """In-tree build of ``libbasq_hip.so`` (hipcc cross-compiles gfx950 without a GPU).
 
-``python -m basq_amd._build`` or ``__graft_entry__.build()``.  The shared library is
-written next to the sources (``basq_amd/csrc/libbasq_hip.so``): it is git-ignored but
-travels with the tree to the GPU box.
+``python -m basq_amd._build`` or ``__graft_entry__.build()``.  Three translation units -- the pairwise-kernel family, the dense
+linear algebra, the per-round reductions -- are compiled side by side (objects under ``basq_amd/csrc/build/``, only the stale
+ones again) and linked into ``basq_amd/csrc/libbasq_hip.so``: git-ignored, but it travels with the tree to the GPU box.
 """
 from __future__ import annotations
 
@@ -10,13 +10,19 @@ import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libbasq_hip.so")
-SOURCES = ["basq_hip.hip"]
-DEPS = ["exp_coeffs.inc", os.path.join("..", "..", "include", "basq_hip.h")]
+OBJ_DIR = os.path.join(CSRC, "build")
+SOURCES = ["basq_pairwise.hip", "basq_linalg.hip", "basq_reduction.hip"]
+COMMON_DEPS = ["basq_common.hpp", os.path.join("..", "..", "include", "basq_hip.h")]
+DEPS = {"basq_pairwise.hip": ["exp_coeffs.inc"]}
 ARCH = "gfx950"
-EXTRA_FLAGS = ["-mllvm", "-amdgpu-mfma-vgpr-form"]
+# -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (no v_accvgpr_read per kernel value; the block sums
+# consume every MFMA result on the VALU right away and have registers to spare)
+FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-const-variable",
+         "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
 def hipcc_path() -> str:
@@ -26,11 +32,27 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
+def _mtime(rel):
+    return os.path.getmtime(os.path.join(CSRC, rel))
+
+
+def _obj(src, obj_dir=OBJ_DIR):
+    return os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+
+
+def _stale(src, obj_dir=OBJ_DIR):
+    obj = _obj(src, obj_dir)
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    return any(_mtime(f) > t for f in [src] + COMMON_DEPS + DEPS.get(src, []))
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + DEPS)
+    return any(_mtime(f) > t for f in SOURCES + COMMON_DEPS + [d for ds in DEPS.values() for d in ds])
 
 
 def build(force: bool = False, verbose: bool = True, defines: dict | None = None, out: str | None = None) -> str:
@@ -41,16 +63,25 @@ def build(force: bool = False, verbose: bool = True, defines: dict | None = None
     target = out or LIB
     if not force and out is None and not needs_build():
         return LIB
-    # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (no v_accvgpr_read per kernel value; the block sums
-    # consume every MFMA result on the VALU right away and have registers to spare)
-    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-Wno-unused-const-variable"] + EXTRA_FLAGS + ["-o", target] + \
-          [os.path.join(CSRC, s) for s in SOURCES]
-    for k, v in (defines or {}).items():
-        cmd.append(f"-D{k}={v}")
+    # a variant keeps its objects apart from the product's
+    obj_dir = OBJ_DIR if out is None else os.path.join(OBJ_DIR, "variant_" + os.path.splitext(os.path.basename(out))[0])
+    os.makedirs(obj_dir, exist_ok=True)
+    hipcc = hipcc_path()
+    dflags = [f"-D{k}={v}" for k, v in (defines or {}).items()]
+
+    def compile_one(src):
+        cmd = [hipcc] + FLAGS + dflags + ["-c", "-o", _obj(src, obj_dir), os.path.join(CSRC, src)]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+
+    todo = [s for s in SOURCES if force or out is not None or _stale(s, obj_dir)]
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        list(ex.map(compile_one, todo))
+    link = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target] + [_obj(s, obj_dir) for s in SOURCES]
     if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+        print(" ".join(link), flush=True)
+    subprocess.run(link, check=True, cwd=CSRC)
     return target
 
 

@@ -70,7 +70,7 @@ def local_blocks(off: int, Rl: int, geo: RoundGeometry) -> int:
     return (lim + geo.S - 1) // geo.S - off // geo.S
 
 
-# Launch geometry of the block-sum kernel (must mirror basq_hip.hip): a wave covers rows_per_wave(kk) Nystrom rows
+# Launch geometry of the block-sum kernel (must mirror basq_pairwise.hip): a wave covers rows_per_wave(kk) Nystrom rows
 # x SETS_PER_WAVE sets, 4 waves per work-group; RESIDENT_WAVES = 256 CUs x 4 SIMDs x 3 waves (register-limited).
 SETS_PER_WAVE = 16
 RESIDENT_WAVES = 256 * 4 * 3
@@ -80,7 +80,7 @@ CHUNK_EFFICIENCY = 0.96          # smallest chunk count reaching this tail effic
 
 
 def rows_per_wave(kk: int) -> int:
-    """BASQ_JT_FOR(KK) * 16 in basq_hip.hip: 64 rows per wave up to KP = 20, 32 beyond."""
+    """BASQ_JT_FOR(KK) * 16 in basq_pairwise.hip: 64 rows per wave up to KP = 20, 32 beyond."""
     return 32 if kk >= 6 else 64
 
 

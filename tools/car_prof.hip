@@ -1,6 +1,6 @@
 // Phase profile of car_eliminate_ring_kernel (in-kernel clock64 stamps: producer slots 0..4, consumers 5..6).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -DBASQ_NS_PROF tools/car_prof.hip -o tools/car_prof
-#include "../basq_amd/csrc/basq_hip.hip"
+#include "../basq_amd/csrc/basq_reduction.hip"
 #include <cstdio>
 #include <cstdlib>
 #include <vector>

@@ -1,5 +1,5 @@
 // microbench_wavesum.hip -- latency of a 64-lane fp64 sum inside a dependent chain (what the per-round reductions are made of):
-//   the DPP form the kernels use (wave_sum / wave_sum4 of basq_hip.hip) against a form on v_mfma_f64_4x4x4_4b_f64:
+//   the DPP form the kernels use (wave_sum / wave_sum4 of basq_reduction.hip) against a form on v_mfma_f64_4x4x4_4b_f64:
 //   with B = ones, D[b][i][j] = sum_k A[b][i][k] adds the four 16-lane rows; fed back as A, a second one adds the four
 //   lanes i of each block; two DPP rotations (row_ror 4, 8) add the four blocks.  Result checked against the DPP sum.
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/microbench_wavesum tools/microbench_wavesum.hip
@@ -56,7 +56,7 @@ __device__ __forceinline__ void wave_sum4_mfma(double& x0, double& x1, double& x
     s0 += dpp_rot_f64<0x128>(s0); s1 += dpp_rot_f64<0x128>(s1); s2 += dpp_rot_f64<0x128>(s2); s3 += dpp_rot_f64<0x128>(s3);
     x0 = readlane_f64(s0, 0); x1 = readlane_f64(s1, 0); x2 = readlane_f64(s2, 0); x3 = readlane_f64(s3, 0);
 }
-__device__ __forceinline__ void wave_sum4_dpp(double& x0, double& x1, double& x2, double& x3) {   // as in basq_hip.hip
+__device__ __forceinline__ void wave_sum4_dpp(double& x0, double& x1, double& x2, double& x3) {   // as in basq_reduction.hip
     auto fold32 = [](double a, double b) {
         const long long ba = __double_as_longlong(a), bb = __double_as_longlong(b);
         const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)ba, (unsigned)bb, false, false);

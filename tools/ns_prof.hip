@@ -1,6 +1,6 @@
 // Phase profile of bidiag_reflectors_reg_kernel (in-kernel cycle stamps kept in LDS, waves 0..3, every 8th step).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -DBASQ_NS_PROF tools/ns_prof.hip -o /tmp/ns_prof
-#include "../basq_amd/csrc/basq_hip.hip"
+#include "../basq_amd/csrc/basq_reduction.hip"
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>

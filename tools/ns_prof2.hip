@@ -1,6 +1,6 @@
 // Phase profile of the cluster kernels (in-kernel clock64 stamps), one CU form.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -DBASQ_NS_PROF tools/ns_prof2.hip -o /tmp/ns_prof2
-#include "../basq_amd/csrc/basq_hip.hip"
+#include "../basq_amd/csrc/basq_reduction.hip"
 #include <cstdio>
 #include <algorithm>
 #include <cstdlib>
