@@ -141,7 +141,8 @@ class Plan:
         # ... and they call the GPU null-space / elimination kernels directly: wider reductions than those hold
         # (2 * num_pts > 1024) and the host-LAPACK route (GPU_NULLSPACE off) take the round-by-round loop
         gpu_reduction = cfg.GPU_NULLSPACE and n_sets <= getattr(ops, "NULLSPACE_MAX_M", 1 << 30)
-        async_rounds = (cfg.ASYNC_ROUNDS and not opaque and objective is None and warp != "wsabim"
+        async_rounds = (cfg.ASYNC_ROUNDS and not opaque and objective is None
+                        and (warp != "wsabim" or hasattr(ops, "blocksum_sq_geo"))
                         and hasattr(ops, "round_next") and not traced_sync and gpu_reduction
                         and (comm.world == 1 or cfg.REPLICATED_REDUCTION or owner is not None))
         return Plan(opaque, sober, warp, posterior, objective is not None, classes, async_rounds, comm.world)
@@ -510,6 +511,50 @@ class Batch:
         records = []                                             # per enqueued round, for the trace: (info|kept buffer)
         cand, mu, gid, wx = self.cand, self.mu, self.gid, self.wx
         n_extra = self.sums.n_extra
+        # WSABI-M (_wsabi.py:240-242): the squared covariance is one more per-pair block sum, added to the class messages; its
+        # likelihood-noise cross terms -- one Nystrom row per candidate, a different one every round -- are one more message PART
+        wsm = self.plan.warp == "wsabim"
+        noise_slot = 1 if (wsm and diag_noise != 0.0) else 0
+        rows_msg = q_ext + 1
+
+        def wsabim_kobs():
+            """``outputscale * k(Xobs, x_p)`` of this rank's live candidates (sized by the upper bound of their number)."""
+            n4, width = self.bmatT.shape[0], max(Rl_up, 1)
+            kobs = ops.empty(n4, width)
+            if n4 != self.n_obs:
+                kobs[self.n_obs:].zero_()
+            ops.gram_into(spec, nys_ext[m:m + self.n_obs], self.n_obs, cand, width, kobs)
+            return kobs
+
+        def wsabim_classes(Mc_, C_, fresh):
+            """The squared term of a class round (``FusedSums.wsabim_class_round`` with the ranges read from the descriptor)."""
+            kobs = wsabim_kobs()
+            n_sq = (C_ if fresh else 0) + n_extra
+            Epart = ops.empty(n_sq, m, S)
+            k = 0
+            if fresh:
+                ops.blocksum_sq_geo(spec, nys_ext, m, cand, mu, g_row, 1, S, C_, self.bmatT, kobs, self.n_obs, 0.0,
+                                    class_mod=C_, class0=0, out=Epart[:C_])
+                k = C_
+            ops.blocksum_sq_geo(spec, nys_ext, m, cand, mu, g_row, 2, S, 1, self.bmatT, kobs, self.n_obs, 0.0, out=Epart[k:k + 1])
+            if n_extra == 2:
+                ops.blocksum_sq_geo(spec, nys_ext, m, cand, mu, g_row, 4, S, 1, self.bmatT, kobs, self.n_obs, 0.0,
+                                    out=Epart[k + 1:k + 2])
+            Me = ops.project_chunks(self.U, q, m, Epart, ops.zeros(n_sq, S), n_sq, S, 1.0)
+            slots = Mc_[:C_ + n_extra] if fresh else Mc_[C_:C_ + n_extra]
+            slots[:, 1:q + 1] += Me[:, 1:q + 1]
+            if noise_slot:
+                val = ops.cov_diag_geo(spec, nys_ext, m, cand, g_row, Rl_up, S, self.bmatT, kobs, self.n_obs, diag_noise)
+                ops.sq_noise_part_geo(mu, val, g_row, self.U, q, m, S, rows_msg, n_extra == 2, Mc_[C_ + n_extra])
+
+        def wsabim_plain(msg_, n_ch):
+            """... and of a round without classes: the kernel carries the noise itself (``FusedSums.wsabim_square_term``)."""
+            kobs = wsabim_kobs()
+            Epart = ops.blocksum_sq_geo(spec, nys_ext, m, cand, mu, g_row, 3, S, n_ch, self.bmatT, kobs, self.n_obs, diag_noise)
+            E = Epart[0] if n_ch == 1 else ops.sum_parts(Epart)
+            if n_extra == 2:                                     # SOBER's first count of the remainder: the whole kernel again
+                E = E + ops.blocksum_sq_geo(spec, nys_ext, m, cand, mu, g_row, 4, S, 1, self.bmatT, kobs, self.n_obs, diag_noise)[0]
+            msg_[1:q + 1] += _mm_splitk(ops, self.U, E, 8)
 
         def tail_block_geo(Xslot, totslot):
             """SOBER's first count of the remainder (descriptor geometry: ``geo_mode`` 4); no set weight is added there."""
@@ -527,6 +572,8 @@ class Batch:
                 if n_extra == 2:
                     tail_block_geo(Xirr[1:2], totirr[1:2])
                 ops.project_chunks(U_ext, q_ext, m_ext, Xirr, totirr, n_extra, S, kscale, out=Mc[C_cur:C_cur + n_extra])
+                if wsm:
+                    wsabim_classes(Mc, C_cur, fresh=False)
                 parts = Mc
             else:
                 if pre is not None:                              # round 1: launched before the basis, host geometry
@@ -554,10 +601,15 @@ class Batch:
                         if n_extra == 2:
                             tail_block_geo(Xpart[n_plain:], totpart[n_plain:])
                 if C_cur >= 2:
-                    Mc = ops.project_chunks(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S, kscale)
+                    Mc = ops.empty(n_chunks + noise_slot, rows_msg, S)
+                    ops.project_chunks(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S, kscale, out=Mc[:n_chunks])
+                    if wsm:
+                        wsabim_classes(Mc, C_cur, fresh=True)
                     parts = Mc
                 else:
                     parts = ops.project(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S, kscale).unsqueeze(0)
+                    if wsm:
+                        wsabim_plain(parts[0], max(1, n_chunks - (n_extra - 1)))
                 del Xpart, totpart
             rows = parts.shape[1]
             if diag_noise != 0.0:
@@ -597,7 +649,7 @@ class Batch:
             plan_C = None
             if Mc is not None and C_cur >= 2:
                 # next round's class messages AND its descriptor, one launch (both read the elimination's outcome)
-                Mn = ops.empty(C_cur // 2 + n_extra, Mc.shape[1], S)
+                Mn = ops.empty(C_cur // 2 + n_extra + noise_slot, Mc.shape[1], S)
                 ops.regroup_round_next(Mc[:C_cur], kept, w_star, tot, Mn[:C_cur // 2], g_row, info, keep_rank, S, -1, True,
                                        geo_t[r + 1])
                 cls = dict(M=Mn, C=C_cur // 2, reg_blocks=None)
@@ -631,6 +683,8 @@ class Batch:
         self.R_lo = R_lo
         if cls is not None:
             cls["reg_blocks"] = int(row[2]) // S
+            if noise_slot:                                       # (the round-by-round loop adds that part by itself)
+                cls["M"] = cls["M"][:cls["C"] + n_extra]
         self.cls = cls
         return False
 

@@ -18,7 +18,7 @@ BASQ_OK = 0
 FAMILY = {"rbf": 0, "matern52": 1, "matern32": 2}
 ROLE_A, ROLE_B = 0, 1
 MAX_DIM = 38
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class KernelSpecC(C.Structure):
@@ -66,6 +66,11 @@ SIGNATURES = {
     "basq_blocksum_sq_f64": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp,
                                        _i64, _i32, _f64, _vp, _vp]),
     "basq_cov_diag_f64": (C.c_int, [_vp, _vp, _i32, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _f64, _vp, _vp]),
+    "basq_blocksum_sq_geo_f64": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i64,
+                                           _i32, _f64, _vp, _vp]),
+    "basq_cov_diag_geo_f64": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _i32, _f64, _vp, _vp]),
+    "basq_sq_noise_part_ws_doubles": (C.c_int64, [_i32]),
+    "basq_sq_noise_part_geo_f64": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "basq_box_muller_f64": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "basq_chol_inv_f64": (C.c_int, [_vp, _i32, _vp, _vp, _f64, _vp]),
     "basq_chol_factor_f64": (C.c_int, [_vp, _i32, _vp, _f64, _vp]),

@@ -464,6 +464,42 @@ class HipOps:
                                          self._stream()), "basq_cov_diag_f64")
         return out
 
+    # -- WSABI-M in the descriptor-driven rounds ---------------------------------------------------------------------
+    def blocksum_sq_geo(self, spec, nys, m, cand, mu, geo_row, mode, S, n_chunks, bmatT, kobs, n_obs, noise, class_mod=0,
+                        class0=0, out=None):
+        """``blocksum_sq`` with the candidate range read from a round descriptor (modes as for ``blocksum_geo``); ``kobs`` holds
+        this rank's live candidates from its first one."""
+        self._chk(bmatT)
+        if kobs.dtype != torch.float64 or kobs.stride(1) != 1:
+            raise ValueError("expected a float64 matrix with unit column stride")
+        Epart = self.empty(n_chunks, m, S) if out is None else out
+        assert Epart.is_contiguous() and tuple(Epart.shape) == (n_chunks, m, S)
+        sc = self.spec_c(spec)
+        check(self.lib.basq_blocksum_sq_geo_f64(C.byref(sc), _ptr(nys), m, _ptr(cand), _ptr(mu), _ptr(geo_row), int(mode), S,
+                                                n_chunks, int(class_mod), int(class0), _ptr(bmatT), bmatT.stride(0), _ptr(kobs),
+                                                kobs.stride(0), int(n_obs), float(noise), _ptr(Epart), self._stream()),
+              "basq_blocksum_sq_geo_f64")
+        return Epart
+
+    def cov_diag_geo(self, spec, nys, m, cand, geo_row, R_max, S, bmatT, kobs, n_obs, noise):
+        """``cov_diag`` for the shard a round descriptor names; launch and output sized for ``R_max`` candidates."""
+        out = self.empty(max(R_max, 1))
+        sc = self.spec_c(spec)
+        check(self.lib.basq_cov_diag_geo_f64(C.byref(sc), _ptr(nys), m, _ptr(cand), _ptr(geo_row), int(max(R_max, 1)), S,
+                                             _ptr(bmatT), bmatT.stride(0), _ptr(kobs), kobs.stride(0), int(n_obs), float(noise),
+                                             _ptr(out), self._stream()), "basq_cov_diag_geo_f64")
+        return out
+
+    def sq_noise_part_geo(self, mu, val, geo_row, U, q, m, S, rows, sober, out):
+        """WSABI-M's noise cross terms as a part of the round's message (``basq_sq_noise_part_geo_f64``) -> ``out [rows, S]``."""
+        self._chk(U)
+        assert out.is_contiguous() and tuple(out.shape) == (rows, S)
+        ws = self.empty(int(self.lib.basq_sq_noise_part_ws_doubles(int(S))))
+        check(self.lib.basq_sq_noise_part_geo_f64(_ptr(mu), _ptr(val), _ptr(geo_row), _ptr(U), U.stride(0), q, m, S, rows,
+                                                  1 if sober else 0, _ptr(ws), _ptr(out), self._stream()),
+              "basq_sq_noise_part_geo_f64")
+        return out
+
     def gram_into(self, spec, packA, na, packB, nb, out):
         """``out[:na, :nb] = outputscale * k(A, B)`` for a caller-provided row-major buffer (row stride ``out.stride(0)``)."""
         self._chk(out)

@@ -276,8 +276,9 @@ struct BlocksumArgs {
 // Candidate range of a descriptor-driven launch (wave-uniform scalar loads and arithmetic; the formulas of blocksum_impl).
 // The descriptor carries the round's GLOBAL geometry and this rank's shard [off, off + Rl) of the live positions
 // (geo[6], geo[7]; one rank: [0, R)); the launch covers the intersection of the shard with the mode's position range.
+// -> the local index of the launch's first position (what per-candidate side arrays must be advanced by).
 template <int KP>
-__device__ __forceinline__ void blocksum_apply_geo(BlocksumArgs& A) {
+__device__ __forceinline__ long long blocksum_apply_geo(BlocksumArgs& A) {
     const long long R = A.geo[0], n_full = A.geo[1], reg_hi = A.geo[2];
     const long long s_off = A.geo[6], s_end = A.geo[6] + A.geo[7];
     long long lo = 0, hi = R;
@@ -312,6 +313,7 @@ __device__ __forceinline__ void blocksum_apply_geo(BlocksumArgs& A) {
     }
     A.blk_per_chunk = (A.blk_hi - A.blk_lo + A.n_chunks - 1) / A.n_chunks;
     if (A.blk_per_chunk < 1) A.blk_per_chunk = 1;
+    return skip;
 }
 
 template <int KK>
@@ -692,11 +694,39 @@ __device__ __forceinline__ void sq_pair_accumulate(const double (&a)[JT][KK], co
     }
 }
 
-template <int KK, int FAM, int JT>
-__global__ void __launch_bounds__(256) blocksum_sq_kernel(const BlocksumArgs A, const SqArgs Q) {
+// The launch arguments as the kernel uses them: the kernarg segment itself (host geometry: every field stays a scalar load --
+// a mutable copy costs the two registers that take the kernel from two waves per SIMD to one), or a copy patched from the
+// round descriptor (GEO).
+template <bool GEO>
+struct SqLaunchView {
+    const BlocksumArgs& A;
+    const SqArgs& Q;
+    __device__ SqLaunchView(const BlocksumArgs& a, const SqArgs& q) : A(a), Q(q) {}
+};
+template <>
+struct SqLaunchView<true> {
+    BlocksumArgs A;
+    SqArgs Q;
+    __device__ SqLaunchView(const BlocksumArgs& a, const SqArgs& q) : A(a), Q(q) {}
+};
+
+#ifndef BASQ_SQ_WAVES_PER_EU
+#define BASQ_SQ_WAVES_PER_EU 2   // the kernel sits at 256 VGPRs: two more (the descriptor-driven variant had them) halve its occupancy
+#endif
+#if BASQ_SQ_WAVES_PER_EU > 0
+#define BASQ_SQ_ATTR __attribute__((amdgpu_waves_per_eu(BASQ_SQ_WAVES_PER_EU)))
+#else
+#define BASQ_SQ_ATTR
+#endif
+template <int KK, int FAM, int JT, bool GEO>
+__global__ void __launch_bounds__(256) BASQ_SQ_ATTR blocksum_sq_kernel(const BlocksumArgs A_in, const SqArgs Q_in) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     constexpr int KP = KK * 4;
+    SqLaunchView<GEO> view(A_in, Q_in);
+    if constexpr (GEO) view.Q.kobs += blocksum_apply_geo<KP>(view.A);   // descriptor-driven round: range (and the ko columns) from HBM
+    const BlocksumArgs& A = view.A;
+    const SqArgs& Q = view.Q;
     const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;            // XCD-aware map: see blocksum_kernel
     const int jg = seq % A.n_jgroups;
     const int gidx = (seq / A.n_jgroups) * 8 + xcd;
@@ -796,7 +826,8 @@ static int launch_blocksum_sq_jt(const BlocksumArgs& A, const SqArgs& Q, hipStre
     const long long npairs = (long long)A.n_stiles * A.n_chunks;
     const long long nblk = ((npairs + 7) / 8) * 8 * B.n_jgroups;
     if (nblk <= 0 || nblk > 0x7fffffffLL) return BASQ_EINVAL;
-    hipLaunchKernelGGL((blocksum_sq_kernel<KK, FAM, JT>), dim3((unsigned)nblk), dim3(256), 0, st, B, Q);
+    if (B.geo) hipLaunchKernelGGL((blocksum_sq_kernel<KK, FAM, JT, true>), dim3((unsigned)nblk), dim3(256), 0, st, B, Q);
+    else hipLaunchKernelGGL((blocksum_sq_kernel<KK, FAM, JT, false>), dim3((unsigned)nblk), dim3(256), 0, st, B, Q);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }
@@ -1138,11 +1169,18 @@ __global__ void __launch_bounds__(1024) dense_blocksum_pairs_kernel(const double
 // The first term is a plain per-pair block sum (basq_blocksum_sq_f64 with noise = 0: it regroups over the rounds of an epoch
 // like every other block sum); this kernel evaluates the bracket, one thread per candidate (0 where kappa >= m):
 //     out[p] = noise * (outputscale k(nys_kappa, x_p) - sum_o bmatT[o][kappa] kobs[o][p]) + 0.5 noise^2
+// geo != NULL (descriptor-driven round): this rank's shard and the round's n_full come from the descriptor.
 template <int FAM>
 __global__ void cov_diag_kernel(const double* __restrict__ nys, int kp, int m, const double* __restrict__ cand,
                                 long long Rl, long long off, long long n_full, int S, const double* __restrict__ bmatT,
                                 long long ldb, const double* __restrict__ kobs, long long ldk, int n_obs,
-                                double outputscale, double noise, double* __restrict__ out) {
+                                double outputscale, double noise, double* __restrict__ out,
+                                const long long* __restrict__ geo) {
+    if (geo) {
+        n_full = geo[1];
+        off = geo[6];
+        Rl = geo[7];
+    }
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= Rl) return;
     const long long pg = off + p;
@@ -1159,6 +1197,67 @@ __global__ void cov_diag_kernel(const double* __restrict__ nys, int kp, int m, c
     for (int o = 0; o < n_obs; ++o) corr = __builtin_fma(bmatT[(long long)o * ldb + kappa], kobs[(long long)o * ldk + p], corr);
     const double c = __builtin_fma(outputscale, kernel_from_arg<FAM>(D), -corr);
     out[p] = __builtin_fma(noise, c, 0.5 * noise * noise);
+}
+
+// The part of a round's message that WSABI-M's noise cross terms contribute (see basq_sq_noise_part_geo_f64), two launches:
+//   (1) BASQ_SQNP_GROUPS work-groups: group g adds mu[p] val[p] of this rank's candidates in full blocks b = g (mod groups) to
+//       ws[g][s], s = the set of p, in block order (a single work-group doing all of it is a chain of ~R / S dependent loads per
+//       thread: 220 us per round at config 5m's size);
+//   (2) one work-group: dvec[s] = sum_g ws[g][s] (index order), dt[k] = mu val of remainder point k (k < m), then
+//       part[1 + r][s] = U[r][s] dvec[s] (s < min(m, S))  + [s == S-1] sum_k U[r][k0 + k] dt[k]  (+ SOBER: U[r][s] dt[s - k0] on [k0, k1))
+#define BASQ_SQNP_GROUPS 64
+__global__ void __launch_bounds__(256) sq_noise_dvec_geo_kernel(const double* __restrict__ mu, const double* __restrict__ val,
+                                                                const long long* __restrict__ geo, int S, double* __restrict__ ws) {
+    const long long n_full = geo[1], off = geo[6], Rl = geo[7];
+    long long t0l = n_full - off;                                  // first local remainder position = end of the full blocks here
+    if (t0l < 0) t0l = 0;
+    if (t0l > Rl) t0l = Rl;
+    const long long b_lo = off / S, b_hi = (off + t0l + S - 1) / S;   // global blocks that intersect the shard's full-block part
+    for (int sidx = threadIdx.x; sidx < S; sidx += blockDim.x) {
+        double acc = 0.0;
+        for (long long b = b_lo + blockIdx.x; b < b_hi; b += gridDim.x) {
+            const long long p = b * S + sidx - off;
+            if (p >= 0 && p < t0l) acc = __builtin_fma(mu[p], val[p], acc);
+        }
+        ws[(long long)blockIdx.x * S + sidx] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(1024) sq_noise_part_geo_kernel(const double* __restrict__ mu, const double* __restrict__ val,
+                                                                 const long long* __restrict__ geo, const double* __restrict__ U,
+                                                                 long long ldu, int q, int m, int S, int rows, int sober,
+                                                                 const double* __restrict__ ws, int groups,
+                                                                 double* __restrict__ part) {
+    __shared__ double dvec[1024], dt[1024];
+    const int tid = threadIdx.x;
+    const long long n_full = geo[1], off = geo[6], Rl = geo[7];
+    long long t0l = n_full - off;
+    if (t0l < 0) t0l = 0;
+    if (t0l > Rl) t0l = Rl;
+    const long long k0 = off + t0l - n_full;
+    long long k1 = k0 + (Rl - t0l);
+    if (k1 > m) k1 = m;
+    const int nrem = (k1 > k0) ? (int)(k1 - k0) : 0;
+    if (tid < S) {
+        double acc = 0.0;
+        for (int g = 0; g < groups; ++g) acc += ws[(long long)g * S + tid];
+        dvec[tid] = acc;
+    }
+    if (tid < nrem) dt[tid] = mu[t0l + tid] * val[t0l + tid];
+    __syncthreads();
+    const int nd = (m < S) ? m : S;
+    for (int idx = tid; idx < rows * S; idx += 1024) {
+        const int r = idx / S, sidx = idx - r * S;
+        double v = 0.0;
+        if (r >= 1 && r <= q) {
+            const double* Ur = U + (long long)(r - 1) * ldu;
+            if (sidx < nd && t0l > 0) v = Ur[sidx] * dvec[sidx];
+            if (sidx == S - 1)
+                for (int k = 0; k < nrem; ++k) v = __builtin_fma(Ur[k0 + k], dt[k], v);
+            if (sober && sidx >= k0 && sidx < k1) v = __builtin_fma(Ur[sidx], dt[sidx - k0], v);
+        }
+        part[idx] = v;
+    }
 }
 
 __global__ void axpb_strided_kernel(const double* __restrict__ x, long long n, long long stride, double a, double b,
@@ -1274,7 +1373,7 @@ int basq_cov_diag_f64(const basq_kernel_spec* spec, const double* nys, int32_t m
 #define BASQ_COV_DIAG(FAM)                                                                                              \
     hipLaunchKernelGGL((cov_diag_kernel<FAM>), grid, block, 0, (hipStream_t)stream, nys, kp, m, cand, (long long)Rl,    \
                        (long long)off, (long long)n_full, S, bmatT, (long long)ldb, kobs, (long long)ldk, n_obs,         \
-                       spec->outputscale, noise, out)
+                       spec->outputscale, noise, out, (const long long*)nullptr)
     switch (spec->family) {
         case BASQ_FAMILY_RBF: BASQ_COV_DIAG(BASQ_FAMILY_RBF); break;
         case BASQ_FAMILY_MATERN52: BASQ_COV_DIAG(BASQ_FAMILY_MATERN52); break;
@@ -1315,6 +1414,67 @@ int basq_blocksum_sq_f64(const basq_kernel_spec* spec, const double* nys, int32_
     const long long nblk = A.blk_hi - A.blk_lo;
     A.blk_per_chunk = (nblk + n_chunks - 1) / n_chunks;
     if (A.blk_per_chunk < 1) A.blk_per_chunk = 1;
+    SqArgs Q;
+    Q.bmatT = bmatT; Q.kobs = kobs; Q.ldb = ldb; Q.ldk = ldk; Q.ko = (n_obs + 3) / 4;
+    Q.outputscale = spec->outputscale; Q.noise = noise;
+    return dispatch_blocksum_sq(basq_kp(spec->d) / 4, spec->family, A, Q, (hipStream_t)stream);
+}
+
+int basq_cov_diag_geo_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
+                          const int64_t* geo, int64_t R_max, int32_t S, const double* bmatT, int64_t ldb, const double* kobs,
+                          int64_t ldk, int32_t n_obs, double noise, double* out, void* stream) {
+    if (!spec_ok(spec) || !nys || !cand || !geo || !bmatT || !kobs || !out) return BASQ_EINVAL;
+    if (m < 1 || R_max < 1 || S < 1 || n_obs < 1 || ldb < m || ldk < R_max) return BASQ_EINVAL;
+    const int kp = basq_kp(spec->d);
+    const dim3 grid((unsigned)((R_max + 255) / 256)), block(256);
+#define BASQ_COV_DIAG(FAM)                                                                                              \
+    hipLaunchKernelGGL((cov_diag_kernel<FAM>), grid, block, 0, (hipStream_t)stream, nys, kp, m, cand, 0LL, 0LL, 0LL, S,  \
+                       bmatT, (long long)ldb, kobs, (long long)ldk, n_obs, spec->outputscale, noise, out,                \
+                       (const long long*)geo)
+    switch (spec->family) {
+        case BASQ_FAMILY_RBF: BASQ_COV_DIAG(BASQ_FAMILY_RBF); break;
+        case BASQ_FAMILY_MATERN52: BASQ_COV_DIAG(BASQ_FAMILY_MATERN52); break;
+        case BASQ_FAMILY_MATERN32: BASQ_COV_DIAG(BASQ_FAMILY_MATERN32); break;
+        default: return BASQ_EUNSUPPORTED;
+    }
+#undef BASQ_COV_DIAG
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int64_t basq_sq_noise_part_ws_doubles(int32_t S) { return (int64_t)BASQ_SQNP_GROUPS * (S > 0 ? S : 0); }
+
+int basq_sq_noise_part_geo_f64(const double* mu, const double* val, const int64_t* geo, const double* U, int64_t ldu,
+                               int32_t q, int32_t m, int32_t S, int32_t rows, int32_t sober, double* ws, double* part,
+                               void* stream) {
+    if (!mu || !val || !geo || !U || !ws || !part) return BASQ_EINVAL;
+    if (q < 1 || m < 1 || S < 1 || S > 1024 || rows < q + 1 || ldu < m) return BASQ_EINVAL;
+    hipLaunchKernelGGL(sq_noise_dvec_geo_kernel, dim3(BASQ_SQNP_GROUPS), dim3(256), 0, (hipStream_t)stream, mu, val,
+                       (const long long*)geo, S, ws);
+    BASQ_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sq_noise_part_geo_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, mu, val, (const long long*)geo,
+                       U, (long long)ldu, q, m, S, rows, sober ? 1 : 0, ws, BASQ_SQNP_GROUPS, part);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_blocksum_sq_geo_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
+                             const double* mu, const int64_t* geo, int32_t geo_mode, int32_t S, int32_t n_chunks,
+                             int32_t class_mod, int32_t class0, const double* bmatT, int64_t ldb, const double* kobs,
+                             int64_t ldk, int32_t n_obs, double noise, double* Epart, void* stream) {
+    if (!spec_ok(spec) || !nys || !cand || !mu || !geo || !bmatT || !kobs || !Epart) return BASQ_EINVAL;
+    if (m < 1 || S < 1 || n_chunks < 1 || n_obs < 1 || geo_mode < 1 || geo_mode > 4) return BASQ_EINVAL;
+    if (class_mod < 0 || class0 < 0 || (class_mod > 0 && class0 + n_chunks > class_mod)) return BASQ_EINVAL;
+    if (class_mod > 0 && geo_mode != 1) return BASQ_EINVAL;       // residue classes cover the regular region only
+    const int jt = BASQ_JT_FOR(basq_kp(spec->d) / 4);
+    if (ldb < (((int64_t)m + 16 * jt - 1) / (16 * jt)) * (16 * jt) || ldk < 1) return BASQ_EINVAL;
+    BlocksumArgs A;
+    A.nys = nys; A.cand = cand; A.mu = mu; A.wx = nullptr; A.Xpart = Epart; A.totpart = nullptr;
+    A.Rl = 0; A.off = 0; A.n_full = 0; A.blk_lo = 0; A.blk_hi = 0; A.blk_per_chunk = 1;   // set on the device
+    A.m = m; A.S = S; A.n_chunks = n_chunks;
+    A.class_mod = class_mod; A.class0 = class0;
+    A.geo = (const long long*)geo; A.geo_mode = geo_mode;
+    A.n_stiles = (S + 15) / 16;
     SqArgs Q;
     Q.bmatT = bmatT; Q.kobs = kobs; Q.ldb = ldb; Q.ldk = ldk; Q.ko = (n_obs + 3) / 4;
     Q.outputscale = spec->outputscale; Q.noise = noise;

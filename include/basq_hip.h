@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BASQ_ABI_VERSION 13
+#define BASQ_ABI_VERSION 14
 
 /* error codes */
 #define BASQ_OK            0
@@ -366,6 +366,40 @@ int basq_blocksum_sq_f64(const basq_kernel_spec* spec, const double* nys, int32_
 int basq_cov_diag_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand, int64_t Rl,
                       int64_t off, int64_t n_full, int32_t S, const double* bmatT, int64_t ldb, const double* kobs,
                       int64_t ldk, int32_t n_obs, double noise, double* out, void* stream);
+
+/*
+ * WSABI-M (BASQ/_wsabi.py:227-249) in the DESCRIPTOR-DRIVEN rounds (no host wait per round; ABI 14): the three entries above
+ * with the candidate range read on the device from a round descriptor (geo: see basq_round_next_i64 -- {R, n_full, reg_hi,
+ * violation, nb, n_tail, shard offset, shard length}), so that the host can enqueue a round of a WSABI-M batch before it knows
+ * how many candidates survived the previous one.
+ *
+ * basq_blocksum_sq_geo_f64: basq_blocksum_sq_f64 over the part of this rank's shard that geo_mode selects, exactly as
+ *   basq_blocksum_geo_f64 does for the kernel itself (1: the regular region [0, reg_hi), the only mode with residue classes;
+ *   2: the rest [reg_hi, R); 3: everything; 4: the ragged remainder as a block of its own -- SOBER/_rchq.py:127-135).  kobs
+ *   holds this rank's live candidates from its FIRST one (column 0 = local position 0); the kernel advances it with `cand`.
+ * basq_cov_diag_geo_f64: basq_cov_diag_f64 for the shard the descriptor names; the launch covers R_max candidates (an upper
+ *   bound of the shard's length), out[p] is written for p below the actual length only.
+ * basq_sq_noise_part_geo_f64: what those values contribute to the round's message (BASQ/_gp.py:275-276 inside
+ *   _wsabi.py:240-242; BASQ/_rchq.py:88: U_svd @ ...), one work-group:
+ *       dvec[s] = sum over this rank's candidates p of set s in FULL blocks of mu[p] val[p]      (position order)
+ *       dt[k]   = mu val of remainder point k (Nystrom row k; k < m)
+ *       part[0][.] = 0,   part[1 + r][s] = U[r][s] dvec[s]  (s < min(m, S))  +  [s == S - 1] sum_k U[r][k0 + k] dt[k]
+ *                                          (+ sober != 0: U[r][s] dt[s - k0] for the remainder's first count, s in [k0, k1))
+ *   U [q, ldu >= m] = the UNSCALED Nystrom basis (the squared term carries no warped means), part [rows >= q + 1, S] is written
+ *   whole (rows beyond q zero), S <= 1024.  dvec is formed by several work-groups (fixed partition of the blocks, partial sums
+ *   added in index order) in the caller's workspace ws [basq_sq_noise_part_ws_doubles(S)].
+ */
+int basq_blocksum_sq_geo_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
+                             const double* mu, const int64_t* geo, int32_t geo_mode, int32_t S, int32_t n_chunks,
+                             int32_t class_mod, int32_t class0, const double* bmatT, int64_t ldb, const double* kobs,
+                             int64_t ldk, int32_t n_obs, double noise, double* Epart, void* stream);
+int basq_cov_diag_geo_f64(const basq_kernel_spec* spec, const double* nys, int32_t m, const double* cand,
+                          const int64_t* geo, int64_t R_max, int32_t S, const double* bmatT, int64_t ldb, const double* kobs,
+                          int64_t ldk, int32_t n_obs, double noise, double* out, void* stream);
+int64_t basq_sq_noise_part_ws_doubles(int32_t S);      /* size of basq_sq_noise_part_geo_f64's workspace `ws` (doubles) */
+int basq_sq_noise_part_geo_f64(const double* mu, const double* val, const int64_t* geo, const double* U, int64_t ldu,
+                               int32_t q, int32_t m, int32_t S, int32_t rows, int32_t sober, double* ws, double* part,
+                               void* stream);
 
 /*
  * Gaussian test matrix of torch.svd_lowrank (BASQ/_rchq.py:29 -> torch._lowrank: R = torch.randn(m, q)): the

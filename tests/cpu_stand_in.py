@@ -440,6 +440,48 @@ class CpuStandInOps:
         out[:Rl][hit] = noise * (kval - corr) + 0.5 * noise * noise
         return out
 
+    # -- WSABI-M in the descriptor-driven rounds: the same arithmetic with the range read from the descriptor ----------------
+    def blocksum_sq_geo(self, spec, nys, m, cand, mu, geo_row, mode, S, n_chunks, bmatT, kobs, n_obs, noise, class_mod=0,
+                        class0=0, out=None):
+        R, n_full, reg_hi, off, Rl = (int(geo_row[k]) for k in (0, 1, 2, 6, 7))
+        lo, hi = (0, reg_hi) if mode == 1 else ((reg_hi, R) if mode == 2 else ((n_full, R) if mode == 4 else (0, R)))
+        lo, hi = max(lo, off), min(hi, off + Rl)
+        hi = max(hi, lo)
+        sk = lo - off
+        if mode == 4:
+            return self.blocksum_sq(spec, nys, m, cand[sk:], mu[sk:], hi - lo, lo - n_full, S, S, n_chunks, bmatT, kobs[:, sk:],
+                                    n_obs, noise, out=out)
+        return self.blocksum_sq(spec, nys, m, cand[sk:], mu[sk:], hi - lo, lo, n_full, S, n_chunks, bmatT, kobs[:, sk:], n_obs,
+                                noise, class_mod=class_mod, class0=class0, out=out)
+
+    def cov_diag_geo(self, spec, nys, m, cand, geo_row, R_max, S, bmatT, kobs, n_obs, noise):
+        n_full, off, Rl = int(geo_row[1]), int(geo_row[6]), int(geo_row[7])
+        out = torch.zeros(max(R_max, 1), dtype=torch.float64)
+        out[:max(Rl, 1)] = self.cov_diag(spec, nys, m, cand, Rl, off, n_full, S, bmatT, kobs, n_obs, noise)[:max(Rl, 1)]
+        return out
+
+    def sq_noise_part_geo(self, mu, val, geo_row, U, q, m, S, rows, sober, out):
+        """The noise cross terms as a message part (``basq_sq_noise_part_geo_f64``; the host-geometry form of the same sums is
+        ``FusedSums.wsabim_class_round``)."""
+        n_full, off, Rl = int(geo_row[1]), int(geo_row[6]), int(geo_row[7])
+        out.zero_()
+        t0l = min(max(n_full - off, 0), Rl)
+        if t0l > 0:
+            wv = mu[:t0l] * val[:t0l]
+            sets = (off + torch.arange(t0l)) % S
+            dvec = torch.zeros(S, dtype=torch.float64).index_add_(0, sets, wv)
+            nd = min(m, S)
+            out[1:q + 1, :nd] = U[:, :nd] * dvec[:nd]
+        if Rl > t0l:
+            k0 = off + t0l - n_full
+            k1 = min(k0 + (Rl - t0l), m)
+            if k1 > k0:
+                dt = mu[t0l:t0l + (k1 - k0)] * val[t0l:t0l + (k1 - k0)]
+                out[1:q + 1, S - 1] += U[:, k0:k1] @ dt
+                if sober:
+                    out[1:q + 1, k0:k1] += U[:, k0:k1] * dt
+        return out
+
     def box_muller(self, u, u_tail=None):
         def bm(v):
             blk = v.view(-1, 16)

@@ -444,10 +444,11 @@ def test_descriptor_violation_repeats_the_batch_round_by_round():
 
 
 @pytest.mark.parametrize("name", ["cfg1_posterior_1e4", "posterior_noise_ragged", "wsabil_noise_ragged", "wsabil_2e4",
-                                  "matern52_posterior", "rbf_ragged"])
+                                  "matern52_posterior", "rbf_ragged", "wsabim_1e4", "wsabim_noise_ragged"])
 def test_descriptor_driven_rounds_structured_kernels(name):
-    """Posterior / WSABI-L kernels (likelihood noise on the block diagonals, incl. the ragged tail block whose length
-    only the device knows) through the descriptor-driven rounds: the round-by-round loop's batch, and the golden's."""
+    """Posterior / WSABI-L / WSABI-M kernels (likelihood noise on the block diagonals, incl. the ragged tail block whose length
+    only the device knows; round 5: WSABI-M's squared covariance and its noise cross terms from the descriptor too) through the
+    descriptor-driven rounds: the round-by-round loop's batch, and the golden's."""
     import basq_amd._config as eng
 
     c = BY_NAME[name]

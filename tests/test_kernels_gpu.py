@@ -463,6 +463,72 @@ def test_blocksum_sq_classes_and_cov_diag_vs_standin(hip_ops, family, d, m, n_ob
     assert (tg[:S - 3] - tc[:S - 3]).abs().max().item() <= 1e-12 * tc.abs().max().item()
 
 
+@pytest.mark.parametrize("R,S,reg_blocks,C,shard,sober", [
+    (10_123, 200, 48, 16, None, False),                  # one rank, ragged remainder of 123
+    (10_123, 200, 48, 16, (3_333, 3_400), True),         # a shard in the regular region; SOBER's extra remainder count (empty here)
+    (10_123, 200, 48, 16, (6_100, 4_023), True),         # a shard that holds the end of the regular region and the remainder
+    (4_060, 58, 64, 8, (4_001, 59), False),              # a shard inside the ragged remainder only
+    (1_000, 50, 16, 4, (0, 1_000), False),               # no remainder (R a multiple of S)
+])
+def test_wsabim_descriptor_kernels_vs_host_geometry(hip_ops, R, S, reg_blocks, C, shard, sober):
+    """Round 5: WSABI-M in the descriptor-driven rounds -- ``basq_blocksum_sq_geo_f64`` (modes 1-4), ``basq_cov_diag_geo_f64``
+    and ``basq_sq_noise_part_geo_f64`` return what the host-geometry entries return for the same numbers (bit for bit where the
+    same kernel runs), with buffers sized for an upper bound; the noise part against the CPU stand-in's closed form."""
+    cpu = CpuStandInOps()
+    d, m, n_obs, q = 5, 130, 41, 24
+    spec = _spec("rbf", d)
+    off, Rl = shard if shard is not None else (0, R)
+    nys, obs, cand = _rand(m, d, 71), _rand(n_obs, d, 72), _rand(R, d, 73)[off:off + Rl]
+    g = torch.Generator().manual_seed(11)
+    mu = (torch.rand(R, generator=g, dtype=torch.float64) + 0.05)[off:off + Rl]
+    Bm = 0.1 * _rand(m, n_obs, 74)
+    U = _rand(q, m, 75)
+    n4, mp = (n_obs + 3) // 4 * 4, (m + 63) // 64 * 64
+    center = hip_ops.to_device(nys.mean(0))
+    pa = hip_ops.pack(spec, hip_ops.to_device(torch.cat([nys, obs], 0)), center, 0, pad_rows_to=64)
+    R_max = Rl + 333
+    pb = hip_ops.zeros(R_max, hip_ops.kp(d))
+    pb[:Rl] = hip_ops.pack(spec, hip_ops.to_device(cand), center, 1)
+    mu_d = hip_ops.zeros(R_max)
+    mu_d[:Rl] = hip_ops.to_device(mu)
+    bT = hip_ops.zeros(n4, mp)
+    bT[:n_obs, :m] = hip_ops.to_device(Bm).t()
+    kobs = hip_ops.zeros(n4, R_max)
+    hip_ops.gram_into(spec, pa[m:m + n_obs], n_obs, pb, R_max, kobs)
+    nb = R // S
+    n_full, reg_hi = nb * S, reg_blocks * S
+    geo = hip_ops.geo_init(2, R, S, reg_hi, off, Rl)
+    noise = 1e-2
+
+    def host_range(lo, hi, n_ch, renumber=False, **kw):
+        lo, hi = max(lo, off), min(hi, off + Rl)
+        hi = max(hi, lo)
+        sk = lo - off
+        o, nf = (lo - n_full, S) if renumber else (lo, n_full)
+        return hip_ops.blocksum_sq(spec, pa, m, pb[sk:], mu_d[sk:], hi - lo, o, nf, S, n_ch, bT, kobs[:, sk:], n_obs,
+                                   kw.pop("noise", 0.0), **kw)
+
+    Ea = hip_ops.blocksum_sq_geo(spec, pa, m, pb, mu_d, geo[0], 1, S, C, bT, kobs, n_obs, 0.0, class_mod=C)
+    assert torch.equal(Ea, host_range(0, reg_hi, C, class_mod=C))
+    Ea = hip_ops.blocksum_sq_geo(spec, pa, m, pb, mu_d, geo[0], 2, S, 1, bT, kobs, n_obs, 0.0)
+    assert torch.equal(Ea, host_range(reg_hi, R, 1))
+    Ea = hip_ops.blocksum_sq_geo(spec, pa, m, pb, mu_d, geo[0], 3, S, 3, bT, kobs, n_obs, noise)
+    assert torch.equal(Ea, host_range(0, R, 3, noise=noise))
+    Ea = hip_ops.blocksum_sq_geo(spec, pa, m, pb, mu_d, geo[0], 4, S, 1, bT, kobs, n_obs, noise)
+    assert torch.equal(Ea, host_range(n_full, R, 1, renumber=True, noise=noise))
+    # the per-candidate noise cross terms and the message part they form
+    va = hip_ops.cov_diag_geo(spec, pa, m, pb, geo[0], R_max, S, bT, kobs, n_obs, noise)
+    vb = hip_ops.cov_diag(spec, pa, m, pb, Rl, off, n_full, S, bT, kobs, n_obs, noise)
+    assert torch.equal(va[:Rl], vb[:Rl])
+    rows = q + 2
+    part = hip_ops.zeros(rows, S) - 7.0                          # (poisoned: the kernel writes the whole part)
+    hip_ops.sq_noise_part_geo(mu_d, va, geo[0], hip_ops.to_device(U), q, m, S, rows, sober, part)
+    want = torch.zeros(rows, S, dtype=torch.float64)
+    cpu.sq_noise_part_geo(mu, va[:max(Rl, 1)].cpu(), hip_ops.to_host(geo[0], "g0").clone(), U, q, m, S, rows, sober, want)
+    assert (part.cpu() - want).abs().max().item() <= 1e-13 * max(want.abs().max().item(), 1e-300)
+    assert float(part[0].abs().max()) == 0.0 and float(part[q + 1:].abs().max()) == 0.0
+
+
 def test_quadrature_step_vs_oracle(hip_ops):
     """EZy = w . mean_predict(X), VarZy = w^T K(X, X) w with the structured kernels' own mean
     (BASQ/_quadrature.py:53-64), against the oracle's CPU kernels."""

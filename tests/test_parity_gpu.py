@@ -362,11 +362,11 @@ def test_tiny_and_degenerate_pools_gpu(N, d, n, m):
         torch.set_default_dtype(prev)
 
 
-@pytest.mark.parametrize("name", [n_ for n_ in FAST + FULL if BY_NAME[n_]["kernel"].get("warp", "none") != "wsabim"])
+@pytest.mark.parametrize("name", FAST + FULL)
 def test_golden_parity_descriptor_driven_rounds(name):
-    """The production path on one GPU (stationary, posterior and WSABI-L kernels) -- rounds enqueued without a host wait,
-    geometry in a device-resident descriptor -- against the same goldens (no trace: a trace selects the round-by-round
-    loop)."""
+    """The production path on one GPU (stationary, posterior, WSABI-L and -- round 5 -- WSABI-M kernels) -- rounds enqueued
+    without a host wait, geometry in a device-resident descriptor -- against the same goldens (no trace: a trace selects the
+    round-by-round loop)."""
     import basq_amd
     import basq_amd._config as eng
 
@@ -375,6 +375,13 @@ def test_golden_parity_descriptor_driven_rounds(name):
     assert eng.ASYNC_ROUNDS
     c = BY_NAME[name]
     fx = load_golden(name)
+    if c["N"] > 2 * c["n"]:                                      # (pools of a single reduction have no such rounds)
+        from basq_amd._batch import Plan
+        from basq_amd._engine import LocalComm
+        from basq_amd._ops import HipOps
+
+        plan = Plan.of(build_product_kernel(c), "basq", None, LocalComm(), HipOps(torch.device(DEV)), None, n_sets=2 * c["n"])
+        assert plan.async_rounds, "this case does not take the descriptor-driven rounds"
     _, idx, w = _run(c, None)
     gi = torch.tensor(fx["idx"], dtype=torch.int64)
     gw = torch.tensor(fx["w"], dtype=torch.float64)
