@@ -382,3 +382,44 @@ def from_gpytorch_model(model, kind: str = "predictive", wsabi_label: str = "wsa
     if kind == "wsabi":
         return WsabiKernel(post, const, mean_cache, wsabi_label, alpha=wsabi_alpha)
     raise ValueError(kind)
+
+
+SOBER_MODES = ("predictive_covariance", "weighted_predictive_covariance", "kernel")
+
+
+def from_sober_kernel(kernel_or_model, mode: str | None = None):
+    """The structured equivalent of SOBER's ``Kernel(model, mode)`` wrapper (``SOBER/_kernel.py:4-45``) -- what the reference's
+    tutorials hand to ``SOBER/_rchq.py:recombination`` -- so that it takes the fused path instead of the dense one.
+
+    ``kernel_or_model``: a ``Kernel`` object (duck-typed: anything with ``.model`` and ``.mode``) or the gpytorch model itself
+    (then ``mode`` is required).  The three modes of ``Kernel.__call__`` (``:16-29``):
+
+    * ``"predictive_covariance"`` -> ``PosteriorKernel`` with NO noise diagonal: SOBER's ``predictive_covariance``
+      (``SOBER/_gp.py:281-305``) has the ``+ lik_var`` lines of ``BASQ/_gp.py:275-276`` commented out;
+    * ``"weighted_predictive_covariance"`` -> ``mu(x) cov(x, y) mu(y)`` (``:32-45``; ``mu = predict_mean`` =
+      ``SOBER/_gp.py:240-253``): ``WsabiKernel(..., "wsabil")`` over the same noise-free covariance;
+    * ``"kernel"`` -> ``model.covar_module.forward`` (``:27``): the ``StationaryKernel``.
+
+    The model's attributes are read exactly as ``from_gpytorch_model`` reads them (``SOBER/_gp.py:255-278`` is
+    ``BASQ/_gp.py:233-256`` verbatim, warm-up call included)."""
+    model = getattr(kernel_or_model, "model", None)
+    if model is not None and hasattr(kernel_or_model, "mode"):
+        mode = kernel_or_model.mode if mode is None else mode
+    else:
+        model = kernel_or_model
+    if mode not in SOBER_MODES:
+        raise ValueError(f'mode should be from {list(SOBER_MODES)}')                  # (the reference's own message, :29)
+    if mode == "kernel":
+        return from_gpytorch_model(model, "prior")
+    post = from_gpytorch_model(model, "predictive")
+    post = PosteriorKernel(post.base, post.Xobs, post.W, 0.0, post.mean_const, post.mean_cache)
+    if mode == "predictive_covariance":
+        return post
+    return WsabiKernel(post, post.mean_const, post.mean_cache, "wsabil")
+
+
+def looks_like_sober_kernel(obj) -> bool:
+    """Duck test for SOBER's ``Kernel`` wrapper: a callable carrying ``.model`` (a GP with a ``covar_module``) and ``.mode``."""
+    return (callable(obj) and hasattr(obj, "mode") and hasattr(getattr(obj, "model", None), "covar_module")
+            and not hasattr(obj, "base"))
+

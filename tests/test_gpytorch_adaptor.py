@@ -145,3 +145,80 @@ def test_gaussian_calc_get_cache_fallback():
 def test_obs_builder_matches_state():
     c = BY_NAME["cfg1_posterior_1e4"]
     assert torch.equal(build_obs(c), _state(c)["Xobs"])
+
+
+# ---- SOBER's Kernel(model, mode) wrapper (SOBER/_kernel.py:4-45) ---------------------------------------------------------
+class DuckSoberKernel:
+    """What ``SOBER/_kernel.py``'s ``Kernel`` looks like from outside: ``.model``, ``.mode``, callable."""
+
+    def __init__(self, model, mode="predictive_covariance"):
+        self.model, self.mode = model, mode
+
+    def __call__(self, x, y):
+        raise AssertionError("the structured equivalent must be used, not the wrapper's dense call")
+
+
+def test_from_sober_kernel_maps_the_three_modes():
+    c = BY_NAME["cfg1_posterior_1e4"]
+    st = _state(c)
+    ref = build_product_kernel(c, st)
+    m = duck_model(c, st)
+    k = BK.from_sober_kernel(DuckSoberKernel(m, "predictive_covariance"))
+    assert isinstance(k, BK.PosteriorKernel) and k.noise == 0.0                  # SOBER/_gp.py:281-305: no noise diagonal
+    assert (k.W - ref.W).abs().max().item() <= 1e-12 * ref.W.abs().max().item() and torch.equal(k.Xobs, ref.Xobs)
+    k = BK.from_sober_kernel(DuckSoberKernel(m, "weighted_predictive_covariance"))
+    assert isinstance(k, BK.WsabiKernel) and k.warp == "wsabil" and k.posterior.noise == 0.0 and k.jitter == 0.0
+    assert k.mean_const == st["mean_const"] and torch.equal(k.mean_cache.reshape(-1), st["mean_cache"].reshape(-1))
+    k = BK.from_sober_kernel(DuckSoberKernel(m, "kernel"))
+    assert isinstance(k, BK.StationaryKernel) and (k.family, k.lengthscale, k.outputscale) == ("rbf", 2.0, 1.3)
+    assert isinstance(BK.from_sober_kernel(m, "kernel"), BK.StationaryKernel)    # (the bare model + a mode)
+    with pytest.raises(ValueError):
+        BK.from_sober_kernel(DuckSoberKernel(m, "nonsense"))
+    with pytest.raises(ValueError):
+        BK.from_sober_kernel(m)                                                  # a bare model needs its mode
+    assert BK.looks_like_sober_kernel(DuckSoberKernel(m)) and not BK.looks_like_sober_kernel(ref)
+    assert not BK.looks_like_sober_kernel(lambda x, y: x @ y.T)
+
+
+def test_sober_entry_adapts_the_wrapper_to_the_fused_path():
+    """``sober.recombination(..., Kernel(model))`` -- the tutorials' call (``SOBER/BASQ/_basq.py:19-36``) -- must not take the
+    dense door silently: the wrapper is replaced by its structured equivalent (a wrapper over an unsupported GP keeps the dense
+    door, with a warning)."""
+    import warnings
+
+    from basq_amd import sober
+
+    c = BY_NAME["cfg1_posterior_1e4"]
+    m = duck_model(c, _state(c))
+    got = sober._adapt_sober_kernel(DuckSoberKernel(m, "predictive_covariance"))
+    assert isinstance(got, BK.PosteriorKernel) and got.noise == 0.0
+    m.covar_module.base_kernel = SimpleNamespace(lengthscale=torch.ones(1, 3))    # ARD: no fused equivalent
+    wrapper = DuckSoberKernel(m, "predictive_covariance")
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        assert sober._adapt_sober_kernel(wrapper) is wrapper
+    assert any("evaluated densely" in str(x.message) for x in wl)
+    f = lambda x, y: x @ y.T                                                      # noqa: E731
+    assert sober._adapt_sober_kernel(f) is f
+
+
+def test_sober_wrapper_drives_the_engine_to_the_sober_golden():
+    """End to end on the stand-in ops: a tutorial-sized SOBER golden (RBF posterior, n_obs = 2) through the adapted wrapper."""
+    import json
+    import os
+
+    from oracle.make_golden_sober import TUTORIAL_CASES, tutorial_inputs
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sober_tutorial.json")
+    with open(path) as f:
+        fx = [r for r in json.load(f) if r["case"]["name"] == "sober_tut01_rbf_nobs2"][0]
+    c = [t for t in TUTORIAL_CASES if t["name"] == "sober_tut01_rbf_nobs2"][0]
+    pts, nys = tutorial_inputs(c)
+    _, st = build_oracle_kernel(c)
+    k = BK.from_sober_kernel(DuckSoberKernel(duck_model(c, dict(st, noise=1e-10)), "predictive_covariance"))
+    torch.manual_seed(c.get("torch_seed", 1))
+    idx, w = RecombinationEngine(CpuStandInOps()).run(pts, 0, c["N"], nys, c["n"], k, variant="sober")
+    assert idx.tolist() == fx["idx"]
+    gw = torch.tensor(fx["w"], dtype=torch.float64)
+    assert ((w - gw).abs() / gw).max().item() <= 1e-5
+
