@@ -1,5 +1,6 @@
 set -u
-out=gpurun_out/r5n; mkdir -p $out
-for i in 1 2; do for lib in libbasq_hip.so libbasq_hip_sqcopy.so; do echo "== $lib"; BASQ_HIP_LIB=$PWD/basq_amd/csrc/$lib timeout -k 10 120 python tools/bench_blocksum_sq.py 2>&1 | grep -v amdgpu.ids; done; done | tee $out/sq_ab.txt
-timeout -k 10 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "wsabim_descriptor" 2>&1 | tail -2
-timeout -k 10 600 python tools/bench_configs.py --only cfg5m_wsabim_5e5 --reps 6 2>&1 | grep cfg5m | cut -c1-200
+out=gpurun_out/r5o; mkdir -p $out
+ROOT=$(pwd)
+( cd /tmp && TMPDIR=/tmp timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$out/prof" -o b -- python3 "$ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --plain > "$ROOT/$out/prof.log" 2>&1 )
+tail -1 $out/prof.log | cut -c1-300
+python tools/trace_batch.py "$(ls $out/prof/*kernel_trace.csv | head -1)" --batch -3 > $out/trace_batch.txt 2>&1; tail -42 $out/trace_batch.txt | cut -c1-200

@@ -37,10 +37,8 @@ job_ab_idle()     { B=${AB_LIB:-basq_amd/csrc/libbasq_hip_bpf2.so}; for i in 1 2
 job_fuzz_more()   { timeout -k 10 1100 python tools/fuzz_more.py --seeds ${FUZZ_SEEDS:-1 2 3} --count ${FUZZ_COUNT:-100} > "$out/fuzz_more.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/fuzz_more.txt" | cut -c1-400 | tail -40; return $rc; }
 job_ab_spin()     { timeout -k 10 400 python tools/ab_engine.py SPIN_WAIT 0 1 --reps 10 --visits 3 2>&1 | grep -v amdgpu.ids > "$out/ab_spin_wait.txt"; rc=$?; cat "$out/ab_spin_wait.txt"; return $rc; }
 job_ab_car()      { ( for r in 1 0 1 0; do echo "== BASQ_CAR_RING=$r"; BASQ_CAR_RING=$r timeout -k 10 120 python tools/bench_reduction.py 100 200 --reps 200 2>&1 | grep -E "car_eliminate|nullspace "; done; for sh in "50 100" "31 62" "100 150"; do for r in 1 0; do echo "== $sh BASQ_CAR_RING=$r"; BASQ_CAR_RING=$r timeout -k 10 120 python tools/bench_reduction.py $sh --reps 100 2>&1 | grep -E "car_eliminate"; done; done ) > "$out/ab_car_ring.txt" 2>&1; rc=$?; cat "$out/ab_car_ring.txt"; return $rc; }
-job_car_exp()     { ( for e in "" _carexp1; do echo "== lib$e"; BASQ_HIP_LIB=$PWD/basq_amd/csrc/libbasq_hip$e.so timeout -k 10 120 python tools/bench_reduction.py 100 200 --reps 200 2>&1 | grep -E "car_eliminate"; done ) > "$out/car_exp.txt" 2>&1; rc=$?; cat "$out/car_exp.txt"; return $rc; }
 job_car_prof()    { /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -Wno-unused-function -DBASQ_NS_PROF tools/car_prof.hip -o /tmp/car_prof > "$out/car_prof_build.log" 2>&1 && timeout -k 10 120 /tmp/car_prof 100 200 > "$out/car_prof.txt" 2>&1; rc=$?; cat "$out/car_prof.txt" | cut -c1-200; return $rc; }
 job_ns_prof()     { /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -Wno-unused-function -DBASQ_NS_PROF tools/ns_prof.hip -o /tmp/ns_prof > "$out/ns_prof_build.log" 2>&1 && timeout -k 10 120 /tmp/ns_prof 100 200 > "$out/ns_prof.txt" 2>&1; rc=$?; head -40 "$out/ns_prof.txt" | cut -c1-200; return $rc; }
-job_ns_exp()      { ( for e in "" _nsexp16 _nsexp32 _nsexp64 _nsexp124; do echo "== lib$e"; BASQ_HIP_LIB=$PWD/basq_amd/csrc/libbasq_hip$e.so timeout -k 10 120 python tools/bench_reduction.py 100 200 --reps 200 2>&1 | grep -E "^nullspace"; done ) > "$out/ns_exp.txt" 2>&1; rc=$?; cat "$out/ns_exp.txt"; return $rc; }
 job_ab_copy_small() { ( for r in 1 2; do for v in 0 1; do for c in cfg2_rbf_1e5 rbf_2e4_defaults; do timeout -k 10 200 python tools/bench_many.py --case $c --batches 24 --inflight 4 --set RAND_COPY_STREAM=$v 2>&1 | grep -v amdgpu.ids; done; done; done ) > "$out/ab_copy_small.txt" 2>&1; rc=$?; cat "$out/ab_copy_small.txt" | cut -c1-150; return $rc; }
 job_tests_ns()    { timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "nullspace or car_eliminate" > "$out/gpu_tests_ns.log" 2>&1; rc=$?; tail -6 "$out/gpu_tests_ns.log" | cut -c1-300; return $rc; }
 job_bench_red()   { ( for sh in "100 200" "50 100" "31 62"; do timeout -k 10 120 python tools/bench_reduction.py $sh --reps 200 2>&1 | grep -E "nullspace|car_eliminate"; done ) > "$out/bench_reduction.txt" 2>&1; rc=$?; cat "$out/bench_reduction.txt"; return $rc; }
@@ -51,6 +49,9 @@ job_ring_variants() { ( for e in "" _rg9x12 _rg10x10 _rg13x8 _rg8x13; do echo "=
 job_tests_car()   { timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "car_eliminate or nullspace_then" > "$out/gpu_tests_car.log" 2>&1; rc=$?; tail -15 "$out/gpu_tests_car.log" | cut -c1-300; return $rc; }
 job_ab_copy()     { timeout -k 10 400 python tools/ab_engine.py RAND_COPY_STREAM 0 1 --reps 10 --visits 3 2>&1 | grep -v amdgpu.ids > "$out/ab_rand_copy_stream.txt"; rc=$?; cat "$out/ab_rand_copy_stream.txt"; return $rc; }
 job_ab_late()     { timeout -k 10 400 python tools/ab_engine.py LATE_CLASSES 2 3 0 4 5 --reps 8 --visits 3 2>&1 | grep -v amdgpu.ids > "$out/ab_late_classes.txt"; rc=$?; cat "$out/ab_late_classes.txt"; return $rc; }
+job_stall()       { for g in default collect freeze; do timeout -k 10 300 python tools/stall_probe.py --steps 60 --gc $g > "$out/stall_$g.txt" 2>&1 || return 1; grep -v amdgpu.ids "$out/stall_$g.txt" | cut -c1-300 | head -3; done; }
+job_trace_small() { prof small tools/bench_many.py --case rbf_2e4_defaults --batches 12 --inflight "" && python tools/trace_batch.py "$(ls $out/prof_small/*kernel_trace.csv | head -1)" > "$out/trace_batch_2e4.txt" 2>&1; rc=$?; tail -34 "$out/trace_batch_2e4.txt" | cut -c1-160; return $rc; }
+job_sq()          { timeout -k 10 200 python tools/bench_blocksum_sq.py > "$out/blocksum_sq.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/blocksum_sq.txt"; return $rc; }
 job_sober_tut()   { timeout -k 10 600 python tools/bench_sober_tutorial.py > "$out/sober_tutorial.txt" 2>&1; rc=$?; grep -v amdgpu.ids "$out/sober_tutorial.txt" | cut -c1-330; return $rc; }
 job_dense_sweep() { for S in 400 200; do for ns in 0 1 2 3 4 5; do BASQ_DBS_NS=$ns timeout -k 10 120 python tools/bench_dense_blocksum.py --S $S 2>&1 | grep -v amdgpu.ids >> "$out/dense_sweep.txt" || return 1; done; done; cat "$out/dense_sweep.txt"; }
 job_dense_fresh() { for nt in 0 1; do for fr in "" "--fresh"; do BASQ_DBS_NT=$nt timeout -k 10 120 python tools/bench_dense_blocksum.py --S 400 $fr 2>&1 | grep -v amdgpu.ids >> "$out/dense_fresh.txt" || return 1; done; done; BASQ_DBS_NT=1 timeout -k 10 200 python -m pytest tests/test_kernels_gpu.py -q -k dense_blocksum 2>&1 | tail -1 >> "$out/dense_fresh.txt"; cat "$out/dense_fresh.txt"; }
