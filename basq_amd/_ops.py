@@ -667,6 +667,8 @@ class HipOps:
         # ONE copy stream per device for the life of the process: the caching allocator keeps a block pool per stream, and
         # ``recombination()`` builds a fresh HipOps per call -- a stream per call left a 20-MB segment behind on each of torch's 32
         # pooled streams before they came round again (tools/stall_probe.py: one hipMalloc per batch for the first 32 batches)
+        # -- and batches in flight share it too: a copy stream per slot was measured and LOST (N = 2e4, two in flight: 250 vs 357
+        # batches/s on one box; HIP maps streams onto a few hardware queues, and every extra stream makes two of them share one)
         side = _COPY_STREAMS.get(self.device.index)
         if side is None:
             side = _COPY_STREAMS[self.device.index] = torch.cuda.Stream(device=self.device)

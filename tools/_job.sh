@@ -1,6 +1,8 @@
 set -u
-out=gpurun_out/r5o; mkdir -p $out
-ROOT=$(pwd)
-( cd /tmp && TMPDIR=/tmp timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$out/prof" -o b -- python3 "$ROOT/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --plain > "$ROOT/$out/prof.log" 2>&1 )
-tail -1 $out/prof.log | cut -c1-300
-python tools/trace_batch.py "$(ls $out/prof/*kernel_trace.csv | head -1)" --batch -3 > $out/trace_batch.txt 2>&1; tail -42 $out/trace_batch.txt | cut -c1-200
+out=gpurun_out/r7z; mkdir -p $out
+for i in 1 2; do
+  for tree in . _r4; do
+    echo "== tree $tree"
+    ( cd $tree && timeout -k 10 200 python tools/bench_many.py --case rbf_2e4_defaults --batches 48 --inflight 2,4,6 2>&1 | grep -v "amdgpu.ids\|^case" )
+  done
+done | tee $out/ab_r4_vs_r5_small_in_flight.txt
