@@ -14,13 +14,23 @@ Public surface (mirrors the reference's names):
 Importing the package does not touch the GPU; the HIP library is loaded on first use and its
 absence is an error (there is no CPU fallback).
 """
-from . import kernels, pools, sober                           # noqa: F401
-from ._basq import BASQ, KernelQuadrature                      # noqa: F401
-from ._engine import EngineTrace                               # noqa: F401
+import os as _os
+
+# Batches in flight (``recombination_many``) run on one HIP stream each, and the ROCm runtime maps streams onto
+# ``GPU_MAX_HW_QUEUES`` hardware queues -- FOUR by default: with more streams than that, two batches' launches queue behind one
+# another.  Sixteen queues: N = 2e4 with four batches in flight 413 -> 660 batches/s, the headline size 72 -> 85
+# (profiles/r07_x_hw_queues_batches_in_flight.txt); one batch at a time is unaffected.  The runtime reads the variable when it
+# initialises, i.e. at the process's first HIP call: importing this package before touching the GPU is enough (``setdefault``:
+# a value the user has chosen is kept; after the first HIP call this line has no effect -- set the variable in the environment).
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+from . import kernels, pools, sober                           # noqa: F401,E402
+from ._basq import BASQ, KernelQuadrature                      # noqa: F401,E402
+from ._engine import EngineTrace                               # noqa: F401,E402
 from ._acquisition_function import SquareRootAcquisitionFunction   # noqa: F401
-from ._gaussian_calc import GaussianCalc                       # noqa: F401
+from ._gaussian_calc import GaussianCalc                       # noqa: F401,E402
 from ._sampler import PriorSampler, UncertaintySampler         # noqa: F401
-from ._rchq import (SlotPool, recombination, recombination_many, recombination_many_sharded,   # noqa: F401
+from ._rchq import (SlotPool, recombination, recombination_many, recombination_many_sharded,   # noqa: F401,E402
                     recombination_sharded, release_slots)
 
 __all__ = ["recombination", "recombination_sharded", "recombination_many", "recombination_many_sharded", "BASQ", "KernelQuadrature", "GaussianCalc", "SquareRootAcquisitionFunction", "PriorSampler", "UncertaintySampler", "EngineTrace", "kernels",

@@ -15,7 +15,7 @@ Rank 0 prints ONE JSON line.
 * value     = steps one after the other (each call returns before the next starts: the reference's synchronous call);
               ``value_concurrent2`` (``concurrent`` object) = max(K, 12) of the same steps with TWO independent batches in flight
               (``basq_amd.recombination_many``: the reference's own pair, selection + quadrature, ``BASQ/_basq.py:82-88,
-              104-106``), results bit-identical to the sequential runs; ``value_concurrent3`` on one GPU, ``value_concurrent4`` /
+              104-106``), results bit-identical to the sequential runs; ``value_concurrent3`` / ``value_concurrent4`` on one GPU, ``value_concurrent4`` /
               ``value_concurrent8`` on multi-GPU lines (owner-rank reductions: batch k's chain on rank k mod N), with an ``rccl``
               object naming the process group the line was measured on;
 * roofline  = the dominant kernel (``blocksum_kernel``): algorithmic flops = pairs * (3d + 3)
@@ -30,7 +30,11 @@ import os
 import sys
 import time
 
-import torch
+# (before the first HIP call: hardware queues for the batches in flight of `value_concurrent*` -- see basq_amd/__init__.py; the
+#  sequential `value` is unaffected)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
+import torch                                                     # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -502,7 +506,7 @@ def main():
     if not (args.no_concurrent or args.no_roofline_batch or args.plain):
         # several ranks: batch k's reductions live on rank k mod G (owner-rank mode, basq_amd/_config.py), so the chains only
         # spread over all G GPUs with at least G batches in flight
-        for k_fl in ([2, 3] if world == 1 and not force_dist else sorted({2, 4, max(4, min(world, 8))})):
+        for k_fl in ([2, 3, 4] if world == 1 and not force_dist else sorted({2, 4, max(4, min(world, 8))})):
             n_c = max(args.steps, 12, 3 * k_fl)                      # enough steps for the pipeline's fill and drain not to dominate
             calls, seeds = [], [1] * n_c
             for k in range(n_c):

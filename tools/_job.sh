@@ -1,8 +1,9 @@
 set -u
-out=gpurun_out/r7z; mkdir -p $out
-for i in 1 2; do
-  for tree in . _r4; do
-    echo "== tree $tree"
-    ( cd $tree && timeout -k 10 200 python tools/bench_many.py --case rbf_2e4_defaults --batches 48 --inflight 2,4,6 2>&1 | grep -v "amdgpu.ids\|^case" )
-  done
-done | tee $out/ab_r4_vs_r5_small_in_flight.txt
+out=gpurun_out/r7r; mkdir -p $out
+timeout -k 10 600 python -m pytest tests/test_many.py tests/test_two_ranks_one_gpu.py -x -q -m gpu > $out/tests.log 2>&1; echo "tests rc=$?"; tail -2 $out/tests.log | cut -c1-200
+timeout -k 10 600 python bench.py --no-cpu-baseline > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"
+python - <<'PY'
+import json
+j=json.load(open('gpurun_out/r7r/bench.json'))
+print(j['value'], j['ms_per_step'], j['value_concurrent2'], j['value_concurrent3'], [c['latency_ms_median'] for c in j['concurrent']], j['roofline']['frac'], j['roofline']['self_check']['ok'], j['roofline']['shader_clock_note'])
+PY
