@@ -20,7 +20,7 @@ from tests.cases import load_golden
 
 pytestmark = pytest.mark.gpu
 
-CASES = ["rbf_ragged", "cfg1_posterior_1e4", "cfg2_rbf_1e5"]
+CASES = ["rbf_ragged", "cfg1_posterior_1e4", "cfg2_rbf_1e5", "wsabim_noise_ragged"]   # (the last: WSABI-M on two shards, r05)
 
 
 def _free_port():
