@@ -1,9 +1,7 @@
 set -u
-out=gpurun_out/r7r; mkdir -p $out
-timeout -k 10 600 python -m pytest tests/test_many.py tests/test_two_ranks_one_gpu.py -x -q -m gpu > $out/tests.log 2>&1; echo "tests rc=$?"; tail -2 $out/tests.log | cut -c1-200
-timeout -k 10 600 python bench.py --no-cpu-baseline > $out/bench.json 2> $out/bench.err; echo "bench rc=$?"
-python - <<'PY'
-import json
-j=json.load(open('gpurun_out/r7r/bench.json'))
-print(j['value'], j['ms_per_step'], j['value_concurrent2'], j['value_concurrent3'], [c['latency_ms_median'] for c in j['concurrent']], j['roofline']['frac'], j['roofline']['self_check']['ok'], j['roofline']['shader_clock_note'])
-PY
+out=gpurun_out/r7c4; mkdir -p $out
+ROOT=$(pwd)
+( cd /tmp && TMPDIR=/tmp timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$out/prof" -o c4 -- python3 "$ROOT/tools/bench_configs.py" --only cfg4_matern52_1e6_d32 --reps 4 > "$ROOT/$out/prof.log" 2>&1 )
+grep cfg4 $out/prof.log | cut -c1-250
+head -12 $out/prof/c4_kernel_stats.csv | cut -c1-150
+for sh in "200 400" "150 300"; do timeout -k 10 120 python tools/bench_reduction.py $sh --reps 50 2>&1 | grep -E "nullspace|car_el" | sed "s/^/[$sh] /"; done
