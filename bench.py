@@ -302,7 +302,14 @@ def main():
 
     check = roofline_checks(k_ms, chain_ms, class_ms) if not args.no_roofline_batch else {"ok": True}
     roofline_suspect = False
-    if not check["ok"]:
+    retake = not check["ok"]
+    if dist is not None:
+        # a traced batch is a collective operation (every rank takes part in its exchanges): the decision to retake it is
+        # rank 0's, broadcast -- ranks deciding on their own timings could disagree and leave each other in a collective
+        flag = torch.tensor([1 if retake else 0], dtype=torch.int32, device=dev)
+        dist.broadcast(flag, src=0)
+        retake = bool(int(flag.item()))
+    if retake:
         first = dict(check, kernel_ms_per_batch=k_ms, chain_ms_per_batch=chain_ms)
         tr = traced_batch()
         k_ms, k_pairs, k_launches, chain_ms, class_ms = launch_figures(tr)
