@@ -1825,18 +1825,30 @@ __global__ void __launch_bounds__(256) nullspace_apply_kernel(const double* __re
     const int c0 = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c0 >= n - m) return;                              // wave-uniform
     double y[NV], v[PF][NV], tv[PF];
+    // loads without branches (round 5: the conditional loads compiled into one exec-mask branch each): a row index below 0 is
+    // clamped and gets tau = 0 (the identity, whatever its entries), a column beyond n is clamped and masked by a select
+    int cc[NV];
+    bool cok[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) y[k] = (lane + 64 * k == m + c0) ? 1.0 : 0.0;
-#pragma unroll
-    for (int p = 0; p < PF; ++p) {
-        const int i = m - 1 - p;
-        tv[p] = (i >= 0) ? tau[i] : 0.0;
+    for (int k = 0; k < NV; ++k) {
+        const int c = lane + 64 * k;
+        cok[k] = c < n;
+        cc[k] = cok[k] ? c : (n - 1);
+        y[k] = (c == m + c0) ? 1.0 : 0.0;
+    }
+    auto load_row = [&](int p, int i) {
+        const int ic = (i >= 0) ? i : 0;
+        const double t = tau[ic];
+        tv[p] = (i >= 0) ? t : 0.0;
+        const double* row = V + (size_t)ic * n;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
-            const int c = lane + 64 * k;
-            v[p][k] = (i >= 0 && c < n) ? V[(size_t)i * n + c] : 0.0;
+            const double x = row[cc[k]];
+            v[p][k] = cok[k] ? x : 0.0;
         }
-    }
+    };
+#pragma unroll
+    for (int p = 0; p < PF; ++p) load_row(p, m - 1 - p);
     for (int i0 = m - 1; i0 >= 0; i0 -= PF) {
 #pragma unroll
         for (int p = 0; p < PF; ++p) {                    // static ring slot p holds row i0 - p
@@ -1847,14 +1859,9 @@ __global__ void __launch_bounds__(256) nullspace_apply_kernel(const double* __re
             for (int k = 0; k < NV; ++k) dot += v[p][k] * y[k];
             dot = wave_sum(dot);
             const double t = tv[p] * dot;
-            const int inext = i - PF;                     // refill the slot behind the reduction
-            tv[p] = (inext >= 0) ? tau[inext] : 0.0;
 #pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                const int c = lane + 64 * k;
-                y[k] -= t * v[p][k];
-                v[p][k] = (inext >= 0 && c < n) ? V[(size_t)inext * n + c] : 0.0;
-            }
+            for (int k = 0; k < NV; ++k) y[k] -= t * v[p][k];
+            load_row(p, i - PF);                          // refill the slot behind the reduction
         }
     }
 #pragma unroll
