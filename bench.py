@@ -53,6 +53,30 @@ POOL_SEEDS = (0, 1, 2, 3, 4)        # seeds 0-4, median
 WORKLOAD = dict(N=1_000_000, d=10, n=100, nys_ratio=1e-2, family="rbf", lengthscale=2.0, outputscale=1.0, pool_seed=0)
 
 
+def roofline_self_check(k_ms, chain_ms, class_ms, per_seed_ms, steady_ms_per_launch, clock_in_situ_mhz):
+    """The checks a roofline line must pass before it is printed (review r04: 17 ms of block sums inside an 18.6-ms batch went out
+    unnoticed) -> dict with the figures, one boolean per check and ``ok``.
+
+    (1) ``fits_in_batch``: everything the traced batch timed runs on ONE stream, one after the other -- block sums + the chains of
+        null space + elimination must fit into a synchronised batch (the median over the pool seeds, 2 % slack);
+    (2) ``class_launch_plausible``: the round-1 class launch cannot take more than 1.25 x its back-to-back time scaled by the clock
+        it was given (2.03 GHz when no sample exists: the in-situ clock of every run so far; the ramp after a chain costs ~18 %)."""
+    out = {}
+    med = sorted(per_seed_ms)[len(per_seed_ms) // 2] if per_seed_ms else None
+    if med is not None and k_ms > 0:
+        out["blocksum_plus_chain_ms"] = round(k_ms + chain_ms, 3)
+        out["median_ms_per_seed"] = round(med, 3)
+        out["fits_in_batch"] = bool(k_ms + chain_ms <= 1.02 * med)
+    if steady_ms_per_launch is not None and class_ms:
+        clock = clock_in_situ_mhz or 2030.0
+        bound = 1.25 * steady_ms_per_launch * (2400.0 / clock)
+        out["class_launch_ms"] = round(max(class_ms), 3)
+        out["class_launch_bound_ms"] = round(bound, 3)
+        out["class_launch_plausible"] = bool(max(class_ms) <= bound)
+    out["ok"] = all(v for v in out.values() if isinstance(v, bool))
+    return out
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -285,20 +309,8 @@ def main():
     #      than 1.25 x its back-to-back time scaled by the clock it was given (2.4 GHz nominal when no sample exists: the ramp
     #      after a chain costs ~18 %).  A violated check retakes the traced batch once; a second violation marks the line.
     def roofline_checks(k_ms_, chain_ms_, class_ms_):
-        out = {}
-        med = sorted(per_seed_ms)[len(per_seed_ms) // 2] if per_seed_ms else None
-        if med is not None and k_ms_ > 0:
-            out["blocksum_plus_chain_ms"] = round(k_ms_ + chain_ms_, 3)
-            out["median_ms_per_seed"] = round(med, 3)
-            out["fits_in_batch"] = bool(k_ms_ + chain_ms_ <= 1.02 * med)
-        if steady is not None and class_ms_:
-            clock = clock_in_situ or 2030.0                      # (no sample: the in-situ clock of every builder run, r04)
-            bound = 1.25 * steady["ms_per_launch"] * (2400.0 / clock)
-            out["class_launch_ms"] = round(max(class_ms_), 3)
-            out["class_launch_bound_ms"] = round(bound, 3)
-            out["class_launch_plausible"] = bool(max(class_ms_) <= bound)
-        out["ok"] = all(v for k_, v in out.items() if isinstance(v, bool))
-        return out
+        return roofline_self_check(k_ms_, chain_ms_, class_ms_, per_seed_ms, steady["ms_per_launch"] if steady else None,
+                                   clock_in_situ)
 
     check = roofline_checks(k_ms, chain_ms, class_ms) if not args.no_roofline_batch else {"ok": True}
     roofline_suspect = False
