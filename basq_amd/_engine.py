@@ -86,10 +86,20 @@ class TorchDistComm:
                 return hit[1]
             except Exception:
                 pass
+        for k in [k for k, (_, c) in _SLOT_COMMS.items() if not _group_alive(self.dist, c.group)]:
+            del _SLOT_COMMS[k]                                   # communicators of a destroyed world
         ranks = list(range(self.dist.get_world_size())) if self.group is None else self.dist.get_process_group_ranks(self.group)
         comm = TorchDistComm(self.dist.new_group(ranks=ranks))
         _SLOT_COMMS[key] = (parent, comm)
         return comm
+
+
+def _group_alive(dist, group) -> bool:
+    try:
+        dist.get_rank(group)
+        return True
+    except Exception:
+        return False
 
 
 _SLOT_COMMS = {}                 # (id of the parent group, slot) -> (parent group, TorchDistComm on its own process group)

@@ -491,3 +491,61 @@ def test_host_staged_comm_drives_the_engine():
             assert idx == load_golden(nm)["idx"], f"rank {rank} {nm} (in flight)"
         assert len(slot_b) == 2 and all(n > 0 for _, n in slot_b)
     assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
+
+
+# ---- per-slot process groups survive a destroy + re-init of the default group in one process -------------------
+def _reinit_worker(rank, world, ports, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    torch.set_num_threads(2)
+    from basq_amd._engine import Job, RecombinationEngine, TorchDistComm, _SLOT_COMMS, release_slot_comms
+    from basq_amd._partition import initial_shards
+    from tests.cpu_stand_in import CpuStandInOps
+
+    names = ["rbf_ragged", "cfg1_posterior_1e4"]
+    out = []
+    try:
+        for phase, port in enumerate(ports):
+            os.environ["MASTER_PORT"] = str(port)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            jobs = []
+            for name in names:
+                c = BY_NAME[name]
+                pts, nys = build_pool(c)
+                off, n = initial_shards(c["N"], world)[rank]
+                jobs.append(Job(pts[off:off + n].clone(), off, c["N"], nys, c["n"], build_product_kernel(c), seed=c["torch_seed"]))
+            res = RecombinationEngine(CpuStandInOps(), TorchDistComm()).run_many(jobs, [CpuStandInOps(), CpuStandInOps()])
+            out.append([i.tolist() for i, _ in res])
+            n_cached = len(_SLOT_COMMS)
+            if phase == 0:
+                dist.destroy_process_group()             # (the cache still holds communicators of the destroyed world)
+            else:
+                release_slot_comms()                     # the documented way: sub-groups destroyed, cache empty
+                assert len(_SLOT_COMMS) == 0
+                dist.destroy_process_group()
+            out.append(n_cached)
+        q.put((rank, out))
+    except Exception as e:                               # noqa: BLE001
+        q.put((rank, repr(e)))
+
+
+def test_slot_process_groups_survive_a_reinitialised_default_group():
+    """The cache of per-slot process groups (``TorchDistComm.for_slot``) used to be keyed on ``id(group)`` -- ``id(None)`` for the
+    default group -- so after ``destroy_process_group()`` and a second ``init_process_group()`` in the same process (test suites,
+    long-lived services) it handed out communicators of the DESTROYED world.  Two initialisations in one process, owner-rank
+    reductions on two slots in both: goldens both times."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ports = [_free_port(), _free_port()]
+    procs = [ctx.Process(target=_reinit_worker, args=(r, world, ports, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [load_golden(nm)["idx"] for nm in ("rbf_ragged", "cfg1_posterior_1e4")]
+    for rank, out in res:
+        assert isinstance(out, list), f"rank {rank}: {out}"
+        assert out[0] == want and out[2] == want, f"rank {rank}"
+        assert out[1] == 2 and out[3] == 2               # two slot groups cached per initialisation (the stale ones replaced)
