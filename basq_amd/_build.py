@@ -22,7 +22,10 @@ ARCH = "gfx950"
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs (no v_accvgpr_read per kernel value; the block sums
 # consume every MFMA result on the VALU right away and have registers to spare)
 FLAGS = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-const-variable",
-         "-mllvm", "-amdgpu-mfma-vgpr-form"]
+         "-mllvm", "-amdgpu-mfma-vgpr-form",
+         # every kernel's registers / scratch / occupancy, kept beside the object (build/<unit>.resources.txt) and checked by
+         # tests/test_kernel_resources.py: two registers too many halve a kernel's occupancy without a word from the compiler
+         "-Rpass-analysis=kernel-resource-usage"]
 
 
 def hipcc_path() -> str:
@@ -40,19 +43,51 @@ def _obj(src, obj_dir=OBJ_DIR):
     return os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
 
 
+def resources_path(src, obj_dir=OBJ_DIR):
+    return os.path.join(obj_dir, os.path.splitext(src)[0] + ".resources.txt")
+
+
 def _stale(src, obj_dir=OBJ_DIR):
     obj = _obj(src, obj_dir)
-    if not os.path.exists(obj):
+    if not os.path.exists(obj) or not os.path.exists(resources_path(src, obj_dir)):
         return True
     t = os.path.getmtime(obj)
     return any(_mtime(f) > t for f in [src] + COMMON_DEPS + DEPS.get(src, []))
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or any(_stale(s) for s in SOURCES):
         return True
     t = os.path.getmtime(LIB)
     return any(_mtime(f) > t for f in SOURCES + COMMON_DEPS + [d for ds in DEPS.values() for d in ds])
+
+
+def kernel_resources(obj_dir=OBJ_DIR):
+    """-> ``{kernel (mangled): {vgprs, agprs, scratch, occupancy, lds, sgprs, unit}}`` from the build's resource reports."""
+    import re
+
+    out = {}
+    for src in SOURCES:
+        path = resources_path(src, obj_dir)
+        if not os.path.exists(path):
+            continue
+        name = None
+        for ln in open(path):
+            ln = ln.strip()
+            m = re.match(r"Function Name: (\S+)", ln)
+            if m:
+                name = m.group(1)
+                out[name] = {"unit": src}
+                continue
+            if name is None:
+                continue
+            for key, pat in (("sgprs", r"TotalSGPRs: (\d+)"), ("vgprs", r"^VGPRs: (\d+)"), ("agprs", r"AGPRs: (\d+)"),
+                             ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"), ("occupancy", r"Occupancy \[waves/SIMD\]: (\d+)"),
+                             ("lds", r"LDS Size \[bytes/block\]: (\d+)"), ("vgpr_spill", r"VGPRs Spill: (\d+)")):
+                m = re.search(pat, ln)
+                if m:
+                    out[name][key] = int(m.group(1))
+    return out
 
 
 def build(force: bool = False, verbose: bool = True, defines: dict | None = None, out: str | None = None) -> str:
@@ -73,7 +108,16 @@ def build(force: bool = False, verbose: bool = True, defines: dict | None = None
         cmd = [hipcc] + FLAGS + dflags + ["-c", "-o", _obj(src, obj_dir), os.path.join(CSRC, src)]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True, cwd=CSRC)
+        r = subprocess.run(cmd, cwd=CSRC, stderr=subprocess.PIPE, text=True)
+        remarks = [ln for ln in r.stderr.splitlines() if "[-Rpass-analysis=kernel-resource-usage]" in ln]
+        other = [ln for ln in r.stderr.splitlines() if "[-Rpass-analysis=kernel-resource-usage]" not in ln
+                 and not ln.lstrip().startswith(("|", "^")) and not ln[:6].strip().isdigit()]
+        if r.returncode != 0 or any("warning:" in ln or "error:" in ln for ln in other):
+            sys.stderr.write("\n".join(other) + "\n")
+        if r.returncode != 0:
+            raise subprocess.CalledProcessError(r.returncode, cmd)
+        with open(resources_path(src, obj_dir), "w") as f:
+            f.write("\n".join(ln.split("remark: ", 1)[1].replace(" [-Rpass-analysis=kernel-resource-usage]", "") for ln in remarks) + "\n")
 
     todo = [s for s in SOURCES if force or out is not None or _stale(s, obj_dir)]
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:

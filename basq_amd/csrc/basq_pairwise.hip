@@ -710,14 +710,11 @@ struct SqLaunchView<true> {
     __device__ SqLaunchView(const BlocksumArgs& a, const SqArgs& q) : A(a), Q(q) {}
 };
 
-#ifndef BASQ_SQ_WAVES_PER_EU
-#define BASQ_SQ_WAVES_PER_EU 2   // the kernel sits at 256 VGPRs: two more (the descriptor-driven variant had them) halve its occupancy
-#endif
-#if BASQ_SQ_WAVES_PER_EU > 0
-#define BASQ_SQ_ATTR __attribute__((amdgpu_waves_per_eu(BASQ_SQ_WAVES_PER_EU)))
-#else
-#define BASQ_SQ_ATTR
-#endif
+// Two waves per SIMD where the kernel fits 256 registers without spilling -- RBF with KP <= 12 (d <= 10: BASELINE config 5's shape
+// sits at exactly 256; two more registers, which the descriptor-driven variant would take, halve its occupancy and its speed) --
+// and the compiler's own choice everywhere else: forced on the wider variants the same attribute makes them SPILL (112-392 bytes
+// per lane at KK >= 5), where they otherwise run at one wave per SIMD with their registers intact.
+#define BASQ_SQ_ATTR __attribute__((amdgpu_waves_per_eu((KK <= 3 && FAM == BASQ_FAMILY_RBF) ? 2 : 1)))
 template <int KK, int FAM, int JT, bool GEO>
 __global__ void __launch_bounds__(256) BASQ_SQ_ATTR blocksum_sq_kernel(const BlocksumArgs A_in, const SqArgs Q_in) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
