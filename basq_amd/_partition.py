@@ -80,8 +80,8 @@ CHUNK_EFFICIENCY = 0.96          # smallest chunk count reaching this tail effic
 
 
 def rows_per_wave(kk: int) -> int:
-    """BASQ_JT_FOR(KK) * 16 in basq_pairwise.hip: 64 rows per wave up to KP = 20, 32 beyond."""
-    return 32 if kk >= 6 else 64
+    """BASQ_JT_FOR(KK) * 16 in basq_pairwise.hip: 64 rows per wave up to KP = 16, 32 beyond (BASQ_JT_LARGE_FROM = 5)."""
+    return 32 if kk >= 5 else 64
 
 
 def choose_chunks(n_local_blocks: int, m: int, S: int, kk: int = 3, max_chunks: int = 32, min_blocks: int = 4,

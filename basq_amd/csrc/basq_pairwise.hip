@@ -356,8 +356,11 @@ __device__ __forceinline__ void tile_accumulate(const double (&a)[JT][KK], const
 #define BASQ_BS_PREFETCH 0      // 0 = by KK (A/B builds: -DBASQ_BS_PREFETCH=1 or 2)
 #endif
 #define BASQ_BS_PF_FOR(KK) (BASQ_BS_PREFETCH ? BASQ_BS_PREFETCH : ((KK) <= 8 ? 2 : 1))
+#ifndef BASQ_BS_KK2_WAVES
+#define BASQ_BS_KK2_WAVES 3     // three waves per SIMD asked for at KK = 2, RBF (d = 3..6): left alone the kernel takes 170 registers, two
+#endif                          // over -- 6.93 -> 6.42 ms per 1e10 pairs at d = 5 (profiles/r07_x_blocksum_variants_d5_d16.txt; A/B builds: 1)
 #ifndef BASQ_BS_WAVES
-#define BASQ_BS_ATTR
+#define BASQ_BS_ATTR __attribute__((amdgpu_waves_per_eu((KK == 2 && FAM == BASQ_FAMILY_RBF) ? BASQ_BS_KK2_WAVES : 1)))
 #else
 #define BASQ_BS_ATTR __attribute__((amdgpu_waves_per_eu(BASQ_BS_WAVES, BASQ_BS_WAVES)))
 #endif
@@ -547,7 +550,11 @@ __global__ void __launch_bounds__(256) BASQ_BS_ATTR blocksum_kernel(const Blocks
 #ifndef BASQ_JT_SMALL
 #define BASQ_JT_SMALL 4         // row tiles per wave for KP <= 20 (A/B builds: -DBASQ_JT_SMALL=2)
 #endif
-#define BASQ_JT_FOR(KK) ((KK) >= 6 ? 2 : BASQ_JT_SMALL)
+#ifndef BASQ_JT_LARGE_FROM
+#define BASQ_JT_LARGE_FROM 5    // two row tiles per wave from this KK on.  Round 5: 5 instead of 6 -- at KK = 5 (d = 15..18) four tiles cost
+#endif                          // 186-254 registers = two waves per SIMD; with two tiles 128-160 = three or four: 10.46 -> 9.92 ms per 1e10
+                                // pairs at d = 16 RBF, 14.67 -> 14.48 Matern-5/2 (profiles/r07_x_blocksum_variants_d5_d16.txt; A/B builds: 6)
+#define BASQ_JT_FOR(KK) ((KK) >= BASQ_JT_LARGE_FROM ? 2 : BASQ_JT_SMALL)
 
 template <int KK, int FAM, int XS>
 static int launch_blocksum(const BlocksumArgs& A, hipStream_t st) {

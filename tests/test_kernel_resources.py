@@ -30,6 +30,7 @@ def _find(res, pattern):
 HOT = {
     r"15blocksum_kernelILi3ELi0ELi4ELi2E": (3, "headline block sums (RBF, d = 10): three waves per SIMD cover a load's latency"),
     r"15blocksum_kernelILi9ELi1ELi2ELi2E": (3, "config 4's block sums (Matern-5/2, d = 32)"),
+    r"15blocksum_kernelILi[1-9]ELi[012]ELi[24]ELi2E": (3, "every other dimension up to d = 34 (round 5: d = 3..6 and d = 15..18 sat at two waves)"),
     r"18blocksum_sq_kernelILi3ELi0ELi4ELb[01]E": (2, "WSABI-M's squared covariance at config 5's shape, both variants"),
     r"28bidiag_reflectors_reg_kernelILi4ELi7E": (4, "one work-group of 16 waves on ONE compute unit: below 4 the launch fails"),
     r"28bidiag_reflectors_reg_kernelILi4ELi[24]E": (4, "the same for the smaller shapes"),
