@@ -170,6 +170,68 @@ __device__ __forceinline__ double kernel_from_arg_k(double D, const ExpK& k, con
     }
 }
 
+// Scaled-argument form of the two table schemes (round 5; the block sums): the Nystrom fragments are multiplied by N/ln2
+// once per launch (they stay in registers), so the matrix instruction delivers y = x N/ln2 itself, and
+//     ti = (int)y = -floor(|y|) = N n + j   (v_cvt_i32_f64 truncates),      f = |y| - floor(|y|)   (v_fract_f64, |.| a modifier)
+// replace the magic-number round, the subtraction of the magic number and the FMA that forms r: exp(x) = 2^n T[j] 2^(-f/N) with a
+// polynomial in f on [0, 1) (same interval width, same errors: 2.5e-14 / 1.7e-17) -- ONE fp64 instruction fewer per kernel value
+// (11 instead of 12 VALU beside the 12 matrix lane-operations at d = 10).  Both halves read |y|: an argument that rounding left a hair
+// above zero (coincident points: D = a.a + 2 h = +-1e-16 |a|^2) evaluates exp(-|x|), 2 |x| ~ 1e-15 away.  Below ~-3.6e5 (the
+// conversion saturates; exp = 0 from -745 on) the result is an exact 0 as before.
+#ifndef BASQ_BS_SCALED_ARG
+#define BASQ_BS_SCALED_ARG 1       // A/B builds: -DBASQ_BS_SCALED_ARG=0 (the unscaled form above; same results to ~1e-15)
+#endif
+template <int XS>
+struct ExpScale {
+    static constexpr double value = (XS == 2) ? BASQ_4096_OVER_LN2 : BASQ_2048_OVER_LN2;    // N / ln2
+};
+
+// `arg_scale`: what takes the Matern kernels' r to y (-sqrt(5) N/ln2, -sqrt(3) N/ln2); unused for RBF
+template <int XS>
+__device__ __forceinline__ void expk_init_scaled(ExpK& k, double arg_scale) {
+    k.k32 = vgpr_const(arg_scale);
+    k.nhi = 0.0;
+    k.magic = 0.0;
+    if (XS == 2) {
+        k.c3 = vgpr_const(BASQ_EXP_W2);
+        k.c2 = vgpr_const(BASQ_EXP_W1);
+        k.one = vgpr_const(BASQ_EXP_W0);
+    } else {
+        k.c3 = vgpr_const(BASQ_EXP_B3);
+        k.c2 = vgpr_const(BASQ_EXP_B2);
+        k.one = vgpr_const(BASQ_EXP_B1);
+    }
+}
+
+template <int XS>
+__device__ __forceinline__ double exp_scaled_k(double y, const ExpK& k, const double* tab) {
+    const int ti = (int)y;                                              // N n + j (two's complement)
+    const double f = __builtin_amdgcn_fract(__builtin_fabs(y));
+    const double T = tab[ti & (ExpScheme<XS>::N - 1)];
+    double w = __builtin_fma(k.c3, f, k.c2);
+    w = __builtin_fma(w, f, k.one);
+    const double e = (XS == 2) ? (T * w)                                // T (w0 + w1 f + w2 f^2)
+                               : __builtin_fma(T * f, w, T);            // T (1 + f (b1 + b2 f + b3 f^2))
+    return ldexp(e, ti >> ExpScheme<XS>::SHIFT);
+}
+
+// Kernel value from the block sums' scaled product: RBF: Dp = -1/2 |(x-y)/l|^2 N/ln2; Matern: Dp = |(x-y)/l|^2 (the fragments
+// times -2: exact), k.k32 = -sqrt(5) N/ln2 resp. -sqrt(3) N/ln2.
+template <int FAM, int XS>
+__device__ __forceinline__ double kernel_from_scaled_k(double Dp, const ExpK& k, const double* tab) {
+    if (FAM == BASQ_FAMILY_RBF) {
+        return exp_scaled_k<XS>(Dp, k, tab);
+    } else {
+        const double r2 = fmax(Dp, 1e-30);                              // gpytorch: clamp_min(1e-30) before sqrt
+        const double r = BASQ_FAST_SQRT ? sqrt_pos_fast(r2) : sqrt(r2);
+        const double e = exp_scaled_k<XS>(r * k.k32, k, tab);
+        if (FAM == BASQ_FAMILY_MATERN52)
+            return __builtin_fma(5.0 / 3.0, r2, __builtin_fma(0x1.1e3779b97f4a8p+1, r, 1.0)) * e;     // (1 + sqrt(5) r + 5/3 r^2) e
+        else
+            return __builtin_fma(0x1.bb67ae8584caap+0, r, 1.0) * e;                                     // (1 + sqrt(3) r) e
+    }
+}
+
 // Sum over the 16 lanes that share g = lane >> 4 (the 16 columns of an MFMA tile); fixed butterfly
 // order, result in every lane of the group.
 // ------------------------------------------------------------------------------------------------
@@ -345,7 +407,11 @@ __device__ __forceinline__ void tile_accumulate(const double (&a)[JT][KK], const
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) D = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt][kk], f.b[kk], D, 0, 0, 0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[jt][r] = __builtin_fma(kernel_from_arg_k<FAM, XS>(D[r], ek, tab), f.w, acc[jt][r]);
+        for (int r = 0; r < 4; ++r) {
+            const double kv = BASQ_BS_SCALED_ARG ? kernel_from_scaled_k<FAM, XS>(D[r], ek, tab)
+                                                 : kernel_from_arg_k<FAM, XS>(D[r], ek, tab);
+            acc[jt][r] = __builtin_fma(kv, f.w, acc[jt][r]);
+        }
     }
 }
 
@@ -388,13 +454,19 @@ __global__ void __launch_bounds__(256) BASQ_BS_ATTR blocksum_kernel(const Blocks
     if (j0 >= A.m) return;     // wave-uniform
     const int s0 = st * 16;
     ExpK ek;
-    expk_init<XS>(ek);
+    // (scaled-argument form: the products come out as the exp's table argument, resp. as the Matern kernels' squared distance)
+    constexpr double a_scale = !BASQ_BS_SCALED_ARG ? 1.0 : (FAM == BASQ_FAMILY_RBF) ? ExpScale<XS>::value : -2.0;
+    if (BASQ_BS_SCALED_ARG)
+        expk_init_scaled<XS>(ek, (FAM == BASQ_FAMILY_MATERN52) ? -0x1.1e3779b97f4a8p+1 * ExpScale<XS>::value
+                                                               : -0x1.bb67ae8584caap+0 * ExpScale<XS>::value);
+    else
+        expk_init<XS>(ek);
 
     double a[JT][KK];
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) a[jt][kk] = A.nys[(long long)(j0 + jt * 16 + c) * KP + kk * 4 + g];
+        for (int kk = 0; kk < KK; ++kk) a[jt][kk] = A.nys[(long long)(j0 + jt * 16 + c) * KP + kk * 4 + g] * a_scale;
 
     double acc[JT][4];
 #pragma unroll
