@@ -188,25 +188,16 @@ def _skip_test_matrix_draw(ops, m, q):
 
 
 class _DenseProducts:
-    """The Nystrom Gram matrix ``A`` resident on this GPU: the three products of the range finder (``_mm_splitk``).
+    """The Nystrom Gram matrix ``A`` resident on this GPU: the three products of the range finder (``_mm_splitk``)."""
 
-    ``symmetric``: ``A`` is the Gram matrix of a stationary kernel -- symmetric to an ulp of its entries -- so ``A Q`` is
-    computed as ``A^T Q`` too, like the sharded form below has always done (``_config.SYMMETRIC_GRAM_PRODUCTS``): the transposed
-    form of ``basq_skinny_gemm_f64`` reads the stored matrix in whole 128-byte rows per contraction step and runs at its fp64-pipe
-    time (285 us per [1e4, 1e4] x [1e4, 99] product), the row-major form takes 400 us (profiles/r07_y_*).  Posterior kernels (their
-    Gram entries are differences that can cancel: the triangles then differ by much more than an ulp, and an ill-conditioned
-    posterior amplifies that as it amplifies any perturbation -- ``test_reference_is_unstable_for_ill_conditioned_posteriors``),
-    SOBER's jittered Gram and opaque callables keep the reference's ``A`` / ``A^T`` sequence."""
-
-    def __init__(self, ops, A, symmetric=False):
+    def __init__(self, ops, A):
         self.ops, self.A, self.At, self.m = ops, A, A.t(), A.shape[0]
-        self.symmetric = bool(symmetric) and cfg.SYMMETRIC_GRAM_PRODUCTS
 
     def draw(self, q, trace):
         return _gaussian_test_matrix(self.ops, self.m, q, trace)
 
     def a(self, Q):
-        return _mm_splitk(self.ops, self.At if self.symmetric else self.A, Q)
+        return _mm_splitk(self.ops, self.A, Q)
 
     def at(self, Q):
         return _mm_splitk(self.ops, self.At, Q)
@@ -382,7 +373,7 @@ FALLBACK_NOTE = ("range finder: a Cholesky pivot flagged a numerically rank-defi
                  "was recomputed with host Householder QR from the same Gaussian draw")
 
 
-def nystrom_basis_steps(ops, A, q_req: int, trace=None, overlap=None, notes=None, symmetric=False):
+def nystrom_basis_steps(ops, A, q_req: int, trace=None, overlap=None, notes=None):
     """``ker_svd_sparsify`` as a step generator -> :class:`BasisResult` (see :func:`nystrom_basis`).
 
     What the reference's result depends on is only (i) the Gaussian draw and (ii) the *range* of each intermediate
@@ -404,10 +395,9 @@ def nystrom_basis_steps(ops, A, q_req: int, trace=None, overlap=None, notes=None
     ``fallback()`` -- host Householder QR + the reference's SVD, from the same Gaussian draw.
 
     ``A``: the Gram matrix (a tensor) or a products object (``_DenseProducts`` / ``_ShardedProducts``).
-    ``symmetric``: a tensor ``A`` is symmetric to an ulp (a stationary kernel's Gram matrix): see ``_DenseProducts``.
     ``overlap``: optional callable that enqueues independent GPU work; it is called once, behind the range finder's launches.
     """
-    prod = _DenseProducts(ops, A, symmetric) if torch.is_tensor(A) else A
+    prod = _DenseProducts(ops, A) if torch.is_tensor(A) else A
     m = prod.m
     with _Timer(ops, trace, "basis.randn"):
         R = prod.draw(q_req, trace)
@@ -458,9 +448,9 @@ def nystrom_basis_steps(ops, A, q_req: int, trace=None, overlap=None, notes=None
     return BasisResult(fallback() if (cfg.GPU_RANGE_FINDER and q_req <= m) else _host_range_finder(ops, prod, R, trace))
 
 
-def nystrom_basis(ops, A, q_req: int, trace=None, overlap=None, symmetric=False):
+def nystrom_basis(ops, A, q_req: int, trace=None, overlap=None):
     """Blocking form of :func:`nystrom_basis_steps` -> ``U`` (the pivot flag is read back and honoured here)."""
-    res = drive(nystrom_basis_steps(ops, A, q_req, trace, overlap, symmetric=symmetric))
+    res = drive(nystrom_basis_steps(ops, A, q_req, trace, overlap))
     if res.bad is not None and int(res.bad.cpu()[0]) != 0:
         return res.fallback()
     return res.U

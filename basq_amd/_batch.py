@@ -407,8 +407,7 @@ class Batch:
                 A = kernel.dense(ops, pts_nys, pts_nys, self.center)
                 if self.plan.sober:
                     A = make_cov_psd(A)
-            res = yield from nystrom_basis_steps(ops, A, self.num_pts - 1, trace, overlap=late, notes=self.notes,
-                                                 symmetric=bool(getattr(kernel, "symmetric_gram", False)) and not self.plan.sober)
+            res = yield from nystrom_basis_steps(ops, A, self.num_pts - 1, trace, overlap=late, notes=self.notes)
             del A
             U, bad, self._basis_fallback = res.U, res.bad, res.fallback
             assert U.shape[0] == q

@@ -12,10 +12,6 @@ HOST_SVD_THREADS = 1             # 100x200 / 99x99 SVDs: fastest single-threaded
 
 # The range finder's products on basq_skinny_gemm_f64 (False: library GEMMs through torch, for A/B comparisons).
 OWN_RANGE_GEMM = True
-# A stationary kernel's Nystrom Gram matrix is symmetric to an ulp of its entries: ``A Q`` is computed as ``A^T Q`` (the
-# faster form of basq_skinny_gemm_f64: 285 vs 400 us per headline product), as the sharded range finder has always done.  False:
-# the reference's A / A^T sequence (what posterior kernels and opaque callables always get).
-SYMMETRIC_GRAM_PRODUCTS = True
 # CholeskyQR's factor + triangular solve in ONE launch whose solvers start on a column panel as soon as the factor has
 # published it (basq_cholqr_f64; same bits as the two separate launches).  False: the two launches of round 2.
 FUSED_CHOLQR = True

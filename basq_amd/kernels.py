@@ -66,11 +66,6 @@ def _mm(ops, A, B):
 class StationaryKernel:
     """``outputscale * base(|x - y| / lengthscale)``, base in {rbf, matern52, matern32}, shared lengthscale."""
 
-    # K(P, P) is symmetric to an ulp of its entries (a function of |x - y|^2, which the device forms from the same products in
-    # either order): the range finder may read it as its own transpose (``_basis._DenseProducts``).  The posterior kernels do NOT
-    # claim this: ``k(x, y) - k(x, X) W k(X, y)`` can cancel, and its two triangles then differ by far more than an ulp.
-    symmetric_gram = True
-
     def __init__(self, family: str, lengthscale: float, outputscale: float = 1.0):
         if family not in FAMILY:
             raise ValueError(f"unknown kernel family {family!r}; expected one of {sorted(FAMILY)}")
