@@ -89,6 +89,53 @@ def test_blocksum_vs_standin(hip_ops, family, d, m, S, Rl, off, n_full, n_chunks
     assert (tg - tc).abs().max().item() <= 1e-13 * tc.abs().max().item()
 
 
+@pytest.mark.parametrize("family", ["rbf", "matern52", "matern32"])
+def test_blocksum_single_values_over_the_whole_exponent_range(hip_ops, family):
+    """The block sums' exponential takes its argument ALREADY SCALED from the matrix instruction (v_cvt_i32_f64 + v_fract_f64 of
+    |y|; basq_pairwise.hip ``exp_scaled_k``): one candidate per set (S = R) turns every entry of the block sums into ONE kernel
+    value, checked against float64 formulas evaluated on the raw points (direct differences, no expansion) over the whole range --
+    coincident points (the product comes out as +-1e-16 |x|^2: both signs must give 1), values down to the denormals, exact zeros
+    beyond -745 -- and against ``gpytorch``'s formulas (``BASQ/_parameters.py:192-208`` picks the kernels)."""
+    d, ell = 3, 1.3
+    spec = _spec(family, d, ell=ell)
+    g = torch.Generator().manual_seed(11)
+    nys = torch.randn(64, d, generator=g, dtype=torch.float64) * 2.0
+    dirs = torch.randn(96, d, generator=g, dtype=torch.float64)
+    dirs = dirs / dirs.norm(dim=1, keepdim=True)
+    # distances (in lengthscales) from 0 to 60: -r^2/2 down to -1800 (RBF), -sqrt(5) r down to -134 (Matern)
+    r = torch.cat([torch.zeros(32, dtype=torch.float64), torch.linspace(1e-9, 60.0, 64, dtype=torch.float64)])
+    cand = nys[torch.arange(96) % 64] + dirs * (r * ell)[:, None]        # candidates 0..31 ARE Nystrom points 0..31
+    R = S = 96
+    mu = torch.ones(R, dtype=torch.float64)
+    center = nys.mean(0)
+    dev = hip_ops.to_device
+    A_g = hip_ops.pack(spec, dev(nys), dev(center), 0, pad_rows_to=64)
+    B_g = hip_ops.pack(spec, dev(cand), dev(center), 1)
+    X, _ = hip_ops.blocksum(spec, A_g, 64, B_g, dev(mu), None, R, 0, R, S, 1)
+    X = X.cpu().reshape(64, S)
+    diff = (nys[:, None, :] - cand[None, :, :]) / ell
+    r2 = (diff * diff).sum(-1)
+    if family == "rbf":
+        arg, want = -0.5 * r2, torch.exp(-0.5 * r2)
+    else:
+        rr = r2.clamp_min(1e-30).sqrt()
+        c = 5.0 ** 0.5 if family == "matern52" else 3.0 ** 0.5
+        poly = (1.0 + c * rr + (5.0 / 3.0) * r2) if family == "matern52" else (1.0 + c * rr)
+        arg, want = -c * rr, poly * torch.exp(-c * rr)
+    # what the expanded product x.y + h_x + h_y can lose: ~13 roundings at the size of its terms
+    size = ((nys - center) / ell).pow(2).sum(1)[:, None] + ((cand - center) / ell).pow(2).sum(1)[None, :]
+    tol = 1e-13 + 4e-15 * size + 1e-15 * arg.abs()
+    normal = want > 1e-290
+    rel = ((X - want).abs() / want.clamp_min(1e-300))[normal]
+    assert (rel <= tol[normal]).all(), (rel / tol[normal]).max().item()
+    assert (X[~normal] <= 1e-289).all() and (X[~normal] >= 0).all()
+    if family == "rbf":
+        assert (X[arg < -746.0] == 0.0).all()                           # exact zeros, no denormal garbage
+    # coincident points: exactly the pairs (j, j) for j < 32
+    same = X[torch.arange(32), torch.arange(32)]
+    assert (same - 1.0).abs().max().item() <= 1e-13
+
+
 def test_matvec_vs_standin(hip_ops):
     cpu = CpuStandInOps()
     spec = _spec("rbf", 10)
