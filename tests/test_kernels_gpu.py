@@ -89,15 +89,18 @@ def test_blocksum_vs_standin(hip_ops, family, d, m, S, Rl, off, n_full, n_chunks
     assert (tg - tc).abs().max().item() <= 1e-13 * tc.abs().max().item()
 
 
+@pytest.mark.parametrize("accurate", [False, True])
 @pytest.mark.parametrize("family", ["rbf", "matern52", "matern32"])
-def test_blocksum_single_values_over_the_whole_exponent_range(hip_ops, family):
+def test_blocksum_single_values_over_the_whole_exponent_range(hip_ops, family, accurate):
     """The block sums' exponential takes its argument ALREADY SCALED from the matrix instruction (v_cvt_i32_f64 + v_fract_f64 of
     |y|; basq_pairwise.hip ``exp_scaled_k``): one candidate per set (S = R) turns every entry of the block sums into ONE kernel
     value, checked against float64 formulas evaluated on the raw points (direct differences, no expansion) over the whole range --
     coincident points (the product comes out as +-1e-16 |x|^2: both signs must give 1), values down to the denormals, exact zeros
     beyond -745 -- and against ``gpytorch``'s formulas (``BASQ/_parameters.py:192-208`` picks the kernels)."""
+    import dataclasses
+
     d, ell = 3, 1.3
-    spec = _spec(family, d, ell=ell)
+    spec = dataclasses.replace(_spec(family, d, ell=ell), accurate_exp=accurate)     # 2048-entry table + cubic (posterior kernels)
     g = torch.Generator().manual_seed(11)
     nys = torch.randn(64, d, generator=g, dtype=torch.float64) * 2.0
     dirs = torch.randn(96, d, generator=g, dtype=torch.float64)
@@ -124,7 +127,7 @@ def test_blocksum_single_values_over_the_whole_exponent_range(hip_ops, family):
         arg, want = -c * rr, poly * torch.exp(-c * rr)
     # what the expanded product x.y + h_x + h_y can lose: ~13 roundings at the size of its terms
     size = ((nys - center) / ell).pow(2).sum(1)[:, None] + ((cand - center) / ell).pow(2).sum(1)[None, :]
-    tol = 1e-13 + 4e-15 * size + 1e-15 * arg.abs()
+    tol = (2e-15 if accurate else 1e-13) + 4e-15 * size + 1e-15 * arg.abs()
     normal = want > 1e-290
     rel = ((X - want).abs() / want.clamp_min(1e-300))[normal]
     assert (rel <= tol[normal]).all(), (rel / tol[normal]).max().item()
