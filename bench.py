@@ -155,16 +155,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        one_batch(k=k)
     # The ONE full garbage collection every Python process owes after its imports and set-up, paid here instead of inside the
     # timed loop: the imports leave the collector's older generations primed, the first young-generation pass of the loop
     # cascades into a full collection, and that walks every object torch has created -- 35-44 ms, the "48.6-ms step among twenty
     # of 18.6 ms" of round 4's driver run (tools/stall_probe.py, profiles/r07_a_stall_probe_*.txt).  Later passes are
-    # young-generation only (0.05-0.2 ms every 5-20 batches) and stay inside the timed region.
+    # young-generation only (0.05-0.2 ms every 5-20 batches) and stay inside the timed region.  It is paid after the FIRST
+    # warm-up batch (which creates what the set-up still owes: streams, pinned buffers, the kernels' first launches), so that the
+    # remaining warm-up batches run between those 40 ms of an idle GPU and the timed loop: the first timed step no longer opens
+    # on a shader clock that has dropped (it was ~1 ms slower than the rest).
     import gc
 
-    gc.collect()
+    for k in range(args.warmup):
+        one_batch(k=k)
+        if k == 0:
+            gc.collect()
+    if args.warmup == 0:
+        gc.collect()
     barrier()
     t0 = time.perf_counter()
     step_marks = []
