@@ -55,11 +55,44 @@ def _stale(src, obj_dir=OBJ_DIR):
     return any(_mtime(f) > t for f in [src] + COMMON_DEPS + DEPS.get(src, []))
 
 
+def _all_inputs():
+    return SOURCES + COMMON_DEPS + [d for ds in DEPS.values() for d in ds]
+
+
+def source_hash() -> str:
+    """sha256 over the kernel sources, the shared header, the generated table AND the compiler flags: names the binary a counter
+    pass or a resource report was taken on (``tools/pmc_summary.py`` stores it, ``bench.py`` compares it with the tree's)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for rel in sorted(_all_inputs()):
+        h.update(os.path.basename(rel).encode() + b"\0")
+        with open(os.path.join(CSRC, rel), "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+STAMP = os.path.join(CSRC, "libbasq_hip.stamp")              # source_hash() of the tree the in-tree library was built from
+
+
+def _stamp_matches() -> bool:
+    try:
+        with open(STAMP) as f:
+            return f.read().strip() == source_hash()
+    except OSError:
+        return False
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB) or any(_stale(s) for s in SOURCES):
+    """The LIBRARY against its sources and flags only (the objects and resource reports under ``build/`` do not travel to the GPU
+    box: their absence there must not trigger a rebuild over a library a running process has mapped)."""
+    if not os.path.exists(LIB):
         return True
+    if os.path.exists(STAMP):
+        return not _stamp_matches()                              # sources or FLAGS changed since the library was linked
     t = os.path.getmtime(LIB)
-    return any(_mtime(f) > t for f in SOURCES + COMMON_DEPS + [d for ds in DEPS.values() for d in ds])
+    return any(_mtime(f) > t for f in _all_inputs())
 
 
 def kernel_resources(obj_dir=OBJ_DIR):
@@ -126,6 +159,9 @@ def build(force: bool = False, verbose: bool = True, defines: dict | None = None
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.run(link, check=True, cwd=CSRC)
+    if out is None:
+        with open(STAMP, "w") as f:
+            f.write(source_hash() + "\n")
     return target
 
 

@@ -122,13 +122,16 @@ class SlotPool:
 _DEFAULT_POOL = SlotPool()
 
 
-def release_slots():
-    """Free the streams and cached buffers ``recombination_many`` / ``recombination_many_sharded`` keep between calls, and the
-    per-slot process groups of the latter (collective on several ranks: every rank calls it)."""
-    from ._engine import release_slot_comms
-
+def release_slots(comms: bool = False):
+    """Free the streams and cached buffers ``recombination_many`` / ``recombination_many_sharded`` keep between calls.  LOCAL:
+    a rank may call it on its own (memory pressure on one rank).  ``comms=True`` additionally destroys the per-slot process
+    groups of ``recombination_many_sharded`` -- a COLLECTIVE: every rank of the group must make the same call, or the next
+    sharded call rebuilds sub-groups on some ranks only and hangs in ``new_group`` (``_engine.release_slot_comms``)."""
     _DEFAULT_POOL.release()
-    release_slot_comms()
+    if comms:
+        from ._engine import release_slot_comms
+
+        release_slot_comms()
 
 
 def _run_many(jobs, device, comm, in_flight, timings=None, pool: SlotPool | None = None):

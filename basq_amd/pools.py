@@ -64,3 +64,70 @@ def pool_digest(t: torch.Tensor) -> str:
     """sha256 of the raw little-endian float64 bytes (fixture integrity check)."""
     a = np.ascontiguousarray(t.detach().cpu().numpy().astype("<f8", copy=False))
     return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def _host_stationary(x: torch.Tensor, y: torch.Tensor, family: str, lengthscale: float, outputscale: float) -> torch.Tensor:
+    """``ScaleKernel(RBF | Matern)`` on HOST tensors, for the few hundred synthetic observations below only (the candidates'
+    kernel values are the HIP library's business): squared distances of the points centred on the first operand's mean from one
+    augmented product ``[-2a, |a|^2, 1] [b, 1, |b|^2]^T``, clamped at zero -- the formulation gpytorch publishes for its
+    stationary kernels (``BASQ/_parameters.py:192-208`` selects them)."""
+    def sq_dist(a, b):
+        shift = a.mean(-2, keepdim=True)
+        a, b = a - shift, b - shift
+        an, bn = a.pow(2).sum(-1, keepdim=True), b.pow(2).sum(-1, keepdim=True)
+        lhs = torch.cat([-2.0 * a, an, torch.ones_like(an)], dim=-1)
+        rhs = torch.cat([b, torch.ones_like(bn), bn], dim=-1)
+        return lhs.matmul(rhs.transpose(-2, -1)).clamp_min_(0)
+
+    if family == "rbf":
+        base = sq_dist(x.div(lengthscale), y.div(lengthscale)).div_(-2).exp_()
+    else:
+        mean = x.mean(dim=-2, keepdim=True)
+        r = sq_dist((x - mean).div(lengthscale), (y - mean).div(lengthscale)).clamp_min_(1e-30).sqrt_()
+        c5, c3 = 5.0 ** 0.5, 3.0 ** 0.5
+        if family == "matern52":
+            base = (c5 * r).add(1).add(5.0 / 3.0 * r ** 2) * torch.exp(-c5 * r)
+        elif family == "matern32":
+            base = (c3 * r).add(1) * torch.exp(-c3 * r)
+        else:
+            raise ValueError(family)
+    return base.mul(outputscale)
+
+
+def synthetic_gp_state(Xobs: torch.Tensor, family: str, lengthscale: float, outputscale: float, noise: float, seed: int):
+    """A stand-in for a FITTED exact GP on the observations ``Xobs`` (host tensor), as the posterior / WSABI kernels of BASELINE
+    configs 1 and 5 need one and gpytorch is not in the image: targets from a fixed smooth positive function of the inputs (no
+    random numbers, no libm beyond ``exp``), then the caches gpytorch's prediction strategy would hold --
+
+        W = (K(X, X) + noise I)^-1   (``BASQ/_gp.py:246-255``: ``S S^T`` of ``covar_cache``),   mean_cache = W (y - mean(y)).
+
+    -> ``(W [n_obs, n_obs], mean_const, mean_cache [n_obs], y)``.  The synthetic-input twin of ``gmm_pool``: ``bench.py``'s
+    ``configs`` leg and the tools build their posterior kernels from it; ``tests/test_pools.py`` holds it bit-identical to the
+    generator the reference-generated goldens were made with."""
+    n = Xobs.shape[0]
+    K = _host_stationary(Xobs, Xobs, family, float(lengthscale), float(outputscale)) + noise * torch.eye(n, dtype=Xobs.dtype)
+    proj = torch.arange(1, Xobs.shape[1] + 1, dtype=Xobs.dtype) / Xobs.shape[1]
+    t = Xobs @ proj
+    y = 1.0 + 0.5 * t * t / (1.0 + t * t) + 0.01 * (seed % 7)
+    mean_const = float(y.mean())
+    W = torch.cholesky_inverse(torch.linalg.cholesky(K))
+    return W, mean_const, W @ (y - mean_const), y
+
+
+def kernel_for_case(c: dict):
+    """The structured kernel object of a parity case ``c`` (``tests/cases.py``: the dict stored verbatim in every golden fixture)
+    built from seeds alone -- pool-style observations + ``synthetic_gp_state``."""
+    from . import kernels as BK
+
+    k = c["kernel"]
+    base = BK.StationaryKernel(k["family"], k["lengthscale"], k["outputscale"])
+    p = k.get("posterior")
+    if p is None:
+        return base
+    Xobs = gmm_pool(p["n_obs"], c["d"], p["obs_seed"])
+    W, mean_const, mean_cache, _ = synthetic_gp_state(Xobs, k["family"], k["lengthscale"], k["outputscale"], p["noise"],
+                                                      p["obs_seed"])
+    post = BK.PosteriorKernel(base, Xobs, W, p.get("diag_noise", p["noise"]))
+    if k.get("warp", "none") == "none":
+        return post
+    return BK.WsabiKernel(post, mean_const, mean_cache, k["warp"])

@@ -49,6 +49,8 @@ PEAK_FP64_VECTOR_TFLOPS = 78.6      # MI355X nominal: 256 CU x 128 flop/clk x 2.
 MEASURED_FP64_TFLOPS = {"fma_only": 72.9, "mfma_only": 47.2, "mixed_fma_mfma": 63.1}
 PEAK_HBM_GBS = 8000.0
 POOL_SEEDS = (0, 1, 2, 3, 4)        # seeds 0-4, median
+CONFIG_STEPS = 3                    # timed batches per entry of `configs` (after two warm-up batches)
+WATCHDOG_EXIT_CODE = 3              # the runs with batches in flight did not finish on several ranks (the line is printed first)
 
 WORKLOAD = dict(N=1_000_000, d=10, n=100, nys_ratio=1e-2, family="rbf", lengthscale=2.0, outputscale=1.0, pool_seed=0)
 
@@ -77,6 +79,24 @@ def roofline_self_check(k_ms, chain_ms, class_ms, per_seed_ms, steady_ms_per_lau
     return out
 
 
+def newest_counters(profiles_dir, tree_hash=None):
+    """-> (record, file name, stale) of the newest committed counter summary ``profiles/r*_pmc.json`` (names sort by round and
+    letter); ``stale`` = the record's ``kernel_source_sha256`` is absent or differs from the tree's (``tree_hash``: for tests)."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(profiles_dir, "r[0-9][0-9]_*pmc.json")) + glob.glob(os.path.join(profiles_dir, "r[0-9][0-9]_pmc.json")),
+                   key=os.path.basename)
+    if not files:
+        return None, None, None
+    with open(files[-1]) as f:
+        rec = json.load(f)
+    if tree_hash is None:
+        from basq_amd._build import source_hash
+
+        tree_hash = source_hash()
+    return rec, os.path.basename(files[-1]), rec.get("kernel_source_sha256") != tree_hash
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,29 +112,69 @@ def parse():
     ap.add_argument("--no-roofline-batch", action="store_true", help="skip the traced batch, the per-seed latencies and the "
                     "pipelined runs (counter passes: tools/gpu_jobs.sh pmc)")
     ap.add_argument("--no-concurrent", action="store_true", help="skip the runs with several batches in flight")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other one-GPU BASELINE configurations (`configs`)")
+    ap.add_argument("--no-h2d", action="store_true", help="skip `value_incl_h2d` (the pool handed over from host memory)")
     ap.add_argument("--plain", action="store_true", help="for kernel statistics under rocprofv3: the timed loop, the per-seed "
                     "batches and the traced batch only -- no batches in flight, no back-to-back repetition of the round-1 "
                     "launch, no clock sampler (every block-sum launch in the profile then belongs to a batch)")
     return ap.parse_args()
 
 
+def self_launch(n_ranks: int) -> int:
+    """``python bench.py --gpus N`` WITHOUT a launcher (no ``RANK`` in the environment): start the N ranks here, as children of a
+    parent that never touches the GPU -- ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py <same arguments>``, the command the driver would have used -- relay what they print, and make rank 0's
+    JSON line the LAST line of this process's standard output.  -> the launcher's exit code (non-zero if any rank failed or a
+    watchdog fired).  Nothing here may call into HIP: a parent that had initialised the GPU could not start children safely."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()                             # (counting devices does not initialise the runtime)
+    if have < n_ranks:
+        raise SystemExit(f"bench.py --gpus {n_ranks}: this node shows {have} GPU(s)")
+    with socket.socket() as sk:                                  # a free rendezvous port on the loop-back interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] no launcher in the environment: starting {n_ranks} rank(s) through torch.distributed.run (port {port})",
+          file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line_json = None
+    for ln in proc.stdout:                                       # the ranks' stderr goes straight through
+        if ln.startswith('{"metric"'):
+            line_json = ln.rstrip("\n")                          # held back: printed LAST
+        else:
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+    rc = proc.wait()
+    if line_json is not None:
+        print(line_json, flush=True)
+    elif rc == 0:
+        rc = 4                                                   # the ranks left without a line: never a success
+    return rc
+
+
 def main():
     args = parse()
+    force_dist_env = os.environ.get("BASQ_BENCH_FORCE_DIST") == "1"
+    if "RANK" not in os.environ and (args.gpus > 1 or force_dist_env):
+        # no launcher: be the launcher (before anything touches the GPU)
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+        args.gpus = world                                        # an external launcher decides the rank count
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists in basq_amd)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    # BASQ_BENCH_FORCE_DIST=1: take the multi-rank code path (RCCL group, sharded entry, collectives) even with one
-    # rank -- the only way to exercise it on a 1-GPU box; never set by the driver.
-    force_dist = os.environ.get("BASQ_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    # BASQ_BENCH_FORCE_DIST=1: take the multi-rank code path (launcher, RCCL group, sharded entry, collectives) even with
+    # one rank -- the only way to exercise it on a 1-GPU box (tests/test_bench_dist_gpu.py); never set by the driver.
+    force_dist = force_dist_env and "RANK" in os.environ
     if world > 1 or force_dist:
         import torch.distributed as dist
 
@@ -135,12 +195,16 @@ def main():
     # Every rank regenerates the same pools (bit-reproducible generator) and keeps its contiguous slice.
     off, Rl = initial_shards(N, world)[rank]
     pools_dev = []
-    pool = None
+    pools_pinned = []                                                # (one rank only: the pools in page-locked host memory, for
+    pool = None                                                      #  `value_incl_h2d`)
+    want_h2d = world == 1 and not (args.no_roofline_batch or args.plain or args.no_h2d)
     for sd in POOL_SEEDS:
         p = gmm_pool(N, d, sd)
         if sd == POOL_SEEDS[0]:
             pool = p                                                 # host copy of seed 0: the CPU baseline's input
         pools_dev.append((p[:m].to(dev), p[off:off + Rl].to(dev)))   # PriorSampler: pts_nys = prefix of the pool
+        if want_h2d:
+            pools_pinned.append(p.pin_memory())
         del p
 
     def one_batch(trace=None, k=0):
@@ -341,14 +405,78 @@ def main():
     # group per pass, tools/gpu_jobs.sh pmc -> tools/pmc_summary.py), committed with the commit they were taken on.
     # FETCH_SIZE / WRITE_SIZE in KiB; the kernel's loads are 8 B per lane (not the 16-B-per-lane streams whose gfx950
     # half-count the micro-architecture guide describes): calibrated in the file against the launch's compulsory bytes.
-    pmc_rec, pmc_name = None, None
-    for name in ("r07_z_pmc.json", "r07_x_pmc.json", "r06_x_pmc.json", "r06_pmc.json", "r05_pmc.json", "r03_pmc.json"):   # the newest committed counter passes
-        path = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(path) and N == WORKLOAD["N"] and d == WORKLOAD["d"] and world == 1:
-            with open(path) as f:
-                pmc_rec = json.load(f)
-            pmc_name = name
-            break
+    # Counters cannot be collected from inside the run, so they are REPLAYED from the file -- and bound to the binary: every file
+    # carries the hash of the kernel sources + compiler flags it was taken on (`kernel_source_sha256`, basq_amd._build.source_hash);
+    # if the tree's hash differs, `counters_stale` is true and traffic / mfma_util / fp64_pipe_busy_pmc are null.
+    pmc_rec, pmc_name, counters_stale = None, None, None
+    if N == WORKLOAD["N"] and d == WORKLOAD["d"] and world == 1:
+        pmc_rec, pmc_name, counters_stale = newest_counters(os.path.join(ROOT, "profiles"))
+    pmc_live = None if counters_stale else pmc_rec
+
+    # ---- the same steps with the pool handed over from HOST memory (outside `value`): the reference's boundary starts from host
+    #      tensors (``BASQ/_sampler.py:31-34``: ``prior.sample`` on the CPU); page-locked here, one copy per batch on the launch stream
+    h2d = None
+    if pools_pinned:
+        def one_batch_h2d(k):
+            pts = pools_pinned[k % len(pools_pinned)].to(dev, non_blocking=True)
+            torch.manual_seed(1)
+            return basq_amd.recombination(pts, pts[:m], n, kern, dev)
+
+        for k in range(2):
+            one_batch_h2d(k)
+        barrier()
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            i_h, w_h = one_batch_h2d(k)
+        barrier()
+        dth = time.perf_counter() - t1
+        i_d, w_d = one_batch(k=args.steps - 1)
+        h2d = dict(value=args.steps / dth, unit="batches/s", steps=args.steps, ms_per_step=1e3 * dth / args.steps,
+                   bytes_per_batch=int(N * d * 8), bit_identical_to_resident=bool(torch.equal(i_h, i_d) and torch.equal(w_h, w_d)),
+                   note="pool [N, d] float64 copied from page-locked host memory inside every step; never part of `value`")
+        del pools_pinned[:]
+
+    # ---- the other BASELINE configurations that fit one GPU (configs[1], [3], [4] and tutorial 03's WSABI-M at config 5's size),
+    #      outside `value`: a few batches each, checked against the reference-generated golden of the same case ----
+    configs_out = None
+    if world == 1 and not force_dist and not (args.no_configs or args.no_roofline_batch or args.plain):
+        from basq_amd.pools import kernel_for_case
+
+        configs_out = []
+        for name, label in (("cfg2_rbf_1e5", "configs[1]"), ("cfg4_matern52_1e6_d32", "configs[3] on ONE GPU"),
+                            ("cfg5_wsabil_5e5", "configs[4]"), ("cfg5m_wsabim_5e5", "configs[4]'s size with WSABI-M")):
+            gpath = os.path.join(ROOT, "tests", "golden", name + ".json")
+            if not os.path.exists(gpath):
+                continue
+            with open(gpath) as f:
+                fx = json.load(f)
+            c = fx["case"]
+            pts_c = gmm_pool(c["N"], c["d"], c["pool_seed"]).to(dev)
+            nys_c = pts_c[: c["m"]]
+            kern_c = kernel_for_case(c)
+
+            def run_c():
+                torch.manual_seed(c["torch_seed"])
+                return basq_amd.recombination(pts_c, nys_c, c["n"], kern_c, dev)
+
+            run_c()
+            run_c()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(CONFIG_STEPS):
+                i_c, w_c = run_c()
+            torch.cuda.synchronize()
+            ms_c = 1e3 * (time.perf_counter() - t1) / CONFIG_STEPS
+            same = i_c.cpu().tolist() == fx["idx"]
+            gw = torch.tensor(fx["w"], dtype=torch.float64)
+            configs_out.append(dict(name=name, baseline_config=label, N=c["N"], d=c["d"], n=c["n"], m=c["m"],
+                                    kernel=c["kernel"]["family"] + ("" if c["kernel"]["posterior"] is None else "+posterior")
+                                    + ("" if c["kernel"]["warp"] == "none" else "+" + c["kernel"]["warp"]),
+                                    steps=CONFIG_STEPS, ms_per_batch=round(ms_c, 3), batches_per_s=round(1e3 / ms_c, 2),
+                                    indices_identical=bool(same),
+                                    max_rel_weight_error=float(((w_c.cpu() - gw).abs() / gw).max().item()) if same else None))
+            del pts_c, nys_c, kern_c
+        torch.cuda.empty_cache()
 
     if args.breakdown:
         tb = basq_amd.EngineTrace(time_kernels=False, host_sync=True)
@@ -454,13 +582,18 @@ def main():
                 "peak_measured_source": "profiles/r02_microbench_fp64_rates.txt (fma-only 72.9, mfma-only 47.2, both "
                                         "interleaved 63.1 TF/s: the figure that applies to this kernel's instruction mix)",
                 # counters (rocprofv3 --pmc passes over this command, per BATCH = all block-sum launches of one batch)
-                "traffic": pmc_rec["hbm_bytes_per_batch"] if pmc_rec else None,
-                "hbm_GBs_counter": (pmc_rec["hbm_bytes_per_batch"] / (k_ms * 1e-3) / 1e9) if (pmc_rec and k_ms > 0) else None,
-                "hbm_frac": (pmc_rec["hbm_bytes_per_batch"] / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if (pmc_rec and k_ms > 0) else None,
-                "mfma_util": pmc_rec.get("mfma_util") if pmc_rec else None,
-                "fp64_pipe_busy_pmc": pmc_rec.get("fp64_pipe_busy") if pmc_rec else None,
-                "counters_source": (f"profiles/{pmc_name} (commit {pmc_rec.get('commit')}, {pmc_rec.get('source')}); bytes per "
-                                    "batch from the counters, time from this run's HIP events") if pmc_rec else None,
+                "traffic": pmc_live["hbm_bytes_per_batch"] if pmc_live else None,
+                "hbm_GBs_counter": (pmc_live["hbm_bytes_per_batch"] / (k_ms * 1e-3) / 1e9) if (pmc_live and k_ms > 0) else None,
+                "hbm_frac": (pmc_live["hbm_bytes_per_batch"] / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS) if (pmc_live and k_ms > 0) else None,
+                "mfma_util": pmc_live.get("mfma_util") if pmc_live else None,
+                "fp64_pipe_busy_pmc": pmc_live.get("fp64_pipe_busy") if pmc_live else None,
+                "stall_counters": pmc_live.get("stalls") if pmc_live else None,
+                "counters_stale": counters_stale,
+                "counters_source": (f"profiles/{pmc_name} (commit {pmc_rec.get('commit')}, kernel sources "
+                                    f"{str(pmc_rec.get('kernel_source_sha256'))[:12]}, {pmc_rec.get('source')}); bytes per "
+                                    "batch from the counters, time from this run's HIP events"
+                                    + ("; STALE: taken on other kernel sources than this tree's -- figures withheld" if counters_stale else ""))
+                if pmc_rec else None,
                 "steady_state": steady,
                 # the clock the class launches (most of kernel_ms_per_batch) actually had, and the fraction against the fp64
                 # peak AT that clock: what the kernel leaves on the table, as opposed to what the power manager withholds
@@ -486,6 +619,9 @@ def main():
                         "that batch (the clock is sampled in a second traced batch and kept only if its launches took the same time)",
             },
             "cpu_baseline": cpu,
+            "value_incl_h2d": h2d["value"] if h2d else None,
+            "incl_h2d": h2d,
+            "configs": configs_out,
             "result_digest": {"n_selected": int(idx.numel()), "w_sum": float(w.sum().item())},
             "parity_vs_golden": parity,
         }
@@ -520,9 +656,14 @@ def main():
                 emit(build_line(dict(concurrent), note="the runs with batches in flight did not ALL finish within the watchdog's limit "
                                                        "on this machine (those that did are reported): value and roofline are from "
                                                        "the sequential path, completed before"))
-            # (exit code 0 on purpose: `value` and the roofline were measured before, on the sequential path, and a driver that
-            #  drops the line of a non-zero exit would lose them; the time-out itself is in `concurrent_timed_out`)
-            os._exit(0)
+            # The line is out (flushed) and carries `concurrent_timed_out`; the process leaves with a NON-ZERO code of its own
+            # (3): a hang of the owner-rank path must not read as a successful run.  Every rank runs this timer, so no peer is
+            # left waiting in a collective for a rank that has gone; nothing is restarted or re-executed.
+            try:
+                sys.stdout.flush()
+                sys.stderr.flush()
+            finally:
+                os._exit(WATCHDOG_EXIT_CODE)
 
         watchdog = threading.Timer(float(os.environ.get("BASQ_BENCH_CONCURRENT_LIMIT_S", "240")), give_up)
         watchdog.daemon = True

@@ -260,9 +260,15 @@ def test_structured_differential_fuzz_gpu():
             unstable_log.append(label + f"; reference vs itself: idx moves {ref_idx_moves}, rel {ref_rel:.2e}")
         print("\n".join(unstable_log))
         assert compared >= 100 and min(kinds) >= 20, (compared, kinds)
-        # PINNED (review r04: "a regression from 6 to 12 passes silently"): exactly these cases of the list leave the bar, each with
-        # the reference's own instability shown above -- a new member is a regression, a missing one a change worth a look
-        assert unstable_cases == STRUCTURED_FUZZ_UNSTABLE, (unstable_cases, unstable_log)
+        # (review r04: "a regression from 6 to 12 passes silently"; ADVICE r5: an exact set breaks on any legitimate 1-ulp change.)
+        # Every member has shown the reference's own instability above; the KNOWN members are the expected ones, at most two
+        # further cases may cross the bar (another compiler, another exponential) before this is a regression worth a look,
+        # and a known case coming back inside the bar is only reported
+        new = sorted(set(unstable_cases) - set(STRUCTURED_FUZZ_UNSTABLE))
+        back = sorted(set(STRUCTURED_FUZZ_UNSTABLE) - set(unstable_cases))
+        if new or back:
+            warnings.warn(f"structured fuzz: cases outside the bar changed -- new {new}, back inside {back}")
+        assert len(new) <= 2, (unstable_cases, unstable_log)
     finally:
         torch.set_default_dtype(prev)
 

@@ -15,6 +15,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import basq_amd                                  # noqa: E402
+
+basq_amd.configure_hw_queues()                                      # (before the first GPU call)
 from basq_amd._engine import Job, LocalComm, RecombinationEngine   # noqa: E402
 from basq_amd._rchq import _DEFAULT_POOL                # noqa: E402
 from basq_amd.pools import gmm_pool              # noqa: E402

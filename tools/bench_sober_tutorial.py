@@ -18,6 +18,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import basq_amd                                                    # noqa: E402
+
+basq_amd.configure_hw_queues()                                      # (before the first GPU call)
 from basq_amd import sober                                         # noqa: E402
 from oracle.make_golden_sober import TUTORIAL_CASES, tutorial_inputs   # noqa: E402
 from tests.cases import build_product_kernel                      # noqa: E402

@@ -103,6 +103,9 @@ for tag, ctr in (("dfetch", "FETCH_SIZE"), ("dwrite", "WRITE_SIZE")):
               f"128-B requests of 16-B-per-lane streaming reads at 64 B, MI355X_MICROARCH.md: FETCH_SIZE x 2 for such reads)")
 PY
 cat "$out/pmc_dense_summary.txt"; }
+# stall / issue counters of the block sums: one tolerant pass per group (a counter this part does not offer fails only its own pass)
+job_pmc_stalls()  { ( cd /tmp && rocprofv3 --list-avail > "$ROOT/$out/rocprof_list_avail.txt" 2>&1 ); for g in "a:SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "b:SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY" "c:SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" "d:SQ_WAVES SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" "e:SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_CYCLES_VALU SQ_INSTS_VALU_MFMA_MOPS_F64"; do pmc "stall_${g%%:*}" "${g#*:}" || note "pass stall_${g%%:*} failed (kept going)"; done; return 0; }
+job_attribute()   { timeout -k 10 900 python tools/attribute_mismatch.py > "$out/attribute_mismatch.txt" 2>&1; rc=$?; grep -v "amdgpu.ids\|^\[{" "$out/attribute_mismatch.txt" | cut -c1-220; return $rc; }
 job_pmc()         { pmc fetch "FETCH_SIZE" && pmc write "WRITE_SIZE" && pmc pipe "SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" && python tools/pmc_summary.py "$out" > "$out/pmc_summary.json"; rc=$?; cut -c1-400 "$out/pmc_summary.json"; return $rc; }
 
 for j in "$@"; do

@@ -71,6 +71,11 @@ def main():
             res["commit"] = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
         except OSError:
             pass
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from basq_amd._build import source_hash
+
+    # the binary these counters belong to: bench.py replays the file only while the tree's kernel sources hash to the same value
+    res["kernel_source_sha256"] = source_hash()
     per = {}
     for tag in ("fetch", "write", "pipe"):
         g = batches(per_dispatch(os.path.join(out, f"pmc_{tag}")))
@@ -120,6 +125,32 @@ def main():
             simd_cycles = 1024.0 * gui / 8.0
             res["mfma_util"] = mfma_busy / simd_cycles                       # matrix-instruction busy cycles / SIMD cycles
             res["fp64_pipe_busy"] = (4.0 * valu + mfma_busy) / simd_cycles   # + 4 issue cycles per VALU wave instruction
+    # stall / issue counters (one pass per group, `tools/gpu_jobs.sh pmc_stalls`): per-batch sums over the block-sum launches and the
+    # ratios the review asked for -- where the fp64 pipe's idle share goes
+    stalls = {}
+    for d_ in sorted(glob.glob(os.path.join(out, "pmc_stall_*"))):
+        if not os.path.isdir(d_):
+            continue
+        try:
+            g = batches(per_dispatch(d_))
+        except SystemExit:
+            continue
+        g = g[1:] if len(g) > 1 else g
+        names = sorted({c for grp in g for dsp in grp for c in dsp["c"]})
+        for c in names:
+            stalls[c] = mean_sum(g, c)
+    if stalls:
+        wc = stalls.get("SQ_WAVE_CYCLES")
+        ratios = {}
+        if wc:
+            for c in ("SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS",
+                      "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_ANY", "SQ_INST_CYCLES_VMEM", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_MISC"):
+                if stalls.get(c) is not None:
+                    ratios[c + "_per_wave_cycle"] = stalls[c] / wc
+        res["stalls"] = {"per_batch": stalls, "ratios": ratios,
+                         "note": "SQ_WAVE_CYCLES counts (in quad-cycle units on this part) the cycles waves spent resident; "
+                                 "WAIT_INST_ANY: waiting for any instruction issue; WAIT_ANY: waiting on s_waitcnt; ACTIVE_INST_x: "
+                                 "cycles an instruction of type x was executing, per wave"}
     res["source"] = ("rocprofv3 --pmc, one counter group per pass (FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU "
                      "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE) over `python bench.py --steps 2 --warmup 1 "
                      "--no-cpu-baseline --no-roofline-batch`; mean over the batches after the first; KiB x 1024, raw (8-B-per-lane "
