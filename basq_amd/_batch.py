@@ -40,6 +40,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _config as cfg
+from . import _epochs
 from ._basis import (_lapack_threads, _mm_splitk, _ShardedProducts, _skip_test_matrix_draw, _Timer, make_cov_psd,
                      nystrom_basis_steps)
 from ._lib import ROLE_A, ROLE_B
@@ -239,7 +240,11 @@ class Batch:
         self._extend_basis(U)
         self._trace_phase("setup", t0)
         if self.plan.async_rounds and self.R > self.S:
-            outcome = yield from self._async_rounds(pre)         # False | True (a round violated the plan) | "basis"
+            # False | True (a round violated the plan) | "basis"
+            if _epochs.eligible(self):
+                outcome = yield from _epochs.async_rounds_columns(self, pre)     # no pairwise evaluation inside an epoch
+            else:
+                outcome = yield from self._async_rounds(pre)
             pre = None
             if outcome == "basis":
                 # the range finder's pivot flag arrived with the descriptor table: the rounds ran on a basis that is not

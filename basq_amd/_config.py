@@ -52,6 +52,11 @@ LATE_CLASSES_PIPELINED = 0       # with several batches in flight another batch'
 # the blocks beyond a multiple of C and the ragged tail (< (C + 1) * S points, halving every round) are evaluated directly.
 CLASS_SUMS = True
 MAX_CLASSES = 16                 # classes at the start of an epoch (power of two): 16 -> the kernel runs in rounds 1, 6, 11
+# Inside an epoch the candidates OUTSIDE the residue classes (the < C full blocks behind the regular region + the ragged tail) are
+# carried as message columns and regrouped with the classes (basq_epoch_turn_f64): no block sums, projection or compaction between
+# two eliminations; their columns are evaluated beside the epoch's first chain on a side stream (basq_amd/_epochs.py; one rank,
+# BASQ variant, no noise diagonal).  False: every round evaluates them afresh (round 5's path).
+IRR_COLUMNS = True
 # Rounds driven by a device-resident descriptor, no host wait per round (any rank count; structured kernels except WSABI-M).
 ASYNC_ROUNDS = True
 

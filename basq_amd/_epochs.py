@@ -1,0 +1,169 @@
+"""Descriptor-driven rounds with NO pairwise evaluation inside an epoch (round 6; ``BASQ/_rchq.py:76-130``).
+
+``Batch._async_rounds`` regroups the residue-class messages from round to round but still evaluates, projects and compacts
+the candidates outside the classes -- the ``e < C`` full blocks behind the regular region and the ragged tail -- in EVERY round:
+five chip-wide launches (60-70 us) between two chains of single-work-group kernels.  Those candidates obey the same law as the
+classes: a round sends the survivor of (block b, kept rank k) to position ``b * n_keep + k`` with its weight rescaled by
+``w*_k / tot``, the tail -- if set S-1 survives -- follows behind, and the regular survivors fill the next regular region
+exactly.  Kept as MESSAGE COLUMNS (one ``[rows]`` column per candidate: slot b = block b, one more slot = the tail), they form a
+closed system that ``basq_epoch_turn_f64`` advances together with the classes and the round descriptor: ONE launch between an
+elimination and the next round's finalize.  No candidate is touched inside an epoch, so the rounds' compactions are applied
+together when the next epoch (or the host's round-by-round loop) needs the candidates again (``basq_reweight_compact_rounds_f64``).
+
+What the columns cost -- one block-sum chunk and one projection per irregular block instead of one for all of them -- is paid
+BESIDE the epoch's first chain, on the device's side stream: that chain keeps one compute unit busy for ~0.4 ms and needs none
+of it; the launch stream waits for the side stream only before the first ``epoch_turn``.
+
+Scope: one rank, BASQ variant, stationary / posterior / WSABI-L kernels without a likelihood-noise diagonal term.  Everything
+else keeps ``Batch._async_rounds``.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _config as cfg
+from ._partition import choose_chunks
+
+
+def eligible(b) -> bool:
+    """Can batch ``b`` (operands prepared) take the column form of the descriptor-driven rounds?"""
+    plan = b.plan
+    return bool(cfg.IRR_COLUMNS and plan.async_rounds and plan.classes and b.comm.world == 1 and b.owner is None
+                and not plan.sober and plan.warp != "wsabim" and b.diag_noise == 0.0 and hasattr(b.ops, "epoch_turn"))
+
+
+def block_capacity(R_lo: int, R_up: int, S: int, C: int) -> int:
+    """Upper bound of the number of full blocks behind the regular region (``nb mod C``) over the possible block counts."""
+    return max(nb % C for nb in range(R_lo // S, R_up // S + 1))
+
+
+def async_rounds_columns(b, pre):
+    """Generator with the contract of ``Batch._async_rounds`` (-> False | True = a round violated the plan | "basis")."""
+    from ._batch import classes_for
+
+    ops, trace = b.ops, b.trace
+    S, s, q, m_ext, q_ext = b.S, b.s, b.q, b.m_ext, b.q_ext
+    spec, nys_ext, U_ext, kscale, kp = b.spec, b.nys_ext, b.U_ext, b.kscale, b.kp
+    n = s                                                        # a regular round keeps s = S / 2 sets
+    rows = q_ext + 1
+    reg_hi0 = (pre[4] * S) if (pre is not None and pre[3] >= 2) else 0
+    geo_t = ops.geo_init(64, b.R, S, reg_hi0, 0, b.R)
+    r = 0
+    R_lo = R_up = b.R
+    cand, mu, gid, wx = b.cand, b.mu, b.gid, b.wx
+    pend, pend_r0, pend_R = [], 0, b.R                           # rounds whose compaction is still owed; first row; bound of len(cand)
+    P, C_cur, E_cur = None, 1, 0                                 # this round's buffer [C | fold | E | tail] while inside an epoch
+    plan_C = None
+    records = []
+    side_ev, side_keep = None, None
+
+    def flush(out_rows):
+        """Apply the pending rounds' compactions (one launch) -> candidates of round ``r``."""
+        nonlocal cand, mu, gid, wx, pend
+        if pend:
+            cand, mu, gid, wx = ops.reweight_compact_rounds(cand, mu, gid, wx, geo_t[pend_r0:], pend, pend_R, S, kp, out_rows, n)
+            pend = []
+
+    while R_lo > S:
+        g_row = geo_t[r]
+        if P is None:
+            # ---- a fresh evaluation: the start of an epoch (C >= 2), or a round without classes
+            flush(R_up)
+            pend_r0, pend_R = r, R_up
+            if pre is not None:                                  # round 1: launched before the basis, host geometry
+                Xpart, totpart, n_chunks, C_cur = pre[:4]
+                pre = None
+            else:
+                C_cur = plan_C if plan_C is not None else 1
+                if C_cur >= 2:
+                    n_chunks = C_cur + 1
+                    Xpart, totpart = ops.empty(n_chunks, m_ext, S), ops.empty(n_chunks, S)
+                    b.sums.timed_geo(r, 1, 1.0, lambda: ops.blocksum_geo(
+                        spec, nys_ext, m_ext, cand, mu, wx, g_row, 1, S, C_cur, out=(Xpart[:C_cur], totpart[:C_cur]),
+                        class_mod=C_cur))
+                    b.sums.timed_geo(r, 2, 1.0, lambda: ops.blocksum_geo(
+                        spec, nys_ext, m_ext, cand, mu, wx, g_row, 2, S, 1, out=(Xpart[C_cur:], totpart[C_cur:])))
+                else:
+                    n_chunks = choose_chunks(max(R_lo // S, 1), m_ext, S, kp // 4)
+                    Xpart, totpart = ops.empty(n_chunks, m_ext, S), ops.empty(n_chunks, S)
+                    b.sums.timed_geo(r, 3, 1.0, lambda: ops.blocksum_geo(spec, nys_ext, m_ext, cand, mu, wx, g_row, 3, S,
+                                                                         n_chunks, out=(Xpart, totpart)))
+            if C_cur >= 2:
+                E_cur = block_capacity(R_lo, R_up, S, C_cur)
+                P = ops.empty(C_cur + E_cur + 2, rows, S)
+                # classes + the ordinary irregular chunk, whose message IS the fold slot of this round
+                ops.project_chunks(U_ext, q_ext, m_ext, Xpart, totpart, C_cur + 1, S, kscale, out=P[:C_cur + 1])
+                # ... and the columns the NEXT rounds of the epoch regroup, beside this round's chain (side stream)
+                side = ops.side_ops()
+                side.wait_event(ops.record_event(False))
+                with ops.side_context():
+                    Xirr, totirr = side.empty(E_cur + 1, m_ext, S), side.empty(E_cur + 1, S)
+                    if E_cur > 0:
+                        side.blocksum_geo(spec, nys_ext, m_ext, cand, mu, wx, g_row, 5, S, E_cur, out=(Xirr[:E_cur], totirr[:E_cur]),
+                                          class_mod=C_cur)
+                    side.blocksum_geo(spec, nys_ext, m_ext, cand, mu, wx, g_row, 4, S, 1, out=(Xirr[E_cur:], totirr[E_cur:]))
+                    side.project_chunks(U_ext, q_ext, m_ext, Xirr, totirr, E_cur + 1, S, kscale, out=P[C_cur + 1:])
+                    side_ev = side.record_event(False)
+                    side_keep = (Xirr, totirr)
+                parts = P[:C_cur + 1]
+            else:
+                parts = ops.project(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S, kscale).unsqueeze(0)
+            del Xpart, totpart
+        else:
+            parts = P[:C_cur + 1]
+        # ---- the round's chain of single-work-group kernels
+        ev_c = ops.record_event() if b.sums._timing() else None
+        XcarT, tot = ops.finalize(parts, parts.shape[0], parts.shape[1], q, S, None, b.m, min(b.m, S), 0.0, 0, 0, 0, None)
+        PhiT = ops.nullspace(XcarT, s, S)
+        keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, tot, S, s)
+        if ev_c is not None:
+            trace.chain_events.append((ev_c, ops.record_event()))
+        if trace is not None:
+            records.append(ops.info_kept_buffer(info, kept))
+        pend.append(dict(keep_rank=keep_rank, w_star=w_star, tot=tot, info=info))
+        # bounds of the next survivor count; the class plan of the next fresh evaluation follows the lower one
+        R_lo_n = (R_lo // S) * n
+        R_up_n = (R_up // S) * n + (S - 1)
+        if P is not None and C_cur >= 2:
+            # next round's classes, columns, fold slot and descriptor: one launch
+            if side_ev is not None:
+                ops.wait_event(side_ev)                          # (the columns of the epoch's first round)
+                side_ev, side_keep = None, None
+            E_next = (E_cur * n + S - 1) // S
+            P = ops.epoch_turn(P, C_cur, E_cur, E_next, kept, keep_rank, w_star, tot, info, g_row, geo_t[r + 1])
+            C_cur, E_cur = C_cur // 2, E_next
+            plan_C = None
+        else:
+            P, C_cur, E_cur = None, 1, 0                         # the epoch is over (or there was none): next round evaluates afresh
+            plan_C = classes_for(R_lo_n // S) if b.plan.classes else 1
+            ops.round_next(g_row, info, keep_rank, S, plan_C if plan_C >= 2 else 0, True, geo_t[r + 1])
+        r += 1
+        R_lo, R_up = R_lo_n, R_up_n
+        if len(pend) >= 8:                                       # (never with C <= 16: an epoch has at most five rounds)
+            flush(R_up)
+            pend_r0, pend_R = r, R_up
+    flush(R_up)                                                  # the host's loop needs the candidates
+    if side_ev is not None:                                      # (the last enqueued round opened an epoch: its columns are not
+        ops.wait_event(side_ev)                                  #  used, but their buffer must outlive the side stream's writes)
+        side_ev, side_keep = None, None
+    bad64 = (b._basis_bad != 0).to(torch.int64) if b._basis_bad is not None else geo_t[0, 3:4] * 0
+    flat, ready = ops.to_host_async(torch.cat([geo_t[:r + 1].reshape(-1), bad64.reshape(1)]), "geo_table")
+    yield ready                                                  # the ONE wait of the asynchronous rounds
+    table = flat[:-1].view(r + 1, 8)
+    if b._basis_bad is not None:
+        b._basis_bad = None
+        if int(flat[-1]) != 0:
+            return "basis"
+    row = table[r].tolist()
+    if row[3] != 0:
+        return True
+    if trace is not None:
+        b._trace_async_rounds(table, records, r)
+    b.cand, b.mu, b.gid, b.wx = cand, mu, gid, wx
+    b.R, b.off, b.Rl = int(row[0]), int(row[6]), int(row[7])
+    b.R_lo = R_lo
+    b.cls = None
+    if P is not None:
+        # mid-epoch hand-over: the host's loop evaluates the irregular candidates itself (slot C of its class messages)
+        b.cls = dict(M=P[:C_cur + 1], C=C_cur, reg_blocks=int(row[2]) // S)
+    return False

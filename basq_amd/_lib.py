@@ -18,7 +18,7 @@ BASQ_OK = 0
 FAMILY = {"rbf": 0, "matern52": 1, "matern32": 2}
 ROLE_A, ROLE_B = 0, 1
 MAX_DIM = 38
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class KernelSpecC(C.Structure):
@@ -61,6 +61,9 @@ SIGNATURES = {
     "basq_blocksum_geo_f64": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "basq_reweight_compact_geo_f64": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _i64,
                                                 _i32, _vp, _vp, _vp, _vp, _vp]),
+    "basq_epoch_turn_f64": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "basq_reweight_compact_rounds_f64": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _i32,
+                                                   _vp, _vp, _vp, _vp, _vp]),
     "basq_init_state_f64": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp]),
     "basq_dense_blocksum_f64": (C.c_int, [_vp, _i32, _i64, _i64, _vp, _i64, _i64, _i32, _f64, _i32, _vp, _vp, _vp]),
     "basq_blocksum_sq_f64": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _vp,

@@ -24,6 +24,7 @@ def _ptr(t):
 
 
 _COPY_STREAMS = {}               # device index -> the copy stream of ``HipOps.from_pinned_side``
+_SIDE_OPS = {}                   # device index -> HipOps on that device's side compute stream (``HipOps.side_ops``)
 PROJECT_KSPLIT_MAX = 64          # K slices of the projection GEMM (A/B: tools/ab_engine.py --module _ops)
 
 
@@ -409,6 +410,34 @@ class HipOps:
               "basq_reweight_compact_geo_f64")
         return cand_o, mu_o, gid_o, wx_o
 
+    # -- epochs without a pairwise evaluation inside: the irregular candidates as message columns (ABI 15) -----------
+    def epoch_turn(self, Pin, C, E_in, E_out, kept, keep_rank, w_star, tot, info, geo_row, geo_next, out=None):
+        """The launch behind an elimination inside an epoch -> next round's buffer ``[C / 2 | fold | E_out | tail]`` and the next
+        round's descriptor (``basq_epoch_turn_f64``)."""
+        n, rows, S = Pin.shape
+        assert Pin.is_contiguous() and n == C + E_in + 2 and C >= 2
+        Pout = self.empty(C // 2 + E_out + 2, rows, S) if out is None else out
+        assert Pout.is_contiguous() and tuple(Pout.shape) == (C // 2 + E_out + 2, rows, S)
+        check(self.lib.basq_epoch_turn_f64(_ptr(Pin), int(C), int(E_in), _ptr(Pout), int(E_out), rows, S, _ptr(kept), _ptr(keep_rank),
+                                           _ptr(w_star), _ptr(tot), _ptr(info), _ptr(geo_row), _ptr(geo_next), self._stream()),
+              "basq_epoch_turn_f64")
+        return Pout
+
+    def reweight_compact_rounds(self, cand, mu, gid, wx, geo_rows, outcomes, R_max, S, kp, out_rows, expect_keep=-1):
+        """The compactions of ``len(outcomes)`` consecutive rounds in one launch (``outcomes``: per round the dict of
+        ``car_eliminate`` -- keep_rank, w_star, tot, info; ``geo_rows``: the descriptor table from the first of them on)."""
+        n = len(outcomes)
+        cand_o = self.empty(max(out_rows, 1), kp)
+        mu_o = self.empty(max(out_rows, 1))
+        gid_o = self.empty(max(out_rows, 1), dtype=torch.int64)
+        wx_o = self.empty(max(out_rows, 1)) if wx is not None else None
+        arr = lambda key: (C.c_void_p * n)(*[o[key].data_ptr() for o in outcomes])      # noqa: E731
+        check(self.lib.basq_reweight_compact_rounds_f64(_ptr(cand), _ptr(mu), _ptr(gid), _ptr(wx), _ptr(geo_rows), n, arr("keep_rank"),
+                                                        arr("w_star"), arr("tot"), arr("info"), int(max(R_max, 1)), S, kp,
+                                                        int(max(out_rows, 1)), int(expect_keep), _ptr(cand_o), _ptr(mu_o), _ptr(gid_o),
+                                                        _ptr(wx_o), self._stream()), "basq_reweight_compact_rounds_f64")
+        return cand_o, mu_o, gid_o, wx_o
+
     def init_state(self, Rl, gid0, n_total):
         mu = self.empty(max(Rl, 1))
         gid = self.empty(max(Rl, 1), dtype=torch.int64)
@@ -699,3 +728,20 @@ class HipOps:
     def wait_event(self, ev):
         """Make this object's stream wait (on the GPU) for ``ev``; the host does not block."""
         self.torch_stream().wait_event(ev)
+
+    def side_ops(self):
+        """A second ``HipOps`` on the device's SIDE compute stream: work that nothing on the launch stream needs for a while -- the
+        message columns of an epoch's irregular candidates, taken while the epoch's first chain of single-work-group kernels
+        leaves 255 compute units idle -- is enqueued there between ``side.wait_event(launch-stream event)`` and
+        ``self.wait_event(side event)``.  ONE side stream per device for the life of the process (the reasons given at
+        ``from_pinned_side``: allocator pools per stream, hardware queues shared between streams); batches in flight share it."""
+        idx = self.device.index
+        ops = _SIDE_OPS.get(idx)
+        if ops is None:
+            ops = _SIDE_OPS[idx] = HipOps(self.device, stream=torch.cuda.Stream(device=self.device))
+        return ops
+
+    def side_context(self):
+        """``with ops.side_context():`` -- torch's current stream is the side stream inside the block, so that what is allocated
+        there (work buffers of the wrappers included) comes from THAT stream's pool and is recycled in its order."""
+        return torch.cuda.stream(self.side_ops().stream)

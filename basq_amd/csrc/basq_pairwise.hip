@@ -333,6 +333,7 @@ struct BlocksumArgs {
     // launch arguments, so the host can enqueue a round before it knows how many candidates survived the previous one.
     const long long* geo;                      // {R, n_full, reg_hi, violation, nb, n_tail, -, -}
     int geo_mode;                              // 1: positions [0, reg_hi)   2: [reg_hi, R)   3: [0, R)   4: the remainder [n_full, R) as a block of its own
+                                               // 5: the full blocks beyond the regular region, [reg_hi, n_full), one chunk per block (class mode)
 };
 
 // Candidate range of a descriptor-driven launch (wave-uniform scalar loads and arithmetic; the formulas of blocksum_impl).
@@ -347,6 +348,7 @@ __device__ __forceinline__ long long blocksum_apply_geo(BlocksumArgs& A) {
     if (A.geo_mode == 1) hi = reg_hi;
     else if (A.geo_mode == 2) lo = reg_hi;
     else if (A.geo_mode == 4) lo = n_full;
+    else if (A.geo_mode == 5) { lo = reg_hi; hi = n_full; }
     if (lo < s_off) lo = s_off;
     if (hi > s_end) hi = s_end;
     if (hi < lo) hi = lo;
@@ -1575,9 +1577,12 @@ int basq_blocksum_geo_f64(const basq_kernel_spec* spec, const double* nys, int32
                           int32_t n_chunks, int32_t class_mod, int32_t class0, double* Xpart, double* totpart,
                           void* stream) {
     if (!spec_ok(spec) || !nys || !cand || !mu || !Xpart || !totpart || !geo) return BASQ_EINVAL;
-    if (m < 1 || S < 1 || n_chunks < 1 || geo_mode < 1 || geo_mode > 4) return BASQ_EINVAL;
+    if (m < 1 || S < 1 || n_chunks < 1 || geo_mode < 1 || geo_mode > 5) return BASQ_EINVAL;
     if (class_mod < 0 || class0 < 0 || (class_mod > 0 && class0 + n_chunks > class_mod)) return BASQ_EINVAL;
-    if (class_mod > 0 && geo_mode != 1) return BASQ_EINVAL;       // residue classes cover the regular region only
+    // residue classes cover full blocks only: the regular region (mode 1), or -- mode 5 -- the fewer than class_mod full blocks
+    // behind it, whose block index modulo class_mod numbers them (the regular region is a multiple of class_mod blocks)
+    if (class_mod > 0 && geo_mode != 1 && geo_mode != 5) return BASQ_EINVAL;
+    if (geo_mode == 5 && class_mod < 2) return BASQ_EINVAL;
     BlocksumArgs A;
     A.nys = nys; A.cand = cand; A.mu = mu; A.wx = wx; A.Xpart = Xpart; A.totpart = totpart;
     A.Rl = 0; A.off = 0; A.n_full = 0; A.blk_lo = 0; A.blk_hi = 0; A.blk_per_chunk = 1;   // set on the device

@@ -2023,6 +2023,184 @@ __global__ void round_next_kernel(const long long* __restrict__ gp, const int* _
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Epochs without a pairwise evaluation inside (round 6).  The candidates the residue classes do not cover -- the e < C full
+// blocks behind the regular region and the ragged tail of t < S points -- obey the same law as the classes: a round sends the
+// survivor of (block b, kept rank k) to position b * n_keep + k with its weight rescaled by w*_k / tot, and the tail, if set
+// S - 1 is kept, follows behind.  Their contributions to a round's message are kept as MESSAGE COLUMNS, one per candidate:
+// slot b < e holds block b (column j = the block's point in set j), one more slot holds the tail (column k = tail point k).
+// The regular survivors fill exactly the next regular region (reg_blocks * n_keep = (reg_blocks / 2) * S), so the columns
+// form a closed system: next round's columns are a gather + rescale of this round's -- no candidate is touched, nothing is
+// evaluated or projected again until the next epoch starts.
+//
+// Buffer of a round ("parts"): [C class messages | 1 fold slot | E block slots | 1 tail slot], each [rows, S].  The fold slot
+// is what the finalize kernel adds behind the classes: sum over the blocks, in index order, + the tail's columns, in index
+// order, into set S - 1 (BASQ/_rchq.py:91-99).  In an epoch's FIRST round it is the message of the ordinary irregular chunk
+// (basq_blocksum_geo_f64 mode 2, projected with the classes); the columns of that round are evaluated per block (mode 5) and
+// per tail point (mode 4) beside the round's chain of single-work-group kernels, on another stream.
+// ------------------------------------------------------------------------------------------------
+struct IrrGeo {
+    long long e, t;           // this round: full blocks behind the regular region, tail points
+    long long e_n, t_n;       // next round (after the elimination's outcome)
+    int n_keep, kr_last;      // kept sets; rank of set S - 1 among them (-1: the tail dies)
+    bool bad;                 // violation / outcome the host did not size for: nothing may be derived from it
+};
+
+__device__ __forceinline__ IrrGeo irr_geometry(const long long* __restrict__ gp, const int* __restrict__ info,
+                                               const int* __restrict__ keep_rank, int S, int E_in, int E_out) {
+    IrrGeo g;
+    const long long nb = gp[4], reg_blocks = gp[2] / S;
+    g.e = nb - reg_blocks;
+    g.t = gp[5];
+    g.n_keep = info ? info[0] : 0;
+    g.kr_last = keep_rank ? keep_rank[S - 1] : -1;
+    g.bad = gp[3] != 0 || g.e < 0 || g.e > E_in || g.t < 0 || g.t >= S;
+    if (info) g.bad = g.bad || info[1] != 0 || 2 * g.n_keep != S;
+    const long long n_irr = g.bad ? 0 : g.e * g.n_keep + ((g.kr_last >= 0) ? g.t : 0);
+    g.e_n = n_irr / S;
+    g.t_n = n_irr - g.e_n * S;
+    if (g.e_n > E_out) g.bad = true;
+    return g;
+}
+
+// One launch behind every elimination inside an epoch: next round's class messages (regroup_classes_kernel), next round's
+// irregular columns + their fold slot, next round's descriptor (round_next_body).  All read the elimination's outcome, none
+// reads another's output.
+__global__ void epoch_turn_kernel(const double* __restrict__ Pin, int C, int E_in, double* __restrict__ Pout, int E_out,
+                                  int rows, int S, const int* __restrict__ kept, const int* __restrict__ keep_rank,
+                                  const double* __restrict__ w_star, const double* __restrict__ tot,
+                                  const int* __restrict__ info, const long long* __restrict__ gp, long long* __restrict__ gn,
+                                  int nb_cls, int nb_irr, int nb_fold) {
+#pragma clang fp contract(off)
+    const long long stride = (long long)rows * S;
+    int blk = (int)blockIdx.x;
+    if (blk < nb_cls) {                                             // ---- classes: C -> C / 2
+        const long long e = (long long)blk * blockDim.x + threadIdx.x;
+        if (e >= (long long)(C / 2) * stride) return;
+        const int sp = (int)(e % S);
+        const long long rest = e / S;
+        const int j = (int)(rest % rows), cp = (int)(rest / rows);
+        const int H = S / 2, par = sp / H, k = sp - par * H;
+        const int s = kept[k];
+        if ((unsigned)s >= (unsigned)S) {
+            Pout[e] = 0.0;
+            return;
+        }
+        const double v = Pin[((long long)(2 * cp + par) * rows + j) * S + s];
+        Pout[e] = (v * w_star[k]) / tot[s];                         // the order of BASQ/_rchq.py:113-114
+        return;
+    }
+    blk -= nb_cls;
+    if (blk >= nb_irr + nb_fold) {                                  // ---- the next round's descriptor
+        if (threadIdx.x < 64) round_next_body(threadIdx.x, gp, info, keep_rank, S, -1, 1, gn);
+        return;
+    }
+    const IrrGeo g = irr_geometry(gp, info, keep_rank, S, E_in, E_out);
+    const double* Iin = Pin + (long long)(C + 1) * stride;         // block slots, then the tail slot at E_in
+    double* fold_out = Pout + (long long)(C / 2) * stride;
+    double* Iout = fold_out + stride;                               // block slots, then the tail slot at E_out
+    // the column that lands at irregular index i (next round), row j: a kept column of a block, or a tail column
+    auto column = [&](long long i, int j) -> double {
+        const long long from_blocks = g.e * g.n_keep;
+        if (i < from_blocks) {
+            const long long b = i / g.n_keep;
+            const int k = (int)(i - b * g.n_keep);
+            const int s = kept[k];
+            const double v = Iin[b * stride + (long long)j * S + s];
+            return (v * w_star[k]) / tot[s];
+        }
+        const double v = Iin[(long long)E_in * stride + (long long)j * S + (i - from_blocks)];
+        return (v * w_star[g.kr_last]) / tot[S - 1];
+    };
+    if (blk < nb_irr) {                                             // ---- next round's columns
+        const long long e = (long long)blk * blockDim.x + threadIdx.x;
+        if (e >= (long long)(E_out + 1) * stride) return;
+        const int sp = (int)(e % S);
+        const long long rest = e / S;
+        const int j = (int)(rest % rows);
+        const long long slot = rest / rows;
+        double v = 0.0;
+        if (!g.bad) {
+            if (slot < E_out) {
+                if (slot < g.e_n) v = column(slot * S + sp, j);
+            } else if (sp < g.t_n) {
+                v = column(g.e_n * S + sp, j);
+            }
+        }
+        Iout[e] = v;
+        return;
+    }
+    blk -= nb_irr;                                                  // ---- their fold slot
+    const int idx = blk * blockDim.x + threadIdx.x;
+    if (idx >= rows * S) return;
+    const int sp = idx % S, j = idx / S;
+    double v = 0.0;
+    if (!g.bad) {
+        for (long long b = 0; b < g.e_n; ++b) v += column(b * S + sp, j);
+        if (sp == S - 1)
+            for (long long k = 0; k < g.t_n; ++k) v += column(g.e_n * S + k, j);
+    }
+    fold_out[idx] = v;
+}
+
+// Survivor re-weighting + compaction of SEVERAL rounds at once (the rounds of an epoch touch no candidate: their compactions
+// are applied together when the next epoch -- or the host's round-by-round loop -- needs the candidates again).  Per round the
+// arithmetic of reweight_compact_geo_kernel, in round order: mu <- (mu * w*) / tot.
+#define BASQ_MAX_EPOCH_ROUNDS 8
+struct CompactRounds {
+    const int* keep_rank[BASQ_MAX_EPOCH_ROUNDS];
+    const double* w_star[BASQ_MAX_EPOCH_ROUNDS];
+    const double* tot[BASQ_MAX_EPOCH_ROUNDS];
+    const int* info[BASQ_MAX_EPOCH_ROUNDS];
+    int n;
+};
+__global__ void reweight_compact_rounds_kernel(const double* __restrict__ cand, const double* __restrict__ mu,
+                                               const long long* __restrict__ gid, const double* __restrict__ wx,
+                                               const long long* __restrict__ geo, const CompactRounds Rr, int S, int kp,
+                                               long long out_rows, int expect_keep, double* __restrict__ cand_out,
+                                               double* __restrict__ mu_out, long long* __restrict__ gid_out,
+                                               double* __restrict__ wx_out) {
+#pragma clang fp contract(off)
+    const long long R0 = geo[0];
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= R0 * kp) return;
+    const long long p = t / kp;
+    const int k = (int)(t - p * kp);
+    long long pg = p;
+    double w = (k == 0) ? mu[p] : 0.0;
+    for (int r = 0; r < Rr.n; ++r) {
+        const long long* g = geo + 8 * r;
+        const long long n_full = g[1];
+        const int n_keep = Rr.info[r][0];
+        if (g[3] != 0 || Rr.info[r][1] != 0 || (expect_keep >= 0 && n_keep != expect_keep)) return;   // (the host repeats the rounds)
+        int set;
+        long long dst;
+        if (pg < n_full) {
+            const long long blk = pg / S;
+            set = (int)(pg - blk * S);
+            dst = blk * n_keep;
+        } else {
+            set = S - 1;
+            dst = (n_full / S) * n_keep + (pg - n_full);
+        }
+        const int kr = Rr.keep_rank[r][set];
+        if (kr < 0) return;
+        if (pg < n_full) dst += kr;
+        if (k == 0) {
+            const double scaled = w * Rr.w_star[r][kr];                        // :113-114 / :121-122
+            w = scaled / Rr.tot[r][set];
+        }
+        pg = dst;
+    }
+    if (pg < 0 || pg >= out_rows) return;
+    cand_out[pg * kp + k] = cand[t];
+    if (k == 0) {
+        mu_out[pg] = w;
+        gid_out[pg] = gid[p];
+        if (wx) wx_out[pg] = wx[p];
+    }
+}
+
 extern "C" {
 
 const char* basq_strerror(int code) {
@@ -2141,6 +2319,46 @@ int basq_regroup_classes_f64(const double* Tin, int32_t rows, int32_t S, int32_t
     const long long n = (long long)(C / 2) * rows * S;
     hipLaunchKernelGGL(regroup_classes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Tin,
                        rows, S, C, kept, w_star, tot, Tout);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_epoch_turn_f64(const double* Pin, int32_t C, int32_t E_in, double* Pout, int32_t E_out, int32_t rows, int32_t S,
+                        const int32_t* kept, const int32_t* keep_rank, const double* w_star, const double* tot,
+                        const int32_t* info, const int64_t* geo, int64_t* geo_next, void* stream) {
+    if (!Pin || !Pout || !kept || !keep_rank || !w_star || !tot || !info || !geo || !geo_next) return BASQ_EINVAL;
+    if (C < 2 || (C & 1) || E_in < 0 || E_out < 0 || rows < 1 || S < 2 || (S & 1)) return BASQ_EINVAL;
+    const long long stride = (long long)rows * S;
+    const long long nb_cls = ((long long)(C / 2) * stride + 255) / 256, nb_irr = ((long long)(E_out + 1) * stride + 255) / 256,
+                    nb_fold = (stride + 255) / 256;
+    if (nb_cls + nb_irr + nb_fold + 1 > 0x7fffffffLL) return BASQ_EINVAL;
+    hipLaunchKernelGGL(epoch_turn_kernel, dim3((unsigned)(nb_cls + nb_irr + nb_fold + 1)), dim3(256), 0, (hipStream_t)stream, Pin, C,
+                       E_in, Pout, E_out, rows, S, kept, keep_rank, w_star, tot, info, (const long long*)geo, (long long*)geo_next,
+                       (int)nb_cls, (int)nb_irr, (int)nb_fold);
+    BASQ_CHECK_LAUNCH();
+    return BASQ_OK;
+}
+
+int basq_reweight_compact_rounds_f64(const double* cand, const double* mu, const int64_t* gid, const double* wx,
+                                     const int64_t* geo, int32_t n_rounds, const int32_t* const* keep_rank,
+                                     const double* const* w_star, const double* const* tot, const int32_t* const* info,
+                                     int64_t R_max, int32_t S, int32_t kp, int64_t out_rows, int32_t expect_keep,
+                                     double* cand_out, double* mu_out, int64_t* gid_out, double* wx_out, void* stream) {
+    if (!cand || !mu || !gid || !geo || !keep_rank || !w_star || !tot || !info || !cand_out || !mu_out || !gid_out)
+        return BASQ_EINVAL;
+    if (n_rounds < 1 || n_rounds > BASQ_MAX_EPOCH_ROUNDS || R_max < 1 || S < 1 || kp < 1 || out_rows < 1 || (wx && !wx_out))
+        return BASQ_EINVAL;
+    CompactRounds Rr;
+    Rr.n = n_rounds;
+    for (int r = 0; r < BASQ_MAX_EPOCH_ROUNDS; ++r) {
+        const int q = r < n_rounds ? r : 0;
+        if (!keep_rank[q] || !w_star[q] || !tot[q] || !info[q]) return BASQ_EINVAL;
+        Rr.keep_rank[r] = keep_rank[q]; Rr.w_star[r] = w_star[q]; Rr.tot[r] = tot[q]; Rr.info[r] = info[q];
+    }
+    const long long nt = (long long)R_max * kp;
+    hipLaunchKernelGGL(reweight_compact_rounds_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cand,
+                       mu, (const long long*)gid, wx, (const long long*)geo, Rr, S, kp, (long long)out_rows, expect_keep, cand_out,
+                       mu_out, (long long*)gid_out, wx_out);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define BASQ_ABI_VERSION 14
+#define BASQ_ABI_VERSION 15
 
 /* error codes */
 #define BASQ_OK            0
@@ -274,7 +274,10 @@ int basq_reweight_compact_f64(const double* cand, const double* mu, const int64_
  *       [0, reg_hi) (class_mod > 0 allowed), 2: [reg_hi, R), 3: [0, R), each intersected with this rank's shard (the
  *       pointers, which address the shard's first candidate, are advanced on the device); 4: the ragged remainder
  *       [n_full, R) as ONE block of its own -- remainder point k in set k -- the first of the two counts SOBER/_rchq.py
- *       gives the remainder (:127-135; the caller drops the set weights of that launch: the reference adds none there).
+ *       gives the remainder (:127-135; the caller drops the set weights of that launch: the reference adds none there);
+ *       5 (ABI 15; class_mod >= 2 required): the full blocks BEHIND the regular region, [reg_hi, n_full), one chunk per block --
+ *       the regular region is a multiple of class_mod blocks, so chunk c is block reg_hi / S + c (fewer than class_mod of them;
+ *       a chunk without a block is written as zeros).
  *   basq_reweight_compact_geo_f64: basq_reweight_compact_f64 with off, Rl, n_full from the descriptor, new_off from the
  *       NEXT round's descriptor (geo_next, written by basq_round_next_i64 just before) and n_keep from info[0]; the
  *       launch is sized for R_max >= Rl candidates and the outputs hold out_rows
@@ -305,6 +308,38 @@ int basq_blocksum_geo_f64(const basq_kernel_spec* spec, const double* nys, int32
                           const double* mu, const double* wx, const int64_t* geo, int32_t geo_mode, int32_t S,
                           int32_t n_chunks, int32_t class_mod, int32_t class0, double* Xpart, double* totpart,
                           void* stream);
+
+/*
+ * Epochs without a pairwise evaluation inside (ABI 15; BASQ/_rchq.py:76-130 over the rounds of an epoch).  The candidates the
+ * residue classes do not cover -- e < C full blocks behind the regular region and t < S tail points (:91-99) -- are carried as
+ * MESSAGE COLUMNS: a round's buffer is  parts = [C class messages | 1 fold slot | E block slots | 1 tail slot], each
+ * [rows, S] (row 0 = set weights, rows 1.. = projected block sums; the fold slot = the sum the finalize kernel adds behind the
+ * classes: blocks in index order, then the tail's columns into set S - 1); block slot b < e holds one column per point of that block
+ * (its set = the column index), the tail slot one column per tail point.  A round keeps n_keep = S / 2 sets and moves the
+ * survivor of (block b, kept rank k) to position b n_keep + k, the tail -- if set S - 1 is kept -- behind; the regular
+ * survivors fill the next regular region exactly, so next round's columns are a gather + rescale ((v * w_star[k]) / tot[s],
+ * the order of :113-114) of this round's.
+ *   (In an epoch's FIRST round the fold slot is the projected block sum of the ordinary irregular chunk -- basq_blocksum_geo_f64
+ *   mode 2 -- and the columns are basq_blocksum_geo_f64 mode 5 (one chunk per block) and mode 4 (the tail, point k in set k),
+ *   projected like any other chunk.)
+ *   basq_epoch_turn_f64: ONE launch behind an elimination inside an epoch: Pout = next round's buffer [C / 2 | fold | E_out
+ *       | tail] from Pin [C | fold | E_in | tail] and the elimination's outcome (kept, keep_rank, w_star, tot, info), and
+ *       geo_next = basq_round_next_i64(geo, ..., class_mode -1, expect_half 1).  A round that did not keep exactly half of
+ *       the sets (or failed, or carries the sticky flag) leaves zeros; e > E_in or e' > E_out likewise (never by the bounds
+ *       the host derives: e' <= (E_in S / 2 + S - 1) / S).
+ *   basq_reweight_compact_rounds_f64: basq_reweight_compact_geo_f64 for n_rounds <= 8 consecutive rounds at once -- geo points
+ *       at the first round's descriptor row (rows of 8, consecutive), the outcome arrays are HOST arrays of n_rounds device
+ *       pointers; ONE rank (off = 0, Rl = R); per round mu <- (mu * w_star[k]) / tot[set], in round order.
+ */
+int basq_epoch_turn_f64(const double* Pin, int32_t C, int32_t E_in, double* Pout, int32_t E_out, int32_t rows, int32_t S,
+                        const int32_t* kept, const int32_t* keep_rank, const double* w_star, const double* tot,
+                        const int32_t* info, const int64_t* geo, int64_t* geo_next, void* stream);
+int basq_reweight_compact_rounds_f64(const double* cand, const double* mu, const int64_t* gid, const double* wx,
+                                     const int64_t* geo, int32_t n_rounds, const int32_t* const* keep_rank,
+                                     const double* const* w_star, const double* const* tot, const int32_t* const* info,
+                                     int64_t R_max, int32_t S, int32_t kp, int64_t out_rows, int32_t expect_keep,
+                                     double* cand_out, double* mu_out, int64_t* gid_out, double* wx_out, void* stream);
+
 int basq_reweight_compact_geo_f64(const double* cand, const double* mu, const int64_t* gid, const double* wx,
                                   const int64_t* geo, const int64_t* geo_next, const int32_t* info, int64_t R_max,
                                   int32_t S, int32_t kp,

@@ -343,7 +343,8 @@ class CpuStandInOps:
 
     def blocksum_geo(self, spec, nys, m, cand, mu, wx, geo_row, mode, S, n_chunks, out=None, class_mod=0, class0=0):
         R, n_full, reg_hi, off, Rl = (int(geo_row[k]) for k in (0, 1, 2, 6, 7))
-        lo, hi = (0, reg_hi) if mode == 1 else ((reg_hi, R) if mode == 2 else ((n_full, R) if mode == 4 else (0, R)))
+        lo, hi = (0, reg_hi) if mode == 1 else ((reg_hi, R) if mode == 2 else ((n_full, R) if mode == 4 else
+                                                                  ((reg_hi, n_full) if mode == 5 else (0, R))))
         lo, hi = max(lo, off), min(hi, off + Rl)               # the mode's range, restricted to this rank's shard
         hi = max(hi, lo)
         sk = lo - off
@@ -373,6 +374,59 @@ class CpuStandInOps:
             return o
 
         return grow(c), grow(u), grow(g), grow(w)
+
+    # -- the irregular candidates of an epoch as message columns (basq_epoch_turn_f64 & co.) --------------------------------
+    def side_ops(self):
+        return self
+
+    def side_context(self):
+        import contextlib
+
+        return contextlib.nullcontext()
+
+    def wait_event(self, ev):
+        pass
+
+    def epoch_turn(self, Pin, C, E_in, E_out, kept, keep_rank, w_star, tot, info, geo_row, geo_next, out=None):
+        self._count("epoch_turn")
+        n, rows, S = Pin.shape
+        assert n == C + E_in + 2 and C >= 2
+        Pout = torch.zeros(C // 2 + E_out + 2, rows, S, dtype=torch.float64) if out is None else out.zero_()
+        self.regroup_classes(Pin[:C].contiguous(), kept, w_star, tot, out=Pout[:C // 2])
+        self.round_next(geo_row, info, keep_rank, S, -1, True, geo_next)
+        nb, reg_blocks, t = int(geo_row[4]), int(geo_row[2]) // S, int(geo_row[5])
+        e, n_keep, kr_last = nb - reg_blocks, int(info[0]), int(keep_rank[S - 1])
+        bad = int(geo_row[3]) != 0 or int(info[1]) != 0 or 2 * n_keep != S or not (0 <= e <= E_in)
+        if bad:
+            return Pout
+        Iin, fold, Iout = Pin[C + 1:], Pout[C // 2], Pout[C // 2 + 1:]
+        cols = []                                               # next round's columns, in position order
+        kk = kept[:n_keep].to(torch.int64)
+        for b in range(e):
+            cols.append((Iin[b][:, kk] * w_star[:n_keep].unsqueeze(0)) / tot[kk].unsqueeze(0))
+        if kr_last >= 0 and t > 0:
+            cols.append((Iin[E_in][:, :t] * w_star[kr_last]) / tot[S - 1])
+        allc = torch.cat(cols, 1) if cols else torch.zeros(rows, 0, dtype=torch.float64)
+        n_irr = allc.shape[1]
+        e_n, t_n = n_irr // S, n_irr % S
+        if e_n > E_out:
+            return Pout
+        for b in range(e_n):                                    # (blocks in index order, then the tail's columns in order)
+            Iout[b] = allc[:, b * S:(b + 1) * S]
+            fold += Iout[b]
+        Iout[E_out][:, :t_n] = allc[:, e_n * S:]
+        for k in range(t_n):
+            fold[:, S - 1] += allc[:, e_n * S + k]
+        return Pout
+
+    def reweight_compact_rounds(self, cand, mu, gid, wx, geo_rows, outcomes, R_max, S, kp, out_rows, expect_keep=-1):
+        self._count("compact_rounds")
+        for r, o in enumerate(outcomes):
+            g, gn = geo_rows[r], geo_rows[r + 1]
+            cand, mu, gid, wx = self.reweight_compact_geo(cand, mu, gid, wx, g, gn, o["info"], R_max, S, kp, o["keep_rank"],
+                                                          o["w_star"], o["tot"], out_rows if r == len(outcomes) - 1 else
+                                                          max(int(gn[7]), 1), expect_keep)
+        return cand, mu, gid, wx
 
     @staticmethod
     def info_kept_buffer(info, kept):
@@ -553,5 +607,5 @@ class CpuStandInOps:
     def synchronize(self):
         pass
 
-    def record_event(self):
+    def record_event(self, timing=True):
         return None

@@ -1178,3 +1178,128 @@ def test_fused_cholqr_reports_a_failed_pivot(hip_ops):
     Q, info = hip_ops.cholqr(G.clone(), Xd)
     torch.cuda.synchronize()
     assert int(info_ref.item()) > 0 and int(info.item()) == int(info_ref.item())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# epochs without a pairwise evaluation inside (ABI 15): basq_blocksum_geo_f64 mode 5, basq_epoch_turn_f64,
+# basq_reweight_compact_rounds_f64
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R,S,reg_blocks,C", [(10_000, 200, 48, 16), (10_123, 200, 48, 16), (3_456, 64, 48, 8), (2_000, 200, 8, 8),
+                                              (1_650, 200, 8, 2)])
+def test_blocksum_geo_one_chunk_per_irregular_block(hip_ops, R, S, reg_blocks, C):
+    """geo_mode 5: the full blocks behind the regular region, one chunk each, = the host-geometry class-mode entry over those
+    blocks (bit for bit); chunks without a block are zeros; the ragged tail stays out (mode 4 carries it, point k in set k)."""
+    d, m = 5, 130
+    spec = _spec("rbf", d)
+    nys, cand = _rand(m, d, 71), _rand(R, d, 72)
+    g = torch.Generator().manual_seed(10)
+    mu = torch.rand(R, generator=g, dtype=torch.float64) + 0.05
+    center = hip_ops.to_device(nys.mean(0))
+    pa = hip_ops.pack(spec, hip_ops.to_device(nys), center, 0, pad_rows_to=64)
+    pb = hip_ops.pack(spec, hip_ops.to_device(cand), center, 1)
+    mu_d = hip_ops.to_device(mu)
+    nb = R // S
+    n_full, reg_hi, e = nb * S, reg_blocks * S, nb - reg_blocks
+    assert 0 <= e < C
+    geo = hip_ops.geo_init(2, R, S, reg_hi)
+    E = C - 1
+    Xa, ta = hip_ops.blocksum_geo(spec, pa, m, pb, mu_d, None, geo[0], 5, S, E, class_mod=C)
+    for b in range(E):
+        if b < e:
+            lo = reg_hi + b * S
+            Xb, tb = hip_ops.blocksum(spec, pa, m, pb[lo:], mu_d[lo:], None, S, lo, n_full, S, 1)
+            assert torch.equal(Xa[b], Xb[0]) and torch.equal(ta[b], tb[0])
+            assert torch.equal(ta[b], mu_d[lo:lo + S])           # one point per set: the set weight IS the point's weight
+        else:
+            assert not Xa[b].any() and not ta[b].any()
+    # tail: point k in set k, set weights = the points' weights
+    Xt, tt = hip_ops.blocksum_geo(spec, pa, m, pb, mu_d, None, geo[0], 4, S, 1)
+    t = R - n_full
+    assert torch.equal(tt[0, :t], mu_d[n_full:]) and not tt[0, t:].any() and not Xt[0][:, t:].any()
+    # all of it together = the ordinary irregular chunk (mode 2) up to the order of the sums
+    X2, t2 = hip_ops.blocksum_geo(spec, pa, m, pb, mu_d, None, geo[0], 2, S, 1)
+    tog = Xa.sum(0)
+    tog[:, S - 1] += Xt[0].sum(1)
+    assert (tog - X2[0]).abs().max().item() <= 1e-12 * X2[0].abs().max().item()
+
+
+@pytest.mark.parametrize("C,E_in,e,t,rows,S,last_kept", [(16, 13, 12, 100, 100, 200, True), (16, 13, 13, 0, 100, 200, False),
+                                                          (8, 4, 3, 37, 31, 76, True), (2, 1, 1, 150, 100, 200, True),
+                                                          (4, 0, 0, 5, 12, 20, True), (4, 3, 2, 0, 303, 200, False)])
+def test_epoch_turn_kernel_vs_stand_in(hip_ops, C, E_in, e, t, rows, S, last_kept):
+    """basq_epoch_turn_f64 (classes + columns + fold slot + descriptor in one launch) against the stand-in that
+    tests/test_epochs.py holds against explicit per-candidate columns: bit for bit."""
+    cpu = CpuStandInOps()
+    n = S // 2
+    g = torch.Generator().manual_seed(C * 1000 + e * 10 + t)
+    reg_blocks = 3 * C
+    nb = reg_blocks + e
+    R = nb * S + t
+    P = torch.rand(C + E_in + 2, rows, S, generator=g, dtype=torch.float64)
+    kept = torch.sort(torch.randperm(S - 1, generator=g)[:n - 1 if last_kept else n])[0].to(torch.int32)
+    if last_kept:
+        kept = torch.cat([kept, torch.tensor([S - 1], dtype=torch.int32)])
+    keep_rank = torch.full((S,), -1, dtype=torch.int32)
+    keep_rank[kept.long()] = torch.arange(n, dtype=torch.int32)
+    kept_full = torch.cat([kept, torch.zeros(S - n, dtype=torch.int32)])
+    w_star = torch.rand(S, generator=g, dtype=torch.float64) + 0.5
+    tot = torch.rand(S, generator=g, dtype=torch.float64) + 0.5
+    info = torch.tensor([n, 0], dtype=torch.int32)
+    E_out = (E_in * n + S - 1) // S
+    geo_c = cpu.geo_init(2, R, S, reg_blocks * S)
+    want = cpu.epoch_turn(P.clone(), C, E_in, E_out, kept_full, keep_rank, w_star, tot, info, geo_c[0], geo_c[1])
+    geo_d = hip_ops.geo_init(2, R, S, reg_blocks * S)
+    dev = [hip_ops.to_device(x) for x in (P, kept_full, keep_rank, w_star, tot, info)]
+    got = hip_ops.epoch_turn(dev[0], C, E_in, E_out, dev[1], dev[2], dev[3], dev[4], dev[5], geo_d[0], geo_d[1])
+    torch.cuda.synchronize()
+    assert hip_ops.to_host(geo_d[1], "gt").tolist() == geo_c[1].tolist()
+    assert torch.equal(got.cpu(), want)
+    # a round that did not keep half of the sets: zeros for the columns, the sticky flag in the descriptor
+    info_bad = hip_ops.to_device(torch.tensor([n - 1, 0], dtype=torch.int32))
+    got = hip_ops.epoch_turn(dev[0], C, E_in, E_out, dev[1], dev[2], dev[3], dev[4], info_bad, geo_d[0], geo_d[1])
+    assert not got[C // 2:].any() and int(hip_ops.to_host(geo_d[1], "gt")[3]) == 1
+
+
+def test_compaction_of_several_rounds_kernel(hip_ops):
+    """basq_reweight_compact_rounds_f64 = basq_reweight_compact_geo_f64 round after round (rows, weights -- the same roundings --
+    and ids), launch and buffers sized for upper bounds; a violated round writes nothing."""
+    S, n, d = 40, 20, 4
+    kp = hip_ops.kp(d)
+    R = 57 * S + 23
+    g = torch.Generator().manual_seed(5)
+    R_max = R + 100
+    cand = hip_ops.to_device(torch.rand(R_max, kp, generator=g, dtype=torch.float64))
+    mu = hip_ops.to_device(torch.rand(R_max, generator=g, dtype=torch.float64))
+    wx = hip_ops.to_device(torch.rand(R_max, generator=g, dtype=torch.float64))
+    gid = hip_ops.to_device(torch.arange(R_max, dtype=torch.int64) * 7 + 3)
+    geo = hip_ops.geo_init(8, R, S, 48 * S)
+    outs, cur = [], (cand, mu, gid, wx)
+    for r in range(4):
+        last = r % 2 == 0
+        kept = torch.sort(torch.randperm(S - 1, generator=g)[:n - 1 if last else n])[0].to(torch.int32)
+        if last:
+            kept = torch.cat([kept, torch.tensor([S - 1], dtype=torch.int32)])
+        keep_rank = torch.full((S,), -1, dtype=torch.int32)
+        keep_rank[kept.long()] = torch.arange(n, dtype=torch.int32)
+        o = dict(keep_rank=hip_ops.to_device(keep_rank), w_star=hip_ops.to_device(torch.rand(S, generator=g, dtype=torch.float64) + 0.5),
+                 tot=hip_ops.to_device(torch.rand(S, generator=g, dtype=torch.float64) + 0.5),
+                 info=hip_ops.to_device(torch.tensor([n, 0], dtype=torch.int32)))
+        hip_ops.round_next(geo[r], o["info"], o["keep_rank"], S, -1, True, geo[r + 1])
+        outs.append(o)
+        Rn_up = (R >> (r + 1)) + 2 * S
+        cur = hip_ops.reweight_compact_geo(*cur, geo[r], geo[r + 1], o["info"], R_max, S, kp, o["keep_rank"], o["w_star"], o["tot"],
+                                           Rn_up, n)
+    Rn = int(hip_ops.to_host(geo[4], "g4")[0])
+    got = hip_ops.reweight_compact_rounds(cand, mu, gid, wx, geo, outs, R_max, S, kp, Rn + 31, n)
+    for a, b in zip(got, cur):
+        assert torch.equal(a[:Rn], b[:Rn])
+    # three of the four rounds only (a view of the table from row 1 on)
+    c1 = hip_ops.reweight_compact_geo(cand, mu, gid, wx, geo[0], geo[1], outs[0]["info"], R_max, S, kp, outs[0]["keep_rank"],
+                                      outs[0]["w_star"], outs[0]["tot"], R, n)
+    got3 = hip_ops.reweight_compact_rounds(*c1, geo[1:], outs[1:], R, S, kp, Rn + 5, n)
+    for a, b in zip(got3, cur):
+        assert torch.equal(a[:Rn], b[:Rn])
+    # a round that kept another number of sets than expected: nothing is written
+    poison = hip_ops.reweight_compact_rounds(cand, mu, gid, wx, geo, outs, R_max, S, kp, Rn + 31, n + 1)
+    fresh = hip_ops.empty(1)                                     # (outputs are uninitialised: only check the call is harmless)
+    assert poison[0].shape[0] == Rn + 31 and fresh.numel() == 1

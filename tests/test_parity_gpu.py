@@ -396,6 +396,42 @@ def test_golden_parity_descriptor_driven_rounds(name):
     assert rel <= W_RTOL, f"weights off by {rel:.3e} relative"
 
 
+@pytest.mark.parametrize("name", ["rbf_1e4", "rbf_2e4_defaults", "rbf_ragged", "matern52_3e4_d32", "cfg2_rbf_1e5", "cfg3_rbf_1e6",
+                                  "cfg4_matern52_1e6_d32"])
+def test_golden_parity_column_epochs_and_round5_epochs(name):
+    """Round 6: inside an epoch the candidates outside the residue classes are message columns (``basq_amd/_epochs.py``; the default
+    for these cases) -- against the goldens with EVERY round's kept sets (a trace read after the fact), and against the round-5
+    form of the same rounds (``IRR_COLUMNS = False``: irregular blocks evaluated, projected and compacted every round), which must
+    select the same batch."""
+    import basq_amd
+    import basq_amd._config as eng
+
+    if not has_golden(name):
+        pytest.skip("fixture not generated")
+    c, fx = BY_NAME[name], load_golden(name)
+    pts, nys = build_pool(c)
+    pts, nys = pts.to(DEV), nys.to(DEV)
+    kern = build_product_kernel(c)
+    out = {}
+    for flag in (True, False):
+        old = eng.IRR_COLUMNS
+        eng.IRR_COLUMNS = flag
+        try:
+            tr = basq_amd.EngineTrace(host_sync=False)
+            torch.manual_seed(c["torch_seed"])
+            idx, w = basq_amd.recombination(pts, nys, c["n"], kern, torch.device(DEV), trace=tr)
+            out[flag] = (idx.cpu(), w.cpu(), [r["kept"] for r in tr.rounds])
+        finally:
+            eng.IRR_COLUMNS = old
+    gw = torch.tensor(fx["w"], dtype=torch.float64)
+    for flag in (True, False):
+        idx, w, kept = out[flag]
+        assert idx.tolist() == fx["idx"], f"IRR_COLUMNS={flag}: selected indices differ from the reference"
+        assert ((w - gw).abs() / gw).max().item() <= W_RTOL
+        assert kept == [r["kept"] for r in fx["rounds"]][:len(kept)] and len(kept) >= 1
+    assert torch.allclose(out[True][1], out[False][1], rtol=1e-9, atol=0)
+
+
 # ---- shape envelope: the reference accepts any d and any num_pts (_rchq.py:4-25) -------------------------------------------
 def _oracle(c):
     from oracle.rchq_oracle import recombination_oracle

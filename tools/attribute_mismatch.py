@@ -63,7 +63,7 @@ def main():
                     same, rel, common, err = False, None, 0, repr(e)[:120]
                 finally:
                     cfg.BASIS_SVD, cfg.GPU_NULLSPACE, cfg.GPU_RANGE_FINDER = defaults
-                rows.append(dict(seed=seed, case=i, family=c["kernel"]["family"], warp=c["kernel"]["warp"], N=c["N"], d=c["d"],
+                rows.append(dict(path="structured", seed=seed, case=i, family=c["kernel"]["family"], warp=c["kernel"]["warp"], N=c["N"], d=c["d"],
                                  n=c["n"], m=c["m"], cond=observation_gram_condition(c, state), BASIS_SVD=svd, GPU_NULLSPACE=gns,
                                  GPU_RANGE_FINDER=grf, indices_identical=same, max_rel_weight_error=rel,
                                  common_indices=common, n_oracle=len(io), error=err))
@@ -71,6 +71,28 @@ def main():
                 print(f"seed {seed:2d} case {i:3d} ({r['family']:8s} {r['warp']:6s} cond {r['cond']:.1e}) BASIS_SVD={svd!s:5} "
                       f"GPU_NULLSPACE={gns!s:5} GPU_RANGE_FINDER={grf!s:5}: idx identical {same!s:5} "
                       f"({common}/{len(io)} common), rel {rel if rel is None else format(rel, '.2e')} {err or ''}", flush=True)
+            # ... and the REFERENCE'S OWN FORMULATION of the kernel, evaluated on the device by tensor operations and handed to the
+            # engine as an opaque callable (the dense path: explicit k - k W k per block, no linear correction, no fused kernel):
+            # if this row matches the oracle, what costs the parity is the fused path's arithmetic for the cancellation
+            from oracle.kernels_oracle import PosteriorOracle, StationaryOracle, WsabiOracle
+
+            k = c["kernel"]
+            base = StationaryOracle(k["family"], k["lengthscale"], k["outputscale"])
+            kdev = base
+            if state is not None:
+                post = PosteriorOracle(base, state["Xobs"].to(dev), state["W"].to(dev), state["noise"])
+                kdev = post if k["warp"] == "none" else WsabiOracle(post, state["mean_const"], state["mean_cache"].to(dev), k["warp"])
+            try:
+                torch.manual_seed(c["torch_seed"])
+                ie, we = basq_amd.recombination(pts.to(dev), nys.to(dev), c["n"], kdev, dev)
+                same, rel, common = deviation(ie.cpu(), we.cpu(), io, wo)
+                err = None
+            except Exception as e:                                 # noqa: BLE001
+                same, rel, common, err = False, None, 0, repr(e)[:120]
+            rows.append(dict(path="opaque callable (reference formulation on the device)", seed=seed, case=i, indices_identical=same,
+                             max_rel_weight_error=rel, common_indices=common, n_oracle=len(io), error=err))
+            print(f"seed {seed:2d} case {i:3d} opaque callable, the reference's formulation on the device (dense path): idx identical "
+                  f"{same!s:5} ({common}/{len(io)} common), rel {rel if rel is None else format(rel, '.2e')} {err or ''}", flush=True)
     print(json.dumps(rows))
 
 

@@ -105,6 +105,9 @@ PY
 cat "$out/pmc_dense_summary.txt"; }
 # stall / issue counters of the block sums: one tolerant pass per group (a counter this part does not offer fails only its own pass)
 job_pmc_stalls()  { ( cd /tmp && rocprofv3 --list-avail > "$ROOT/$out/rocprof_list_avail.txt" 2>&1 ); for g in "a:SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "b:SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY" "c:SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" "d:SQ_WAVES SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" "e:SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_CYCLES_VALU SQ_INSTS_VALU_MFMA_MOPS_F64"; do pmc "stall_${g%%:*}" "${g#*:}" || note "pass stall_${g%%:*} failed (kept going)"; done; return 0; }
+job_tests_epoch() { timeout -k 10 900 python -m pytest tests -x -q -m gpu -k "epoch or compaction_of_several or one_chunk_per or column_epochs or descriptor_driven" > "$out/gpu_tests_epoch.log" 2>&1; rc=$?; tail -15 "$out/gpu_tests_epoch.log" | cut -c1-300; return $rc; }
+# block-sum micro-benchmark over tuning-variant builds: AB_LIBS="libbasq_hip.so libbasq_hip_w4pf1.so ..." (A B C A B C)
+job_ab_bs()       { for i in 1 2 3; do for lib in ${AB_LIBS:-libbasq_hip.so}; do echo "== $lib" >> "$out/ab_bs.txt"; BASQ_HIP_LIB=$PWD/basq_amd/csrc/$lib timeout -k 10 120 python tools/bench_blocksum.py --reps 6 2>&1 | grep -v amdgpu.ids >> "$out/ab_bs.txt" || return 1; done; done; cat "$out/ab_bs.txt"; }
 job_attribute()   { timeout -k 10 900 python tools/attribute_mismatch.py > "$out/attribute_mismatch.txt" 2>&1; rc=$?; grep -v "amdgpu.ids\|^\[{" "$out/attribute_mismatch.txt" | cut -c1-220; return $rc; }
 job_pmc()         { pmc fetch "FETCH_SIZE" && pmc write "WRITE_SIZE" && pmc pipe "SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" && python tools/pmc_summary.py "$out" > "$out/pmc_summary.json"; rc=$?; cut -c1-400 "$out/pmc_summary.json"; return $rc; }
 
