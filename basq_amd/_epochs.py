@@ -19,6 +19,8 @@ else keeps ``Batch._async_rounds``.
 """
 from __future__ import annotations
 
+import contextlib
+
 import torch
 
 from . import _config as cfg
@@ -94,17 +96,21 @@ def async_rounds_columns(b, pre):
                 # classes + the ordinary irregular chunk, whose message IS the fold slot of this round
                 ops.project_chunks(U_ext, q_ext, m_ext, Xpart, totpart, C_cur + 1, S, kscale, out=P[:C_cur + 1])
                 # ... and the columns the NEXT rounds of the epoch regroup, beside this round's chain (side stream)
-                side = ops.side_ops()
-                side.wait_event(ops.record_event(False))
-                with ops.side_context():
+                # (with other batches in flight there is no idle chip to fill, and a stream shared between the batches only ties
+                #  them together: the same launches go to the batch's own stream then -- same arithmetic, same bits)
+                side = ops if b.pipelined else ops.side_ops()
+                if side is not ops:
+                    side.wait_event(ops.record_event(False))
+                with (contextlib.nullcontext() if side is ops else ops.side_context()):
                     Xirr, totirr = side.empty(E_cur + 1, m_ext, S), side.empty(E_cur + 1, S)
                     if E_cur > 0:
                         side.blocksum_geo(spec, nys_ext, m_ext, cand, mu, wx, g_row, 5, S, E_cur, out=(Xirr[:E_cur], totirr[:E_cur]),
                                           class_mod=C_cur)
                     side.blocksum_geo(spec, nys_ext, m_ext, cand, mu, wx, g_row, 4, S, 1, out=(Xirr[E_cur:], totirr[E_cur:]))
                     side.project_chunks(U_ext, q_ext, m_ext, Xirr, totirr, E_cur + 1, S, kscale, out=P[C_cur + 1:])
-                    side_ev = side.record_event(False)
-                    side_keep = (Xirr, totirr)
+                    if side is not ops:
+                        side_ev = side.record_event(False)
+                        side_keep = (Xirr, totirr)
                 parts = P[:C_cur + 1]
             else:
                 parts = ops.project(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S, kscale).unsqueeze(0)

@@ -2131,16 +2131,36 @@ __global__ void epoch_turn_kernel(const double* __restrict__ Pin, int C, int E_i
         return;
     }
     blk -= nb_irr;                                                  // ---- their fold slot
-    const int idx = blk * blockDim.x + threadIdx.x;
-    if (idx >= rows * S) return;
-    const int sp = idx % S, j = idx / S;
-    double v = 0.0;
-    if (!g.bad) {
-        for (long long b = 0; b < g.e_n; ++b) v += column(b * S + sp, j);
-        if (sp == S - 1)
-            for (long long k = 0; k < g.t_n; ++k) v += column(g.e_n * S + k, j);
+    const int n_plain = (rows * S + (int)blockDim.x - 1) / (int)blockDim.x;
+    if (blk < n_plain) {                                            // every entry but column S - 1: the blocks, in index order
+        const int idx = blk * blockDim.x + threadIdx.x;
+        if (idx >= rows * S) return;
+        const int sp = idx % S, j = idx / S;
+        if (sp == S - 1) return;
+        double v = 0.0;
+        if (!g.bad)
+            for (long long b = 0; b < g.e_n; ++b) v += column(b * S + sp, j);
+        fold_out[idx] = v;
+        return;
     }
-    fold_out[idx] = v;
+    // column S - 1 (BASQ/_rchq.py:91-99: the ragged tail belongs to the last set): one WAVE per row -- up to S - 1 tail columns
+    // go into this one entry, and a single lane walking them was the launch's duration (33 us for 100 columns).  Fixed order:
+    // lane l adds its columns k = l, l + 64, ... in that order, the 64 partial sums meet in an xor butterfly (offsets 32 .. 1;
+    // the same bits in every lane), and the total is added behind the blocks' sum.
+    const int lane = threadIdx.x & 63;
+    const int j = (blk - n_plain) * ((int)blockDim.x >> 6) + ((int)threadIdx.x >> 6);
+    if (j >= rows) return;
+    double part = 0.0;
+    if (!g.bad)
+        for (long long k = lane; k < g.t_n; k += 64) part += column(g.e_n * S + k, j);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o, 64);
+    if (lane == 0) {
+        double v = 0.0;
+        if (!g.bad)
+            for (long long b = 0; b < g.e_n; ++b) v += column(b * S + (S - 1), j);
+        fold_out[(long long)j * S + (S - 1)] = v + part;
+    }
 }
 
 // Survivor re-weighting + compaction of SEVERAL rounds at once (the rounds of an epoch touch no candidate: their compactions
@@ -2154,25 +2174,25 @@ struct CompactRounds {
     const int* info[BASQ_MAX_EPOCH_ROUNDS];
     int n;
 };
-__global__ void reweight_compact_rounds_kernel(const double* __restrict__ cand, const double* __restrict__ mu,
-                                               const long long* __restrict__ gid, const double* __restrict__ wx,
-                                               const long long* __restrict__ geo, const CompactRounds Rr, int S, int kp,
-                                               long long out_rows, int expect_keep, double* __restrict__ cand_out,
-                                               double* __restrict__ mu_out, long long* __restrict__ gid_out,
-                                               double* __restrict__ wx_out) {
+__global__ void __launch_bounds__(256) reweight_compact_rounds_kernel(
+    const double* __restrict__ cand, const double* __restrict__ mu, const long long* __restrict__ gid,
+    const double* __restrict__ wx, const long long* __restrict__ geo, const CompactRounds Rr, int S, int kp, long long out_rows,
+    int expect_keep, double* __restrict__ cand_out, double* __restrict__ mu_out, long long* __restrict__ gid_out,
+    double* __restrict__ wx_out) {
 #pragma clang fp contract(off)
+    // ONE lane per candidate walks the rounds (a few table look-ups each; all but 2^-rounds of the candidates drop out on the
+    // way); the survivors of a wave -- two of 64 after five rounds -- then have their packed rows copied by the whole wave.
     const long long R0 = geo[0];
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= R0 * kp) return;
-    const long long p = t / kp;
-    const int k = (int)(t - p * kp);
-    long long pg = p;
-    double w = (k == 0) ? mu[p] : 0.0;
+    const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    long long pg = (p < R0) ? p : -1;
+    double w = (pg >= 0) ? mu[p] : 0.0;
     for (int r = 0; r < Rr.n; ++r) {
         const long long* g = geo + 8 * r;
         const long long n_full = g[1];
         const int n_keep = Rr.info[r][0];
-        if (g[3] != 0 || Rr.info[r][1] != 0 || (expect_keep >= 0 && n_keep != expect_keep)) return;   // (the host repeats the rounds)
+        if (g[3] != 0 || Rr.info[r][1] != 0 || (expect_keep >= 0 && n_keep != expect_keep)) return;   // uniform: the host repeats the rounds
+        if (pg < 0) continue;
         int set;
         long long dst;
         if (pg < n_full) {
@@ -2184,20 +2204,28 @@ __global__ void reweight_compact_rounds_kernel(const double* __restrict__ cand, 
             dst = (n_full / S) * n_keep + (pg - n_full);
         }
         const int kr = Rr.keep_rank[r][set];
-        if (kr < 0) return;
-        if (pg < n_full) dst += kr;
-        if (k == 0) {
-            const double scaled = w * Rr.w_star[r][kr];                        // :113-114 / :121-122
-            w = scaled / Rr.tot[r][set];
+        if (kr < 0) {
+            pg = -1;
+            continue;
         }
+        if (pg < n_full) dst += kr;
+        const double scaled = w * Rr.w_star[r][kr];                            // :113-114 / :121-122
+        w = scaled / Rr.tot[r][set];
         pg = dst;
     }
-    if (pg < 0 || pg >= out_rows) return;
-    cand_out[pg * kp + k] = cand[t];
-    if (k == 0) {
+    if (pg >= out_rows) pg = -1;                                               // never outside the caller's buffers
+    if (pg >= 0) {
         mu_out[pg] = w;
         gid_out[pg] = gid[p];
         if (wx) wx_out[pg] = wx[p];
+    }
+    unsigned long long alive = __ballot(pg >= 0);
+    while (alive) {
+        const int src_lane = (int)__builtin_ctzll(alive);
+        alive &= alive - 1;
+        const long long dst = __shfl(pg, src_lane, 64);
+        const long long src = p - lane + src_lane;
+        for (int k = lane; k < kp; k += 64) cand_out[dst * kp + k] = cand[src * kp + k];
     }
 }
 
@@ -2330,7 +2358,7 @@ int basq_epoch_turn_f64(const double* Pin, int32_t C, int32_t E_in, double* Pout
     if (C < 2 || (C & 1) || E_in < 0 || E_out < 0 || rows < 1 || S < 2 || (S & 1)) return BASQ_EINVAL;
     const long long stride = (long long)rows * S;
     const long long nb_cls = ((long long)(C / 2) * stride + 255) / 256, nb_irr = ((long long)(E_out + 1) * stride + 255) / 256,
-                    nb_fold = (stride + 255) / 256;
+                    nb_fold = (stride + 255) / 256 + (rows + 3) / 4;       // + one wave per row for column S - 1
     if (nb_cls + nb_irr + nb_fold + 1 > 0x7fffffffLL) return BASQ_EINVAL;
     hipLaunchKernelGGL(epoch_turn_kernel, dim3((unsigned)(nb_cls + nb_irr + nb_fold + 1)), dim3(256), 0, (hipStream_t)stream, Pin, C,
                        E_in, Pout, E_out, rows, S, kept, keep_rank, w_star, tot, info, (const long long*)geo, (long long*)geo_next,
@@ -2355,7 +2383,7 @@ int basq_reweight_compact_rounds_f64(const double* cand, const double* mu, const
         if (!keep_rank[q] || !w_star[q] || !tot[q] || !info[q]) return BASQ_EINVAL;
         Rr.keep_rank[r] = keep_rank[q]; Rr.w_star[r] = w_star[q]; Rr.tot[r] = tot[q]; Rr.info[r] = info[q];
     }
-    const long long nt = (long long)R_max * kp;
+    const long long nt = (long long)R_max;                      // one lane per candidate
     hipLaunchKernelGGL(reweight_compact_rounds_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, (hipStream_t)stream, cand,
                        mu, (const long long*)gid, wx, (const long long*)geo, Rr, S, kp, (long long)out_rows, expect_keep, cand_out,
                        mu_out, (long long*)gid_out, wx_out);

@@ -411,12 +411,19 @@ class CpuStandInOps:
         e_n, t_n = n_irr // S, n_irr % S
         if e_n > E_out:
             return Pout
-        for b in range(e_n):                                    # (blocks in index order, then the tail's columns in order)
+        for b in range(e_n):                                    # the blocks in index order ...
             Iout[b] = allc[:, b * S:(b + 1) * S]
             fold += Iout[b]
         Iout[E_out][:, :t_n] = allc[:, e_n * S:]
+        # ... then the tail's columns into set S - 1, in the kernel's order: lane l of a wave adds columns l, l + 64, ..., the 64
+        # partial sums meet in an xor butterfly (offsets 32 .. 1), the total is added behind the blocks' sum
+        part = torch.zeros(rows, 64, dtype=torch.float64)
         for k in range(t_n):
-            fold[:, S - 1] += allc[:, e_n * S + k]
+            part[:, k % 64] += allc[:, e_n * S + k]
+        lanes = torch.arange(64)
+        for o in (32, 16, 8, 4, 2, 1):
+            part = part + part[:, lanes ^ o]
+        fold[:, S - 1] += part[:, 0]
         return Pout
 
     def reweight_compact_rounds(self, cand, mu, gid, wx, geo_rows, outcomes, R_max, S, kp, out_rows, expect_keep=-1):
