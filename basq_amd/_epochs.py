@@ -14,8 +14,9 @@ What the columns cost -- one block-sum chunk and one projection per irregular bl
 BESIDE the epoch's first chain, on the device's side stream: that chain keeps one compute unit busy for ~0.4 ms and needs none
 of it; the launch stream waits for the side stream only before the first ``epoch_turn``.
 
-Scope: one rank, BASQ variant, stationary / posterior / WSABI-L kernels without a likelihood-noise diagonal term.  Everything
-else keeps ``Batch._async_rounds``.
+Scope: one rank, BASQ variant, stationary / posterior / WSABI-L kernels (``predictive_covariance``'s likelihood noise on the
+block diagonals included: the tail block's per-point weights, which that term needs, are a row of the tail slot).  WSABI-M, the
+SOBER variant and several ranks keep ``Batch._async_rounds``.
 """
 from __future__ import annotations
 
@@ -31,7 +32,7 @@ def eligible(b) -> bool:
     """Can batch ``b`` (operands prepared) take the column form of the descriptor-driven rounds?"""
     plan = b.plan
     return bool(cfg.IRR_COLUMNS and plan.async_rounds and plan.classes and b.comm.world == 1 and b.owner is None
-                and not plan.sober and plan.warp != "wsabim" and b.diag_noise == 0.0 and hasattr(b.ops, "epoch_turn"))
+                and not plan.sober and plan.warp != "wsabim" and hasattr(b.ops, "epoch_turn"))
 
 
 def block_capacity(R_lo: int, R_up: int, S: int, C: int) -> int:
@@ -68,7 +69,8 @@ def async_rounds_columns(b, pre):
 
     while R_lo > S:
         g_row = geo_t[r]
-        if P is None:
+        fresh = P is None
+        if fresh:
             # ---- a fresh evaluation: the start of an epoch (C >= 2), or a round without classes
             flush(R_up)
             pend_r0, pend_R = r, R_up
@@ -117,9 +119,22 @@ def async_rounds_columns(b, pre):
             del Xpart, totpart
         else:
             parts = P[:C_cur + 1]
+        if b.diag_noise != 0.0:
+            # predictive_covariance's noise on the ragged tail block (BASQ/_gp.py:275-276: entries [k][k], tail point k x Nystrom
+            # row k): one more message row carries the tail points' weights -- from the candidates where the round evaluated
+            # them, from the tail slot's columns (set weight of a one-point set; the kernel-weighted one for WSABI-L) inside an epoch
+            buf = ops.empty(1, rows + 1, S)
+            ops.sum_parts(parts, out=buf[0, :rows])
+            if fresh:
+                ops.tail_weights_geo(mu, wx, g_row, S, buf[0, rows])
+            else:
+                buf[0, rows].copy_(P[C_cur + 1 + E_cur][b.wrow])
+            fin = (buf, 1, rows + 1, q, S, b.diagU, b.m, min(b.m, S), b.diag_noise, b.wrow, rows, min(b.m, S), g_row)
+        else:
+            fin = (parts, parts.shape[0], rows, q, S, None, b.m, min(b.m, S), 0.0, 0, 0, 0, None)
         # ---- the round's chain of single-work-group kernels
         ev_c = ops.record_event() if b.sums._timing() else None
-        XcarT, tot = ops.finalize(parts, parts.shape[0], parts.shape[1], q, S, None, b.m, min(b.m, S), 0.0, 0, 0, 0, None)
+        XcarT, tot = ops.finalize(*fin)
         PhiT = ops.nullspace(XcarT, s, S)
         keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, tot, S, s)
         if ev_c is not None:

@@ -9,7 +9,9 @@ from tests.cases import BY_NAME, build_pool, build_product_kernel, has_golden, l
 from tests.cpu_stand_in import CpuStandInOps
 
 # (name, epochs with irregular blocks / tails on the way down)
-COLUMN_CASES = ["rbf_1e4", "rbf_2e4_defaults", "rbf_ragged", "rbf_exact_blocks", "matern32_8e3", "matern52_3e4_d32", "rbf_d1"]
+COLUMN_CASES = ["rbf_1e4", "rbf_2e4_defaults", "rbf_ragged", "rbf_exact_blocks", "matern32_8e3", "matern52_3e4_d32", "rbf_d1",
+                # likelihood noise on the block diagonals (the tail block's too), GP posterior and WSABI-L
+                "cfg1_posterior_1e4", "wsabil_2e4", "matern52_posterior", "posterior_noise_ragged", "wsabil_noise_ragged"]
 
 
 def _run(c, columns, trace=None):
@@ -50,8 +52,8 @@ def test_column_epochs_reproduce_the_goldens(name):
 
 
 def test_column_path_scope():
-    """Likelihood-noise diagonals, WSABI-M and the SOBER variant keep the round-5 rounds (``_epochs.eligible``)."""
-    for name, uses in (("rbf_2e4_defaults", True), ("cfg1_posterior_1e4", False), ("wsabim_1e4", False), ("wsabil_2e4", False)):
+    """WSABI-M (and the SOBER variant, several ranks) keep the round-5 rounds (``_epochs.eligible``)."""
+    for name, uses in (("rbf_2e4_defaults", True), ("cfg1_posterior_1e4", True), ("wsabim_1e4", False), ("wsabil_2e4", True)):
         calls = _run(BY_NAME[name], True)[3]
         assert (calls.get("epoch_turn", 0) > 0) == uses, name
 

@@ -397,7 +397,8 @@ def test_golden_parity_descriptor_driven_rounds(name):
 
 
 @pytest.mark.parametrize("name", ["rbf_1e4", "rbf_2e4_defaults", "rbf_ragged", "matern52_3e4_d32", "cfg2_rbf_1e5", "cfg3_rbf_1e6",
-                                  "cfg4_matern52_1e6_d32"])
+                                  "cfg4_matern52_1e6_d32", "cfg1_posterior_1e4", "wsabil_2e4", "matern52_posterior",
+                                  "posterior_noise_ragged", "wsabil_noise_ragged", "cfg5_wsabil_5e5"])
 def test_golden_parity_column_epochs_and_round5_epochs(name):
     """Round 6: inside an epoch the candidates outside the residue classes are message columns (``basq_amd/_epochs.py``; the default
     for these cases) -- against the goldens with EVERY round's kept sets (a trace read after the fact), and against the round-5
