@@ -1,6 +1,6 @@
 """Descriptor-driven rounds with NO pairwise evaluation inside an epoch (round 6; ``BASQ/_rchq.py:76-130``).
 
-``Batch._async_rounds`` regroups the residue-class messages from round to round but still evaluates, projects and compacts
+``AsyncRounds._async_rounds`` regroups the residue-class messages from round to round but still evaluates, projects and compacts
 the candidates outside the classes -- the ``e < C`` full blocks behind the regular region and the ragged tail -- in EVERY round:
 five chip-wide launches (60-70 us) between two chains of single-work-group kernels.  Those candidates obey the same law as the
 classes: a round sends the survivor of (block b, kept rank k) to position ``b * n_keep + k`` with its weight rescaled by
@@ -16,7 +16,7 @@ of it; the launch stream waits for the side stream only before the first ``epoch
 
 Scope: one rank, BASQ variant, stationary / posterior / WSABI-L kernels (``predictive_covariance``'s likelihood noise on the
 block diagonals included: the tail block's per-point weights, which that term needs, are a row of the tail slot).  WSABI-M, the
-SOBER variant and several ranks keep ``Batch._async_rounds``.
+SOBER variant and several ranks keep ``AsyncRounds._async_rounds``.
 """
 from __future__ import annotations
 
@@ -26,6 +26,7 @@ import torch
 
 from . import _config as cfg
 from ._partition import choose_chunks
+from ._plan import classes_for
 
 
 def eligible(b) -> bool:
@@ -41,9 +42,7 @@ def block_capacity(R_lo: int, R_up: int, S: int, C: int) -> int:
 
 
 def async_rounds_columns(b, pre):
-    """Generator with the contract of ``Batch._async_rounds`` (-> False | True = a round violated the plan | "basis")."""
-    from ._batch import classes_for
-
+    """Generator with the contract of ``AsyncRounds._async_rounds`` (-> False | True = a round violated the plan | "basis")."""
     ops, trace = b.ops, b.trace
     S, s, q, m_ext, q_ext = b.S, b.s, b.q, b.m_ext, b.q_ext
     spec, nys_ext, U_ext, kscale, kp = b.spec, b.nys_ext, b.U_ext, b.kscale, b.kp

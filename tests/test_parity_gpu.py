@@ -344,6 +344,65 @@ def test_fuzz_more_hard_cases_gpu():
         torch.set_default_dtype(prev)
 
 
+def test_index_mismatch_is_attributed_to_the_posterior_cancellation_not_to_the_shortcuts():
+    """Review r05, item 3: WHICH part of the engine costs the parity in structured seed 8 case 33 (RBF posterior, observation Gram
+    cond 3.5e10), the one known index mismatch?  Measured (``tools/attribute_mismatch.py`` ->
+    ``profiles/r08_b_attribution_of_parity_misses_per_switch.txt``) and pinned here:
+
+    * NOT the shortcuts: with the reference-form basis (``BASIS_SVD``: the final SVD of ``svd_lowrank``, ``_rchq.py:28-31``), with
+      the host-LAPACK null space (``GPU_NULLSPACE = False``, ``:138-143``), with ``torch.svd_lowrank`` itself on the host
+      (``GPU_RANGE_FINDER = False``) and with all of them together the engine selects the SAME indices as by default;
+    * the arithmetic of the posterior covariance: the reference's OWN formulation (explicit ``k - k(.,X) W k(X,.)`` per block,
+      ``_gp.py:259-277``) evaluated by device tensor operations and pushed through the engine's dense path reproduces the
+      oracle's indices -- with weights that differ from the oracle's by orders of magnitude more than the 1e-5 bar (2e-2 when
+      recorded): the same formula under another GEMM's rounding.  The fused path folds the correction into the contraction
+      matrix by linearity (``U_ext``), a third rounding of the same cancellation, and lands on other indices."""
+    import warnings
+
+    import basq_amd
+    import basq_amd._config as eng
+    from oracle.kernels_oracle import PosteriorOracle, StationaryOracle
+    from oracle.rchq_oracle import recombination_oracle
+    from tests.cases import build_oracle_kernel, build_pool, build_product_kernel, structured_fuzz_cases
+
+    c = structured_fuzz_cases(8, 34)[33]
+    pts, nys = build_pool(c)
+    ko, state = build_oracle_kernel(c)
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    saved = (eng.BASIS_SVD, eng.GPU_NULLSPACE, eng.GPU_RANGE_FINDER)
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            torch.manual_seed(c["torch_seed"])
+            io, wo = recombination_oracle(pts, nys, c["n"], ko)
+            runs = {}
+            for key in ((False, True, True), (True, True, True), (False, False, True), (True, False, False)):
+                eng.BASIS_SVD, eng.GPU_NULLSPACE, eng.GPU_RANGE_FINDER = key
+                try:
+                    torch.manual_seed(c["torch_seed"])
+                    ie, we = basq_amd.recombination(pts, nys, c["n"], build_product_kernel(c, state), torch.device(DEV))
+                finally:
+                    eng.BASIS_SVD, eng.GPU_NULLSPACE, eng.GPU_RANGE_FINDER = saved
+                runs[key] = ie.cpu().tolist()
+            default = runs[(False, True, True)]
+            if default == io.tolist():
+                return                                               # (a change made the case match: nothing left to attribute)
+            for key, idx in runs.items():
+                assert idx == default, f"BASIS_SVD, GPU_NULLSPACE, GPU_RANGE_FINDER = {key} changes the engine's selection"
+            k = c["kernel"]
+            dev = torch.device(DEV)
+            kdev = PosteriorOracle(StationaryOracle(k["family"], k["lengthscale"], k["outputscale"]), state["Xobs"].to(dev),
+                                   state["W"].to(dev), state["noise"])
+            torch.manual_seed(c["torch_seed"])
+            iq, wq = basq_amd.recombination(pts.to(dev), nys.to(dev), c["n"], kdev, dev)
+            assert iq.cpu().tolist() == io.tolist(), "the reference's formulation on the device no longer reproduces the oracle's indices"
+            rel = ((wq.cpu() - wo).abs() / wo).max().item()
+            assert rel > 1e-4, f"the reference's own formulation now agrees to {rel:.1e}: the case is no longer ill-conditioned?"
+    finally:
+        torch.set_default_dtype(prev)
+
+
 @pytest.mark.parametrize("N,d,n,m", [(1, 2, 2, 1), (2, 2, 2, 1), (2, 2, 3, 2), (3, 1, 2, 2), (5, 3, 2, 3), (4, 2, 2, 4),
                                      (7, 2, 3, 1), (10, 2, 10, 5), (6, 2, 2, 6), (0, 2, 3, 0)])
 def test_tiny_and_degenerate_pools_gpu(N, d, n, m):
