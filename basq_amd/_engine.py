@@ -133,6 +133,7 @@ class EngineTrace:
     time_kernels: bool = False                      # record HIP events around every block-sum launch
     kernel_events: list = field(default_factory=list)   # (start_evt, end_evt, dict(pairs=, R=, m=, S=))
     chain_events: list = field(default_factory=list)    # time_kernels: (start_evt, end_evt) around each round's null space + elimination
+    side_pairs: float = 0.0                         # kernel values evaluated on the side stream (message columns of an epoch's irregular candidates: not in kernel_events)
     sample_clock: object = None                     # time_kernels: a HipOps on a SECOND stream -> shader clock beside each class launch
     host_sync: bool = True                          # synchronise around phases to attribute host timers
 

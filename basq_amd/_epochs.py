@@ -58,6 +58,7 @@ def async_rounds_columns(b, pre):
     plan_C = None
     records = []
     side_ev, side_keep = None, None
+    side_rounds = []                                             # rounds whose columns were evaluated (for the trace)
 
     def flush(out_rows):
         """Apply the pending rounds' compactions (one launch) -> candidates of round ``r``."""
@@ -112,6 +113,7 @@ def async_rounds_columns(b, pre):
                     if side is not ops:
                         side_ev = side.record_event(False)
                         side_keep = (Xirr, totirr)
+                side_rounds.append(r)
                 parts = P[:C_cur + 1]
             else:
                 parts = ops.project(U_ext, q_ext, m_ext, Xpart, totpart, n_chunks, S, kscale).unsqueeze(0)
@@ -179,6 +181,8 @@ def async_rounds_columns(b, pre):
         return True
     if trace is not None:
         b._trace_async_rounds(table, records, r)
+        # the columns' kernel values (every candidate behind the regular region once more, per epoch)
+        trace.side_pairs += float(sum(int(table[k][0]) - int(table[k][2]) for k in side_rounds)) * m_ext
     b.cand, b.mu, b.gid, b.wx = cand, mu, gid, wx
     b.R, b.off, b.Rl = int(row[0]), int(row[6]), int(row[7])
     b.R_lo = R_lo
