@@ -64,7 +64,8 @@ def batches(disp, n_batches=4):
 def main():
     out = sys.argv[1]
     res = {"kernel": "blocksum_kernel<3,0,4> -- all launches of one headline batch (N=1e6, d=10, n=100, m=1e4): 16 residue "
-                     "classes in round 1 (one launch since the end of round 4; 14 + 2 before), fresh evaluations in rounds 6 and 11, the irregular blocks of every round"}
+                     "classes in round 1 (one launch since the end of round 4; 14 + 2 before), fresh evaluations in rounds 6 and 11+; round 6: "
+                     "the irregular candidates once per EPOCH (their message columns, on the side stream) instead of once per round"}
     res["commit"] = sys.argv[2] if len(sys.argv) > 2 else None      # (the GPU box has no .git: pass `git rev-parse --short HEAD`)
     if res["commit"] is None:
         try:
@@ -100,7 +101,7 @@ def main():
     # rows + mu 8 B; 14 of the 16 -- 873 600 candidates -- while the round was launched as 14 + 2) + the Nystrom rows
     # (10 048 x 96 B), fetched once when the XCD map keeps a candidate slice in ONE L2
     big_fetch = mean_big(per["fetch"], "FETCH_SIZE")
-    n_big = 998_400 if res["launches_per_batch"] == 16 else 873_600
+    n_big = 873_600 if res["launches_per_batch"] == 17 else 998_400      # (17 launches per batch: round 1 as 14 + 2 classes, rounds 2-3)
     compulsory = n_big * (96 + 8) + 10_048 * 96
     res["largest_launch"] = {"fetch_KiB": big_fetch, "write_KiB": mean_big(per["write"], "WRITE_SIZE"),
                              "compulsory_fetch_bytes": compulsory,
