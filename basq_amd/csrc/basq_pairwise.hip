@@ -215,6 +215,37 @@ __device__ __forceinline__ double exp_scaled_k(double y, const ExpK& k, const do
     return ldexp(e, ti >> ExpScheme<XS>::SHIFT);
 }
 
+// acc + W exp(x) for the block sums of the RBF kernel (round 6): the candidate's weight W is folded into the polynomial's
+// coefficients ONCE per candidate fragment (three multiplications per 4 JT values: `ExpW`), and the table value takes the power of
+// two BEFORE the product -- acc = fma(2^n T[j], W p(f), acc) -- so that the separate multiplications by the polynomial and by the
+// weight become one FMA: 9 vector instructions per value instead of 10 (cvt, and, shift, fract, two FMAs, shift, ldexp, FMA).
+// 2^n T[j] is exact (T in (1/2, 1]; n <= 0 down to the subnormals, where the value was an exact or rounded 0 before as well).
+#ifndef BASQ_BS_WEIGHTED_POLY
+#define BASQ_BS_WEIGHTED_POLY 1    // A/B builds: -DBASQ_BS_WEIGHTED_POLY=0 (round 5's sequence: e = ldexp(T p, n); acc += e W)
+#endif
+struct ExpW {
+    double c2, c1, c0, w;          // W x the polynomial's coefficients; W itself (the 1e-17 scheme adds it)
+};
+template <int XS>
+__device__ __forceinline__ ExpW expw_for(const ExpK& k, double W) {
+    ExpW e;
+    e.c2 = k.c3 * W;
+    e.c1 = k.c2 * W;
+    e.c0 = k.one * W;
+    e.w = W;
+    return e;
+}
+template <int XS>
+__device__ __forceinline__ double exp_scaled_wacc(double y, const ExpW& k, const double* tab, double acc) {
+    const int ti = (int)y;                                              // N n + j (two's complement)
+    const double f = __builtin_amdgcn_fract(__builtin_fabs(y));
+    const double T = tab[ti & (ExpScheme<XS>::N - 1)];
+    double p = __builtin_fma(k.c2, f, k.c1);
+    p = __builtin_fma(p, f, k.c0);
+    if (XS != 2) p = __builtin_fma(f, p, k.w);                          // W (1 + f (b1 + b2 f + b3 f^2))
+    return __builtin_fma(ldexp(T, ti >> ExpScheme<XS>::SHIFT), p, acc);
+}
+
 // Kernel value from the block sums' scaled product: RBF: Dp = -1/2 |(x-y)/l|^2 N/ln2; Matern: Dp = |(x-y)/l|^2 (the fragments
 // times -2: exact), k.k32 = -sqrt(5) N/ln2 resp. -sqrt(3) N/ln2.
 template <int FAM, int XS>
@@ -403,6 +434,48 @@ __device__ __forceinline__ void load_cand(CandFrag<KK>& f, const BlocksumArgs& A
 template <int KK, int FAM, int JT, int XS>
 __device__ __forceinline__ void tile_accumulate(const double (&a)[JT][KK], const CandFrag<KK>& f, double (&acc)[JT][4],
                                                 const ExpK& ek, const double* tab) {
+    if constexpr (FAM != BASQ_FAMILY_RBF && BASQ_BS_SCALED_ARG && BASQ_BS_WEIGHTED_POLY && BASQ_FAST_SQRT) {
+        // Matern: the weight goes into the PREFACTOR's coefficients (W (1 + sqrt(5) r + 5/3 r^2) resp. W (1 + sqrt(3) r)), the table
+        // value takes the power of two first, and acc = fma(2^n T p(f), W pref(r), acc): one multiplication fewer per value
+        const double W = f.w;
+        const double cw1 = ((FAM == BASQ_FAMILY_MATERN52) ? 0x1.1e3779b97f4a8p+1 : 0x1.bb67ae8584caap+0) * W;
+        const double cw2 = (5.0 / 3.0) * W;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            d4 D = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) D = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt][kk], f.b[kk], D, 0, 0, 0);
+#pragma unroll
+            for (int r_ = 0; r_ < 4; ++r_) {
+                const double r2 = fmax(D[r_], 1e-30);                    // gpytorch: clamp_min(1e-30) before sqrt
+                const double r = sqrt_pos_fast(r2);
+                const double y = r * ek.k32;
+                const int ti = (int)y;
+                const double fr = __builtin_amdgcn_fract(__builtin_fabs(y));
+                const double T = tab[ti & (ExpScheme<XS>::N - 1)];
+                double p = __builtin_fma(ek.c3, fr, ek.c2);
+                p = __builtin_fma(p, fr, ek.one);
+                const double Tn = ldexp(T, ti >> ExpScheme<XS>::SHIFT);
+                const double e = (XS == 2) ? (Tn * p) : __builtin_fma(Tn * fr, p, Tn);
+                const double pref = (FAM == BASQ_FAMILY_MATERN52) ? __builtin_fma(cw2, r2, __builtin_fma(cw1, r, W))
+                                                                  : __builtin_fma(cw1, r, W);
+                acc[jt][r_] = __builtin_fma(e, pref, acc[jt][r_]);
+            }
+        }
+        return;
+    }
+    if constexpr (FAM == BASQ_FAMILY_RBF && BASQ_BS_SCALED_ARG && BASQ_BS_WEIGHTED_POLY) {
+        const ExpW ew = expw_for<XS>(ek, f.w);                          // (a masked column has W = 0: its values add exact zeros)
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            d4 D = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) D = __builtin_amdgcn_mfma_f64_16x16x4f64(a[jt][kk], f.b[kk], D, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[jt][r] = exp_scaled_wacc<XS>(D[r], ew, tab, acc[jt][r]);
+        }
+        return;
+    }
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) {
         d4 D = {0.0, 0.0, 0.0, 0.0};
