@@ -57,6 +57,9 @@ MAX_CLASSES = 16                 # classes at the start of an epoch (power of tw
 # two eliminations; their columns are evaluated beside the epoch's first chain on a side stream (basq_amd/_epochs.py; one rank,
 # BASQ variant, no noise diagonal).  False: every round evaluates them afresh (round 5's path).
 IRR_COLUMNS = True
+# Batches in flight evaluate those columns on their own stream (False) or on a side stream per batch in flight (True; A/B:
+# tools/bench_many.py --set PIPELINED_SIDE_STREAM=1).  A side stream SHARED by the batches lost (profiles/r08_e_*).
+PIPELINED_SIDE_STREAM = False
 # Rounds driven by a device-resident descriptor, no host wait per round (any rank count; structured kernels except WSABI-M).
 ASYNC_ROUNDS = True
 

@@ -100,10 +100,11 @@ def async_rounds_columns(b, pre):
                 # ... and the columns the NEXT rounds of the epoch regroup, beside this round's chain (side stream)
                 # (with other batches in flight there is no idle chip to fill, and a stream shared between the batches only ties
                 #  them together: the same launches go to the batch's own stream then -- same arithmetic, same bits)
-                side = ops if b.pipelined else ops.side_ops()
+                own = b.pipelined and cfg.PIPELINED_SIDE_STREAM and hasattr(ops, "own_side_ops")
+                side = ops.own_side_ops() if own else (ops if b.pipelined else ops.side_ops())
                 if side is not ops:
                     side.wait_event(ops.record_event(False))
-                with (contextlib.nullcontext() if side is ops else ops.side_context()):
+                with (contextlib.nullcontext() if side is ops else (ops.own_side_context() if own else ops.side_context())):
                     Xirr, totirr = side.empty(E_cur + 1, m_ext, S), side.empty(E_cur + 1, S)
                     if E_cur > 0:
                         side.blocksum_geo(spec, nys_ext, m_ext, cand, mu, wx, g_row, 5, S, E_cur, out=(Xirr[:E_cur], totirr[:E_cur]),

@@ -741,7 +741,18 @@ class HipOps:
             ops = _SIDE_OPS[idx] = HipOps(self.device, stream=torch.cuda.Stream(device=self.device))
         return ops
 
+    def own_side_ops(self):
+        """A side stream of THIS object's own (one per batch in flight: ``SlotPool`` keeps the objects, so the streams are
+        created once) -- ``_config.PIPELINED_SIDE_STREAM``."""
+        ops = self.__dict__.get("_own_side")
+        if ops is None:
+            ops = self.__dict__["_own_side"] = HipOps(self.device, stream=torch.cuda.Stream(device=self.device))
+        return ops
+
     def side_context(self):
         """``with ops.side_context():`` -- torch's current stream is the side stream inside the block, so that what is allocated
         there (work buffers of the wrappers included) comes from THAT stream's pool and is recycled in its order."""
         return torch.cuda.stream(self.side_ops().stream)
+
+    def own_side_context(self):
+        return torch.cuda.stream(self.own_side_ops().stream)
