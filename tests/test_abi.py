@@ -62,6 +62,20 @@ def test_argument_validation_without_gpu(lib_path):
     assert lib.basq_nullspace_f64(None, 10, 20, None, None, None, None, None, None) == -1
     assert lib.basq_nullspace_f64(1, 20, 20, 1, 1, 1, None, None, None) == -1    # needs s < M (checked before any launch)
     assert lib.basq_nullspace_f64(1, 10, 2000, 1, 1, 1, None, None, None) == -1  # M <= 1024
+    # ABI 15: the epochs' message columns
+    assert lib.basq_epoch_turn_f64(None, 4, 1, None, 1, 10, 20, None, None, None, None, None, None, None, None) == -1
+    assert lib.basq_epoch_turn_f64(1, 3, 1, 1, 1, 10, 20, 1, 1, 1, 1, 1, 1, 1, None) == -1            # C must be even (and >= 2)
+    assert lib.basq_epoch_turn_f64(1, 4, 1, 1, 1, 10, 21, 1, 1, 1, 1, 1, 1, 1, None) == -1            # S must be even
+    assert lib.basq_epoch_turn_f64(1, 4, -1, 1, 1, 10, 20, 1, 1, 1, 1, 1, 1, 1, None) == -1
+    ptrs = (ctypes.c_void_p * 9)(*([1] * 9))
+    assert lib.basq_reweight_compact_rounds_f64(1, 1, 1, None, 1, 9, ptrs, ptrs, ptrs, ptrs, 10, 4, 4, 10, 2, 1, 1, 1, None, None) == -1   # <= 8 rounds
+    assert lib.basq_reweight_compact_rounds_f64(1, 1, 1, None, 1, 0, ptrs, ptrs, ptrs, ptrs, 10, 4, 4, 10, 2, 1, 1, 1, None, None) == -1
+    assert lib.basq_reweight_compact_rounds_f64(1, 1, 1, 1, 1, 2, ptrs, ptrs, ptrs, ptrs, 10, 4, 4, 10, 2, 1, 1, 1, None, None) == -1       # wx without wx_out
+    nul = (ctypes.c_void_p * 2)(1, None)
+    assert lib.basq_reweight_compact_rounds_f64(1, 1, 1, None, 1, 2, nul, ptrs, ptrs, ptrs, 10, 4, 4, 10, 2, 1, 1, 1, None, None) == -1    # a round without its outcome
+    assert lib.basq_blocksum_geo_f64(ctypes.byref(spec), 1, 1, 1, 1, None, 1, 5, 4, 2, 0, 0, 1, 1, None) == -1   # mode 5 needs the classes
+    assert lib.basq_blocksum_geo_f64(ctypes.byref(spec), 1, 1, 1, 1, None, 1, 2, 4, 2, 4, 0, 1, 1, None) == -1   # classes: modes 1 and 5 only
+    assert lib.basq_blocksum_geo_f64(ctypes.byref(spec), 1, 1, 1, 1, None, 1, 6, 4, 2, 0, 0, 1, 1, None) == -1
     assert lib.basq_reduction_ws_doubles(100, 200) == 0                    # one CU: no workspace
     assert lib.basq_reduction_ws_doubles(200, 400) > 0                     # 4-CU cluster: ring + flags
 

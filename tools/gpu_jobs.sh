@@ -73,6 +73,7 @@ job_prof_concurrent() { prof conc tools/exp_concurrent.py --threads 2 --batches 
 job_prof_opaque() { prof opaque tools/bench_opaque_cfg4.py --reps 1; }
 job_prof_cfg4()   { prof cfg4 tools/bench_configs.py --only cfg4_matern52_1e6_d32; }
 job_prof_cfg5m()  { prof cfg5m tools/bench_configs.py --only cfg5m_wsabim_5e5; }
+job_prof_cfg2()   { prof cfg2 tools/bench_configs.py --only cfg2_rbf_1e5 --reps 6 && python tools/trace_batch.py "$(ls $out/prof_cfg2/*kernel_trace.csv | head -1)" > "$out/trace_batch_cfg2.txt" 2>&1; tail -40 "$out/trace_batch_cfg2.txt" | cut -c1-150; }
 job_drop_traces() { rm -f $out/prof_*/*trace.csv; }
 
 # hardware counters of the dominant kernel, one pass per counter group (never combined with a trace domain)
