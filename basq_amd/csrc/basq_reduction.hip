@@ -1816,13 +1816,17 @@ __global__ void __launch_bounds__(BASQ_WPG * 64) bidiag_cluster_kernel(const dou
 template <int NV>
 __global__ void __launch_bounds__(256) nullspace_apply_kernel(const double* __restrict__ V,
                                                               const double* __restrict__ tau, int m, int n,
-                                                              double* __restrict__ PhiT) {
+                                                              double* __restrict__ PhiT, int xcd_stride) {
+    // (round 6) only every xcd_stride-th work-group of the launch works: work-groups b, b + 8, ... are dealt to ONE XCD, the one
+    // whose L2 holds the reflector rows the single-work-group bidiagonalisation has just written (and the null vectors for the
+    // single-work-group elimination that follows) -- the launch was bound by fetching those rows across the fabric
+    if (blockIdx.x % xcd_stride) return;
     // Reflector rows in flight.  V was written a moment ago by ONE work-group: for the other XCDs its lines come from
     // memory, not from their L2 (~1.2 us), i.e. four reductions' worth of latency is not enough -- 4 rows: 31.3 us,
     // 8: 28.1, 12: 25.7, 16: 25.6 (profiles/r02_m_nullspace_apply_rows_in_flight.txt)
     constexpr int PF = 12;
     const int lane = threadIdx.x & 63;
-    const int c0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int c0 = (blockIdx.x / xcd_stride) * 4 + (threadIdx.x >> 6);
     if (c0 >= n - m) return;                              // wave-uniform
     double y[NV], v[PF][NV], tv[PF];
     // loads without branches (round 5: the conditional loads compiled into one exec-mask branch each): a row index below 0 is
@@ -1868,6 +1872,77 @@ __global__ void __launch_bounds__(256) nullspace_apply_kernel(const double* __re
     for (int k = 0; k < NV; ++k) {
         const int c = lane + 64 * k;
         if (c < n) PhiT[(size_t)c0 * n + c] = y[k];
+    }
+}
+
+// The same apply with 16-BYTE loads (round 6): lane l holds the column PAIRS 2l, 2l + 1 (+ 128 per further slot pair), so a reflector
+// row is NV / 2 load instructions instead of NV.  Why it matters: the rows were written by the bidiagonalisation's launch a
+// moment ago and come back from memory (the L2s are written back and invalidated at the kernel boundary; ~2 us), so the
+// loop needs rows in flight -- and a wave can have 63 vector loads outstanding: at M > 256 (eight column slots) twelve rows of
+// eight 8-byte loads exceed that, twelve rows of four 16-byte loads do not (752 -> 740 us at 200 x 400, profiles/r08_o_*).
+// At 100 x 200 none of the three things tried moved the apply's 25 us: 24 rows in flight instead of 12 (this kernel), the
+// work-groups on the bidiagonalisation's XCD (-3 us), four reflectors per reduction (compact-WY blocks: the four-fold wave
+// sum costs what four single ones do; profiles/r08_m_*, r08_n_*).  Needs an even n (row starts 16-byte aligned).
+template <int NV, int PF>
+__global__ void __launch_bounds__(256) nullspace_apply_pairs_kernel(const double* __restrict__ V,
+                                                                    const double* __restrict__ tau, int m, int n,
+                                                                    double* __restrict__ PhiT, int xcd_stride) {
+    static_assert(NV % 2 == 0, "column pairs");
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    if (blockIdx.x % xcd_stride) return;
+    const int lane = threadIdx.x & 63;
+    const int c0 = (blockIdx.x / xcd_stride) * 4 + (threadIdx.x >> 6);
+    if (c0 >= n - m) return;                              // wave-uniform
+    constexpr int NP = NV / 2;
+    double y[NV], v[PF][NV], tv[PF];
+    int cc[NP];                                           // first column of pair h (clamped inside the row), n even: a pair is in or out
+    bool cok[NP];
+#pragma unroll
+    for (int h = 0; h < NP; ++h) {
+        const int c = 2 * lane + 128 * h;
+        cok[h] = c < n;
+        cc[h] = cok[h] ? c : (n - 2);
+        y[2 * h] = (c == m + c0) ? 1.0 : 0.0;
+        y[2 * h + 1] = (c + 1 == m + c0) ? 1.0 : 0.0;
+    }
+    auto load_row = [&](int p, int i) {
+        const int ic = (i >= 0) ? i : 0;
+        const double t = tau[ic];
+        tv[p] = (i >= 0) ? t : 0.0;
+        const double* row = V + (size_t)ic * n;
+#pragma unroll
+        for (int h = 0; h < NP; ++h) {
+            const d2 x = *reinterpret_cast<const d2*>(row + cc[h]);
+            v[p][2 * h] = cok[h] ? x.x : 0.0;
+            v[p][2 * h + 1] = cok[h] ? x.y : 0.0;
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < PF; ++p) load_row(p, m - 1 - p);
+    for (int i0 = m - 1; i0 >= 0; i0 -= PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {                    // static ring slot p holds row i0 - p
+            const int i = i0 - p;
+            if (i < 0) break;                             // wave-uniform
+            double dot = 0.0;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) dot += v[p][k] * y[k];
+            dot = wave_sum(dot);
+            const double t = tv[p] * dot;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) y[k] -= t * v[p][k];
+            load_row(p, i - PF);                          // refill the slot behind the reduction
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < NP; ++h) {
+        const int c = 2 * lane + 128 * h;
+        if (c < n) {
+            d2 o;
+            o.x = y[2 * h];
+            o.y = y[2 * h + 1];
+            *reinterpret_cast<d2*>(PhiT + (size_t)c0 * n + c) = o;
+        }
     }
 }
 
@@ -2572,10 +2647,21 @@ int basq_nullspace_f64(const double* X, int32_t s, int32_t M, double* V, double*
     const int nvec = M - s;
     // (a form with 16 lanes per null vector was the faster one for M > 256 while four reflector rows were in flight; with
     // twelve, the 64-lane form wins there too: 68 vs 167 us at 200 x 400 -- profiles/r02_n_nullspace_apply_200x400.txt)
-    const dim3 grid((nvec + 3) / 4), block(256);
-    if (M <= 256) hipLaunchKernelGGL(nullspace_apply_kernel<4>, grid, block, 0, st, V, tau, s, M, PhiT);
-    else if (M <= 512) hipLaunchKernelGGL(nullspace_apply_kernel<8>, grid, block, 0, st, V, tau, s, M, PhiT);
-    else hipLaunchKernelGGL(nullspace_apply_kernel<16>, grid, block, 0, st, V, tau, s, M, PhiT);
+    // BASQ_NS_APPLY_XCD=1: the launch's work-groups on ONE XCD (<= 32 of them) -- measured: 3 us of 259 at 100 x 200
+    // (profiles/r08_n_*), not worth tying 25 work-groups to one XCD while other batches are in flight; default: all XCDs
+    static const int apply_xcd = [] { const char* e = getenv("BASQ_NS_APPLY_XCD"); return e ? atoi(e) : 0; }();
+    const int n_wg = (nvec + 3) / 4;
+    const int xs = (apply_xcd && n_wg <= 32) ? cluster_stride() : 1;
+    const dim3 grid((unsigned)(n_wg * xs)), block(256);
+    // 16-byte loads (BASQ_NS_APPLY_PAIRS=0: the 8-byte form): even M, buffers 16-byte aligned.  Measured (profiles/r08_o_*):
+    // 752 -> 740 us at 200 x 400, where twelve rows of eight 8-byte loads exceed a wave's 63 outstanding loads; nothing at
+    // 100 x 200 (24 rows in flight instead of 12: 257 vs 256 us), which keeps the 8-byte kernel
+    static const int apply_pairs = [] { const char* e = getenv("BASQ_NS_APPLY_PAIRS"); return e ? atoi(e) : 1; }();
+    const bool pairs = apply_pairs && (M % 2 == 0) && (((uintptr_t)V | (uintptr_t)PhiT) % 16 == 0);
+    if (pairs && M > 256 && M <= 512) hipLaunchKernelGGL((nullspace_apply_pairs_kernel<8, 12>), grid, block, 0, st, V, tau, s, M, PhiT, xs);
+    else if (M <= 256) hipLaunchKernelGGL(nullspace_apply_kernel<4>, grid, block, 0, st, V, tau, s, M, PhiT, xs);
+    else if (M <= 512) hipLaunchKernelGGL(nullspace_apply_kernel<8>, grid, block, 0, st, V, tau, s, M, PhiT, xs);
+    else hipLaunchKernelGGL(nullspace_apply_kernel<16>, grid, block, 0, st, V, tau, s, M, PhiT, xs);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;
 }
