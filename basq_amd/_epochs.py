@@ -14,9 +14,12 @@ What the columns cost -- one block-sum chunk and one projection per irregular bl
 BESIDE the epoch's first chain, on the device's side stream: that chain keeps one compute unit busy for ~0.4 ms and needs none
 of it; the launch stream waits for the side stream only before the first ``epoch_turn``.
 
-Scope: one rank, BASQ variant, stationary / posterior / WSABI-L kernels (``predictive_covariance``'s likelihood noise on the
-block diagonals included: the tail block's per-point weights, which that term needs, are a row of the tail slot).  WSABI-M, the
-SOBER variant and several ranks keep ``AsyncRounds._async_rounds``.
+Scope: BASQ variant, stationary / posterior / WSABI-L kernels (``predictive_covariance``'s likelihood noise on the block diagonals
+included: the tail block's per-point weights, which that term needs, are a row of the tail slot); one rank, or several with
+replicated reductions -- every rank then carries the PARTIAL class messages and columns of its shard (``epoch_turn`` is linear in
+them: a gather + rescale), the summed message is all-gathered once per round exactly as before, and the compaction of an
+epoch's rounds walks the rank's shard through the descriptors.  WSABI-M, the SOBER variant and batches in flight on several ranks
+(owner-rank reductions) keep ``AsyncRounds._async_rounds``.
 """
 from __future__ import annotations
 
@@ -32,7 +35,8 @@ from ._plan import classes_for
 def eligible(b) -> bool:
     """Can batch ``b`` (operands prepared) take the column form of the descriptor-driven rounds?"""
     plan = b.plan
-    return bool(cfg.IRR_COLUMNS and plan.async_rounds and plan.classes and b.comm.world == 1 and b.owner is None
+    return bool(cfg.IRR_COLUMNS and plan.async_rounds and plan.classes and b.owner is None
+                and (b.comm.world == 1 or cfg.REPLICATED_REDUCTION)
                 and not plan.sober and plan.warp != "wsabim" and hasattr(b.ops, "epoch_turn"))
 
 
@@ -43,17 +47,19 @@ def block_capacity(R_lo: int, R_up: int, S: int, C: int) -> int:
 
 def async_rounds_columns(b, pre):
     """Generator with the contract of ``AsyncRounds._async_rounds`` (-> False | True = a round violated the plan | "basis")."""
-    ops, trace = b.ops, b.trace
-    S, s, q, m_ext, q_ext = b.S, b.s, b.q, b.m_ext, b.q_ext
+    ops, trace, comm = b.ops, b.trace, b.comm
+    multi = comm.world > 1                                       # several ranks: this rank's shard of the candidates and its PARTIAL
+    S, s, q, m_ext, q_ext = b.S, b.s, b.q, b.m_ext, b.q_ext     # messages / columns (epoch_turn is linear); one all-gather per round
     spec, nys_ext, U_ext, kscale, kp = b.spec, b.nys_ext, b.U_ext, b.kscale, b.kp
     n = s                                                        # a regular round keeps s = S / 2 sets
     rows = q_ext + 1
     reg_hi0 = (pre[4] * S) if (pre is not None and pre[3] >= 2) else 0
-    geo_t = ops.geo_init(64, b.R, S, reg_hi0, 0, b.R)
+    geo_t = ops.geo_init(64, b.R, S, reg_hi0, b.off, b.Rl)
     r = 0
     R_lo = R_up = b.R
+    Rl_up = b.Rl                                                 # upper bound of this rank's shard (sizes launches / buffers)
     cand, mu, gid, wx = b.cand, b.mu, b.gid, b.wx
-    pend, pend_r0, pend_R = [], 0, b.R                           # rounds whose compaction is still owed; first row; bound of len(cand)
+    pend, pend_r0, pend_R = [], 0, b.Rl                          # rounds whose compaction is still owed; first row; bound of len(cand)
     P, C_cur, E_cur = None, 1, 0                                 # this round's buffer [C | fold | E | tail] while inside an epoch
     plan_C = None
     records = []
@@ -72,8 +78,8 @@ def async_rounds_columns(b, pre):
         fresh = P is None
         if fresh:
             # ---- a fresh evaluation: the start of an epoch (C >= 2), or a round without classes
-            flush(R_up)
-            pend_r0, pend_R = r, R_up
+            flush(Rl_up)
+            pend_r0, pend_R = r, Rl_up
             if pre is not None:                                  # round 1: launched before the basis, host geometry
                 Xpart, totpart, n_chunks, C_cur = pre[:4]
                 pre = None
@@ -88,7 +94,7 @@ def async_rounds_columns(b, pre):
                     b.sums.timed_geo(r, 2, 1.0, lambda: ops.blocksum_geo(
                         spec, nys_ext, m_ext, cand, mu, wx, g_row, 2, S, 1, out=(Xpart[C_cur:], totpart[C_cur:])))
                 else:
-                    n_chunks = choose_chunks(max(R_lo // S, 1), m_ext, S, kp // 4)
+                    n_chunks = choose_chunks(max(R_lo // S // comm.world, 1), m_ext, S, kp // 4)
                     Xpart, totpart = ops.empty(n_chunks, m_ext, S), ops.empty(n_chunks, S)
                     b.sums.timed_geo(r, 3, 1.0, lambda: ops.blocksum_geo(spec, nys_ext, m_ext, cand, mu, wx, g_row, 3, S,
                                                                          n_chunks, out=(Xpart, totpart)))
@@ -131,8 +137,12 @@ def async_rounds_columns(b, pre):
                 ops.tail_weights_geo(mu, wx, g_row, S, buf[0, rows])
             else:
                 buf[0, rows].copy_(P[C_cur + 1 + E_cur][b.wrow])
-            fin = (buf, 1, rows + 1, q, S, b.diagU, b.m, min(b.m, S), b.diag_noise, b.wrow, rows, min(b.m, S), g_row)
+            if multi:
+                buf = comm.all_gather(buf[0])                    # [world, rows + 1, S], added in rank order by the finalize kernel
+            fin = (buf, buf.shape[0], rows + 1, q, S, b.diagU, b.m, min(b.m, S), b.diag_noise, b.wrow, rows, min(b.m, S), g_row)
         else:
+            if multi:
+                parts = comm.all_gather(ops.sum_parts(parts) if parts.shape[0] > 1 else parts[0])
             fin = (parts, parts.shape[0], rows, q, S, None, b.m, min(b.m, S), 0.0, 0, 0, 0, None)
         # ---- the round's chain of single-work-group kernels
         ev_c = ops.record_event() if b.sums._timing() else None
@@ -147,6 +157,8 @@ def async_rounds_columns(b, pre):
         # bounds of the next survivor count; the class plan of the next fresh evaluation follows the lower one
         R_lo_n = (R_lo // S) * n
         R_up_n = (R_up // S) * n + (S - 1)
+        # this rank's shard [off, off + Rl): at most ceil(Rl / S) + 1 blocks touch it, each keeps n; + the tail
+        Rl_up_n = min(R_up_n, (-(-Rl_up // S) + 1) * n + (S - 1)) if multi else R_up_n
         if P is not None and C_cur >= 2:
             # next round's classes, columns, fold slot and descriptor: one launch
             if side_ev is not None:
@@ -161,14 +173,19 @@ def async_rounds_columns(b, pre):
             plan_C = classes_for(R_lo_n // S) if b.plan.classes else 1
             ops.round_next(g_row, info, keep_rank, S, plan_C if plan_C >= 2 else 0, True, geo_t[r + 1])
         r += 1
-        R_lo, R_up = R_lo_n, R_up_n
+        R_lo, R_up, Rl_up = R_lo_n, R_up_n, Rl_up_n
         if len(pend) >= 8:                                       # (never with C <= 16: an epoch has at most five rounds)
-            flush(R_up)
-            pend_r0, pend_R = r, R_up
-    flush(R_up)                                                  # the host's loop needs the candidates
+            flush(Rl_up)
+            pend_r0, pend_R = r, Rl_up
+    flush(Rl_up)                                                 # the host's loop needs the candidates
     if side_ev is not None:                                      # (the last enqueued round opened an epoch: its columns are not
         ops.wait_event(side_ev)                                  #  used, but their buffer must outlive the side stream's writes)
         side_ev, side_keep = None, None
+    if multi:
+        # every rank ran its own reductions: a cluster-kernel time-out (status 2) is local to ONE rank, and the ranks must agree on
+        # repeating the rounds -- the flag becomes the maximum over the ranks
+        flags = comm.all_gather(geo_t[r, 3:4].to(torch.float64))
+        geo_t[r, 3:4] = flags.max().to(torch.int64).reshape(1)
     bad64 = (b._basis_bad != 0).to(torch.int64) if b._basis_bad is not None else geo_t[0, 3:4] * 0
     flat, ready = ops.to_host_async(torch.cat([geo_t[:r + 1].reshape(-1), bad64.reshape(1)]), "geo_table")
     yield ready                                                  # the ONE wait of the asynchronous rounds

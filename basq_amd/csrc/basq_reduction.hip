@@ -2257,10 +2257,11 @@ __global__ void __launch_bounds__(256) reweight_compact_rounds_kernel(
 #pragma clang fp contract(off)
     // ONE lane per candidate walks the rounds (a few table look-ups each; all but 2^-rounds of the candidates drop out on the
     // way); the survivors of a wave -- two of 64 after five rounds -- then have their packed rows copied by the whole wave.
-    const long long R0 = geo[0];
+    // this rank's shard of the first round: local candidate p is global position off0 + p (one rank: [0, R))
+    const long long off0 = geo[6], Rl0 = geo[7];
     const long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    long long pg = (p < R0) ? p : -1;
+    long long pg = (p < Rl0) ? (off0 + p) : -1;
     double w = (pg >= 0) ? mu[p] : 0.0;
     for (int r = 0; r < Rr.n; ++r) {
         const long long* g = geo + 8 * r;
@@ -2288,6 +2289,7 @@ __global__ void __launch_bounds__(256) reweight_compact_rounds_kernel(
         w = scaled / Rr.tot[r][set];
         pg = dst;
     }
+    if (pg >= 0) pg -= geo[8 * Rr.n + 6];                                       // local index in the shard of the round that follows
     if (pg >= out_rows) pg = -1;                                               // never outside the caller's buffers
     if (pg >= 0) {
         mu_out[pg] = w;

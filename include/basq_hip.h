@@ -329,7 +329,8 @@ int basq_blocksum_geo_f64(const basq_kernel_spec* spec, const double* nys, int32
  *       the host derives: e' <= (E_in S / 2 + S - 1) / S).
  *   basq_reweight_compact_rounds_f64: basq_reweight_compact_geo_f64 for n_rounds <= 8 consecutive rounds at once -- geo points
  *       at the first round's descriptor row (rows of 8, consecutive), the outcome arrays are HOST arrays of n_rounds device
- *       pointers; ONE rank (off = 0, Rl = R); per round mu <- (mu * w_star[k]) / tot[set], in round order.
+ *       pointers; the rank's shard [off, off + Rl) of the first round and its new offset come from the descriptors (geo[6], geo[7]; row
+ *       n_rounds = the descriptor behind the last of the rounds); per round mu <- (mu * w_star[k]) / tot[set], in round order.
  */
 int basq_epoch_turn_f64(const double* Pin, int32_t C, int32_t E_in, double* Pout, int32_t E_out, int32_t rows, int32_t S,
                         const int32_t* kept, const int32_t* keep_rank, const double* w_star, const double* tot,

@@ -406,7 +406,8 @@ def _async_worker(rank, world, port, name, q):
         torch.manual_seed(c["torch_seed"])
         idx, w = RecombinationEngine(ops, TorchDistComm()).run(pts[off:off + n].clone(), off, c["N"], nys, c["n"],
                                                                build_product_kernel(c), tr)
-        q.put((rank, idx.tolist(), w.tolist(), [r["kept"] for r in tr.rounds], ops.calls.get("round_next", 0)))
+        q.put((rank, idx.tolist(), w.tolist(), [r["kept"] for r in tr.rounds], ops.calls.get("round_next", 0),
+               ops.calls.get("epoch_turn", 0), ops.calls.get("compact_rounds", 0)))
     finally:
         dist.destroy_process_group()
 
@@ -419,7 +420,8 @@ def test_sharded_descriptor_driven_rounds(name, world):
     """The N > 1 fast path: every rank's shard of every round comes from the device-resident descriptor
     (``basq_round_next_i64`` evaluates ``next_shard`` in closed form), the per-round all-gather is enqueued like any other
     launch, and the host reads the descriptor table once.  Golden indices and per-round survivor sets on every rank,
-    ranks bit-identical among themselves."""
+    ranks bit-identical among themselves.  Round 6: inside an epoch every rank regroups the PARTIAL class messages and message
+    columns of its shard (``epoch_turn`` is linear), and the compactions of an epoch walk the rank's shard through the descriptors."""
     fx = load_golden(name)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -432,8 +434,10 @@ def test_sharded_descriptor_driven_rounds(name, world):
         p.join(timeout=60)
         assert p.exitcode == 0
     gw = torch.tensor(fx["w"], dtype=torch.float64)
-    for rank, idx, w, kept, n_next in res:
+    for rank, idx, w, kept, n_next, n_turn, n_flush in res:
         assert n_next > 0, "the descriptor-driven rounds did not run"
+        # round 6: several ranks take the column epochs too (partial class messages and columns per rank, basq_amd/_epochs.py)
+        assert n_turn > 0 and n_flush > 0, "the column epochs did not run on this rank"
         assert idx == fx["idx"], f"rank {rank}: indices differ"
         assert kept == [r["kept"] for r in fx["rounds"]]
         assert ((torch.tensor(w, dtype=torch.float64) - gw).abs() / gw).max().item() <= 1e-6

@@ -1260,19 +1260,22 @@ def test_epoch_turn_kernel_vs_stand_in(hip_ops, C, E_in, e, t, rows, S, last_kep
     assert not got[C // 2:].any() and int(hip_ops.to_host(geo_d[1], "gt")[3]) == 1
 
 
-def test_compaction_of_several_rounds_kernel(hip_ops):
+@pytest.mark.parametrize("shard", [None, (0, 700), (611, 903), (2_000, 303), (2_290, 13)])
+def test_compaction_of_several_rounds_kernel(hip_ops, shard):
     """basq_reweight_compact_rounds_f64 = basq_reweight_compact_geo_f64 round after round (rows, weights -- the same roundings --
-    and ids), launch and buffers sized for upper bounds; a violated round writes nothing."""
+    and ids), launch and buffers sized for upper bounds; a violated round writes nothing.  ``shard``: a rank's slice
+    ``[off, off + Rl)`` of the positions (mid-block starts and ends, a slice inside the ragged tail)."""
     S, n, d = 40, 20, 4
     kp = hip_ops.kp(d)
     R = 57 * S + 23
     g = torch.Generator().manual_seed(5)
-    R_max = R + 100
+    off, Rl = shard if shard is not None else (0, R)
+    R_max = Rl + 100
     cand = hip_ops.to_device(torch.rand(R_max, kp, generator=g, dtype=torch.float64))
     mu = hip_ops.to_device(torch.rand(R_max, generator=g, dtype=torch.float64))
     wx = hip_ops.to_device(torch.rand(R_max, generator=g, dtype=torch.float64))
     gid = hip_ops.to_device(torch.arange(R_max, dtype=torch.int64) * 7 + 3)
-    geo = hip_ops.geo_init(8, R, S, 48 * S)
+    geo = hip_ops.geo_init(8, R, S, 48 * S, off, Rl)
     outs, cur = [], (cand, mu, gid, wx)
     for r in range(4):
         last = r % 2 == 0
@@ -1289,7 +1292,7 @@ def test_compaction_of_several_rounds_kernel(hip_ops):
         Rn_up = (R >> (r + 1)) + 2 * S
         cur = hip_ops.reweight_compact_geo(*cur, geo[r], geo[r + 1], o["info"], R_max, S, kp, o["keep_rank"], o["w_star"], o["tot"],
                                            Rn_up, n)
-    Rn = int(hip_ops.to_host(geo[4], "g4")[0])
+    Rn = int(hip_ops.to_host(geo[4], "g4")[7])                 # this rank's share of the survivors
     got = hip_ops.reweight_compact_rounds(cand, mu, gid, wx, geo, outs, R_max, S, kp, Rn + 31, n)
     for a, b in zip(got, cur):
         assert torch.equal(a[:Rn], b[:Rn])
