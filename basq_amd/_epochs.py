@@ -15,11 +15,10 @@ BESIDE the epoch's first chain, on the device's side stream: that chain keeps on
 of it; the launch stream waits for the side stream only before the first ``epoch_turn``.
 
 Scope: BASQ variant, stationary / posterior / WSABI-L kernels (``predictive_covariance``'s likelihood noise on the block diagonals
-included: the tail block's per-point weights, which that term needs, are a row of the tail slot); one rank, or several with
-replicated reductions -- every rank then carries the PARTIAL class messages and columns of its shard (``epoch_turn`` is linear in
+included: the tail block's per-point weights, which that term needs, are a row of the tail slot); one rank, or several (replicated
+or owner-rank reductions) -- every rank then carries the PARTIAL class messages and columns of its shard (``epoch_turn`` is linear in
 them: a gather + rescale), the summed message is all-gathered once per round exactly as before, and the compaction of an
-epoch's rounds walks the rank's shard through the descriptors.  WSABI-M, the SOBER variant and batches in flight on several ranks
-(owner-rank reductions) keep ``AsyncRounds._async_rounds``.
+epoch's rounds walks the rank's shard through the descriptors.  WSABI-M and the SOBER variant keep ``AsyncRounds._async_rounds``.
 """
 from __future__ import annotations
 
@@ -35,8 +34,8 @@ from ._plan import classes_for
 def eligible(b) -> bool:
     """Can batch ``b`` (operands prepared) take the column form of the descriptor-driven rounds?"""
     plan = b.plan
-    return bool(cfg.IRR_COLUMNS and plan.async_rounds and plan.classes and b.owner is None
-                and (b.comm.world == 1 or cfg.REPLICATED_REDUCTION)
+    return bool(cfg.IRR_COLUMNS and plan.async_rounds and plan.classes
+                and (b.comm.world == 1 or cfg.REPLICATED_REDUCTION or b.owner is not None)
                 and not plan.sober and plan.warp != "wsabim" and hasattr(b.ops, "epoch_turn"))
 
 
@@ -48,6 +47,7 @@ def block_capacity(R_lo: int, R_up: int, S: int, C: int) -> int:
 def async_rounds_columns(b, pre):
     """Generator with the contract of ``AsyncRounds._async_rounds`` (-> False | True = a round violated the plan | "basis")."""
     ops, trace, comm = b.ops, b.trace, b.comm
+    owner = b.owner                                              # None: every rank reduces; else: that rank + a broadcast
     multi = comm.world > 1                                       # several ranks: this rank's shard of the candidates and its PARTIAL
     S, s, q, m_ext, q_ext = b.S, b.s, b.q, b.m_ext, b.q_ext     # messages / columns (epoch_turn is linear); one all-gather per round
     spec, nys_ext, U_ext, kscale, kp = b.spec, b.nys_ext, b.U_ext, b.kscale, b.kp
@@ -145,12 +145,19 @@ def async_rounds_columns(b, pre):
                 parts = comm.all_gather(ops.sum_parts(parts) if parts.shape[0] > 1 else parts[0])
             fin = (parts, parts.shape[0], rows, q, S, None, b.m, min(b.m, S), 0.0, 0, 0, 0, None)
         # ---- the round's chain of single-work-group kernels
-        ev_c = ops.record_event() if b.sums._timing() else None
-        XcarT, tot = ops.finalize(*fin)
-        PhiT = ops.nullspace(XcarT, s, S)
-        keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, tot, S, s)
-        if ev_c is not None:
-            trace.chain_events.append((ev_c, ops.record_event()))
+        # (owner-rank mode -- batches in flight on several ranks: the chain runs on ONE rank, its outcome, 3 S + 1 doubles, is
+        #  broadcast stream-ordered on the batch's own process group; every rank then advances its own partial messages with it)
+        res, rv = ops.reduction_result(S) if owner is not None else (None, None)
+        if owner is None or comm.rank == owner:
+            ev_c = ops.record_event() if b.sums._timing() else None
+            XcarT, tot = ops.finalize(*fin, tot_out=None if rv is None else rv["tot"])
+            PhiT = ops.nullspace(XcarT, s, S)
+            keep_rank, kept, w_star, info = ops.car_eliminate(PhiT, tot, S, s, out=rv)
+            if ev_c is not None:
+                trace.chain_events.append((ev_c, ops.record_event()))
+        if owner is not None:
+            comm.broadcast(res, src=owner)
+            keep_rank, kept, w_star, info, tot = rv["keep_rank"], rv["kept"], rv["w_star"], rv["info"], rv["tot"]
         if trace is not None:
             records.append(ops.info_kept_buffer(info, kept))
         pend.append(dict(keep_rank=keep_rank, w_star=w_star, tot=tot, info=info))
@@ -181,7 +188,7 @@ def async_rounds_columns(b, pre):
     if side_ev is not None:                                      # (the last enqueued round opened an epoch: its columns are not
         ops.wait_event(side_ev)                                  #  used, but their buffer must outlive the side stream's writes)
         side_ev, side_keep = None, None
-    if multi:
+    if multi and owner is None:
         # every rank ran its own reductions: a cluster-kernel time-out (status 2) is local to ONE rank, and the ranks must agree on
         # repeating the rounds -- the flag becomes the maximum over the ranks
         flags = comm.all_gather(geo_t[r, 3:4].to(torch.float64))
