@@ -112,10 +112,17 @@ def async_rounds_columns(b, pre):
                     side.wait_event(ops.record_event(False))
                 with (contextlib.nullcontext() if side is ops else (ops.own_side_context() if own else ops.side_context())):
                     Xirr, totirr = side.empty(E_cur + 1, m_ext, S), side.empty(E_cur + 1, S)
+                    timing = b.sums._timing()                    # (HIP events on the stream these launches run on)
                     if E_cur > 0:
+                        ev0 = side.record_event() if timing else None
                         side.blocksum_geo(spec, nys_ext, m_ext, cand, mu, wx, g_row, 5, S, E_cur, out=(Xirr[:E_cur], totirr[:E_cur]),
                                           class_mod=C_cur)
+                        if timing:
+                            b.sums._geo_events.append((ev0, side.record_event(), r, 5))
+                    ev0 = side.record_event() if timing else None
                     side.blocksum_geo(spec, nys_ext, m_ext, cand, mu, wx, g_row, 4, S, 1, out=(Xirr[E_cur:], totirr[E_cur:]))
+                    if timing:
+                        b.sums._geo_events.append((ev0, side.record_event(), r, 4))
                     side.project_chunks(U_ext, q_ext, m_ext, Xirr, totirr, E_cur + 1, S, kscale, out=P[C_cur + 1:])
                     if side is not ops:
                         side_ev = side.record_event(False)

@@ -78,8 +78,8 @@ class FusedSums:
     def resolve_geo_events(self, table):
         b = self.b
         for ev0, ev1, r, mode in self._geo_events:
-            R, reg_hi, off, Rl = (int(table[r][k]) for k in (0, 2, 6, 7))
-            lo, hi = (0, reg_hi) if mode == 1 else ((reg_hi, R) if mode == 2 else (0, R))
+            R, n_full, reg_hi, off, Rl = (int(table[r][k]) for k in (0, 1, 2, 6, 7))
+            lo, hi = {1: (0, reg_hi), 2: (reg_hi, R), 4: (n_full, R), 5: (reg_hi, n_full)}.get(mode, (0, R))
             n = max(0, min(hi, off + Rl) - max(lo, off))
             if n > 0:
                 b.trace.kernel_events.append((ev0, ev1, dict(pairs=float(n) * b.m_ext, R=n, m=b.m_ext, S=b.S, chunks=0)))

@@ -600,8 +600,9 @@ def main():
                 "shader_clock_MHz_in_situ": clock_in_situ, "shader_clock_samples": clk or None, "shader_clock_note": clock_note,
                 "frac_at_in_situ_clock": (achieved_tf / (PEAK_FP64_VECTOR_TFLOPS * clock_in_situ / 2400.0)) if clock_in_situ else None,
                 "launches_per_batch": k_launches, "kernel_ms_per_batch": k_ms, "pairs_per_batch": k_pairs,
-                # kernel values of the message columns (basq_amd/_epochs.py): evaluated on the SIDE stream beside the first chain of
-                # every epoch, neither in `pairs_per_batch` nor in `kernel_ms_per_batch` (0.4 % of the pairs at the headline size)
+                # of which the kernel values of the message columns (basq_amd/_epochs.py), evaluated on the SIDE stream beside the first
+                # chain of every epoch; their launches are timed by HIP events on THAT stream and are part of `launches_per_batch`,
+                # `pairs_per_batch` and `kernel_ms_per_batch` (0.4 % of the pairs at the headline size, ~0.2 ms of short launches)
                 "side_stream_pairs_per_batch": getattr(tr, "side_pairs", 0.0),
                 # the chains of single-work-group kernels (finalize + null space + elimination per round) of the same traced batch
                 "chain_ms_per_batch": chain_ms, "chain_rounds": len(tr.chain_events),
