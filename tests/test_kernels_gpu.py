@@ -1302,7 +1302,31 @@ def test_compaction_of_several_rounds_kernel(hip_ops, shard):
     got3 = hip_ops.reweight_compact_rounds(*c1, geo[1:], outs[1:], R, S, kp, Rn + 5, n)
     for a, b in zip(got3, cur):
         assert torch.equal(a[:Rn], b[:Rn])
-    # a round that kept another number of sets than expected: nothing is written
-    poison = hip_ops.reweight_compact_rounds(cand, mu, gid, wx, geo, outs, R_max, S, kp, Rn + 31, n + 1)
-    fresh = hip_ops.empty(1)                                     # (outputs are uninitialised: only check the call is harmless)
-    assert poison[0].shape[0] == Rn + 31 and fresh.numel() == 1
+    # a round that kept another number of sets than expected, a failed elimination, the sticky flag of an earlier round: NOTHING is
+    # written (the outputs are poisoned first and must come back untouched; the C entry is called directly to keep the buffers)
+    import ctypes as C
+
+    from basq_amd._ops import _ptr
+
+    rows = Rn + 31
+    co, mo, go, wo = hip_ops.empty(rows, kp), hip_ops.empty(rows), hip_ops.empty(rows, dtype=torch.int64), hip_ops.empty(rows)
+
+    def call(expect, infos=None, geo_rows=None):
+        co.fill_(-7.0), mo.fill_(-7.0), go.fill_(-7), wo.fill_(-7.0)
+        arr = lambda key, src: (C.c_void_p * len(outs))(*[o[key].data_ptr() for o in src])      # noqa: E731
+        use = outs if infos is None else [dict(o, info=i) for o, i in zip(outs, infos)]
+        rc = hip_ops.lib.basq_reweight_compact_rounds_f64(_ptr(cand), _ptr(mu), _ptr(gid), _ptr(wx), _ptr(geo if geo_rows is None else geo_rows),
+                                                          len(outs), arr("keep_rank", use), arr("w_star", use), arr("tot", use), arr("info", use),
+                                                          R_max, S, kp, rows, expect, _ptr(co), _ptr(mo), _ptr(go), _ptr(wo), hip_ops._stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+        return bool((co == -7.0).all() and (mo == -7.0).all() and (go == -7).all() and (wo == -7.0).all())
+
+    assert not call(n) or Rn == 0                                # the regular call does write (unless this shard has no survivor)
+    assert call(n + 1)                                           # another number of kept sets than the host sized for
+    failed = [o["info"] for o in outs]
+    failed[2] = hip_ops.to_device(torch.tensor([n, 1], dtype=torch.int32))
+    assert call(n, infos=failed)                                 # an elimination that stopped early in the third round
+    flagged = geo.clone()
+    flagged[1, 3] = 1
+    assert call(n, geo_rows=flagged)                             # the sticky violation flag in the second round's descriptor
