@@ -227,11 +227,13 @@ struct ExpW {
     double c2, c1, c0, w;          // W x the polynomial's coefficients; W itself (the 1e-17 scheme adds it)
 };
 template <int XS>
-__device__ __forceinline__ ExpW expw_for(const ExpK& k, double W) {
+__device__ __forceinline__ ExpW expw_for(const ExpK&, double W) {
+    // (the coefficients as LITERALS, not from ExpK's registers: three multiplications per candidate fragment can afford a scalar
+    //  operand each, and the six registers ExpK holds them in are then free in this form of the kernel)
     ExpW e;
-    e.c2 = k.c3 * W;
-    e.c1 = k.c2 * W;
-    e.c0 = k.one * W;
+    e.c2 = ((XS == 2) ? BASQ_EXP_W2 : BASQ_EXP_B3) * W;
+    e.c1 = ((XS == 2) ? BASQ_EXP_W1 : BASQ_EXP_B2) * W;
+    e.c0 = ((XS == 2) ? BASQ_EXP_W0 : BASQ_EXP_B1) * W;
     e.w = W;
     return e;
 }
@@ -497,6 +499,20 @@ __device__ __forceinline__ void tile_accumulate(const double (&a)[JT][KK], const
 #define BASQ_BS_PREFETCH 0      // 0 = by KK (A/B builds: -DBASQ_BS_PREFETCH=1 or 2)
 #endif
 #define BASQ_BS_PF_FOR(KK) (BASQ_BS_PREFETCH ? BASQ_BS_PREFETCH : ((KK) <= 8 ? 2 : 1))
+// Round 6: the RBF kernel at d = 7..10 WITHOUT per-candidate kernel weights (no WSABI warp: the headline shape) is an instantiation of
+// its own -- `NOWX`: the weight pointer is a compile-time null (one register pair per candidate fragment less, no select / product
+// per fragment) -- and, with the polynomial's coefficients as literals (`expw_for`), it needs 128 registers where the general form
+// needs 161: FOUR waves per SIMD at the same prefetch distance, no scratch.  6.93 -> 6.56 ms per 1e10 pairs, same box, alternating
+// (profiles/r08_t_*); forcing four waves on the general form cost 11 spilled registers for 2 % (profiles/r08_c_*).
+// ... and likewise wherever the leaner form crosses the 128-register line (compiler's resource report, round 6: e.g. Matern-5/2 at
+// KK = 2: 159 -> 128, KK = 6: 159 -> 112, KK = 7: 163 -> 118, KK = 8: 154 -> 124; RBF at KK = 7..10: 139-145 -> 117-126); pairs where it
+// does not (KK = 1, 4, 5; Matern at KK = 3, 9, 10: config 4's kernel stays at 159 registers, three waves) keep the one general form.
+#ifndef BASQ_BS_NOWX_FOR
+#define BASQ_BS_NOWX_FOR(KK, FAM)                                                                                              \
+    (((KK) == 3 && (FAM) == BASQ_FAMILY_RBF) || ((KK) == 2 && (FAM) == BASQ_FAMILY_MATERN52) ||                               \
+     ((KK) == 6 && (FAM) != BASQ_FAMILY_RBF) || (KK) == 7 || (KK) == 8 || ((KK) == 9 && (FAM) != BASQ_FAMILY_MATERN52) ||      \
+     ((KK) == 10 && (FAM) == BASQ_FAMILY_RBF))
+#endif
 #ifndef BASQ_BS_KK2_WAVES
 #define BASQ_BS_KK2_WAVES 3     // three waves per SIMD asked for at KK = 2, RBF (d = 3..6): left alone the kernel takes 170 registers, two
 #endif                          // over -- 6.93 -> 6.42 ms per 1e10 pairs at d = 5 (profiles/r07_x_blocksum_variants_d5_d16.txt; A/B builds: 1)
@@ -505,10 +521,11 @@ __device__ __forceinline__ void tile_accumulate(const double (&a)[JT][KK], const
 #else
 #define BASQ_BS_ATTR __attribute__((amdgpu_waves_per_eu(BASQ_BS_WAVES, BASQ_BS_WAVES)))
 #endif
-template <int KK, int FAM, int JT, int XS>
+template <int KK, int FAM, int JT, int XS, bool NOWX = false>
 __global__ void __launch_bounds__(256) BASQ_BS_ATTR blocksum_kernel(const BlocksumArgs A_in) {
     constexpr int KP = KK * 4;
     BlocksumArgs A = A_in;
+    if constexpr (NOWX) A.wx = nullptr;                          // (what the launcher checked: a compile-time fact from here on)
     if (A.geo) blocksum_apply_geo<KP>(A);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
@@ -711,6 +728,13 @@ static int launch_blocksum(const BlocksumArgs& A, hipStream_t st) {
     const long long npairs = (long long)A.n_stiles * A.n_chunks;
     const long long nblk = ((npairs + 7) / 8) * 8 * B.n_jgroups;   // (set tile, chunk) pairs padded to the 8 XCDs
     if (nblk <= 0 || nblk > 0x7fffffffLL) return BASQ_EINVAL;
+    if constexpr (BASQ_BS_NOWX_FOR(KK, FAM)) {
+        if (B.wx == nullptr) {                             // no per-candidate kernel weights: the leaner instantiation
+            hipLaunchKernelGGL((blocksum_kernel<KK, FAM, JT, XS, true>), dim3((unsigned)nblk), dim3(256), 0, st, B);
+            BASQ_CHECK_LAUNCH();
+            return BASQ_OK;
+        }
+    }
     hipLaunchKernelGGL((blocksum_kernel<KK, FAM, JT, XS>), dim3((unsigned)nblk), dim3(256), 0, st, B);
     BASQ_CHECK_LAUNCH();
     return BASQ_OK;

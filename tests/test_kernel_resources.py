@@ -37,9 +37,13 @@ def _find(res, pattern):
 
 # mangled-name pattern -> (minimum waves per SIMD, why it matters)
 HOT = {
-    r"15blocksum_kernelILi3ELi0ELi4ELi2E": (3, "headline block sums (RBF, d = 10): three waves per SIMD cover a load's latency"),
+    r"15blocksum_kernelILi3ELi0ELi4ELi2ELb0E": (3, "block sums at d = 7..10 with per-candidate kernel weights (WSABI-L): three waves per SIMD"),
+    r"15blocksum_kernelILi3ELi0ELi4ELi[12]ELb1E": (4, "headline block sums (RBF, d = 10, no kernel weights): 128 registers = FOUR waves per SIMD "
+                                                     "(round 6; the general form needs 161)"),
     r"15blocksum_kernelILi9ELi1ELi2ELi2E": (3, "config 4's block sums (Matern-5/2, d = 32)"),
     r"15blocksum_kernelILi[1-9]ELi[012]ELi[24]ELi2E": (3, "every other dimension up to d = 34 (round 5: d = 3..6 and d = 15..18 sat at two waves)"),
+    r"15blocksum_kernelILi(2ELi1|6ELi[12]|[78]ELi[012]|9ELi[02]|10ELi0)ELi[24]ELi2ELb1E": (4, "the instantiations without per-candidate kernel weights "
+                                                                                              "that cross the 128-register line (round 6)"),
     r"18blocksum_sq_kernelILi3ELi0ELi4ELb[01]E": (2, "WSABI-M's squared covariance at config 5's shape, both variants"),
     r"28bidiag_reflectors_reg_kernelILi4ELi7E": (4, "one work-group of 16 waves on ONE compute unit: below 4 the launch fails"),
     r"28bidiag_reflectors_reg_kernelILi4ELi[24]E": (4, "the same for the smaller shapes"),
@@ -58,7 +62,7 @@ def test_hot_kernel_occupancy(res, pattern):
     want, why = HOT[pattern]
     for name, v in _find(res, pattern).items():
         assert v["occupancy"] >= want, f"{name}: {v['occupancy']} waves per SIMD (VGPRs {v['vgprs']} + AGPRs {v['agprs']}), want >= {want}: {why}"
-        assert v["scratch"] == 0, f"{name}: {v['scratch']} bytes of scratch per lane"
+        assert v["scratch"] <= SCRATCH_ALLOWED.get(name, 0), f"{name}: {v['scratch']} bytes of scratch per lane"
 
 
 def test_no_kernel_spills(res):

@@ -117,6 +117,7 @@ job_ab_bs_matern() { for i in 1 2 3; do for lib in ${AB_LIBS:-libbasq_hip.so}; d
 job_ab_side_many() { ( for v in 0 1 0 1; do echo "== PIPELINED_SIDE_STREAM=$v"; timeout -k 10 200 python tools/bench_many.py --batches 24 --inflight 2,3,4 --set PIPELINED_SIDE_STREAM=$v 2>&1 | grep -v amdgpu.ids; done; for c in cfg2_rbf_1e5 rbf_2e4_defaults; do for v in 0 1 0 1; do echo "== $c PIPELINED_SIDE_STREAM=$v"; timeout -k 10 200 python tools/bench_many.py --case $c --batches 32 --inflight 2,4 --set PIPELINED_SIDE_STREAM=$v 2>&1 | grep -v amdgpu.ids; done; done ) > "$out/ab_side_many.txt" 2>&1; rc=$?; grep -v "^config\|^case" "$out/ab_side_many.txt" | cut -c1-130; return $rc; }
 job_ab_apply_xcd() { ( for sh in "100 200" "50 100"; do for v in 0 1 0 1; do echo "== $sh BASQ_NS_APPLY_XCD=$v"; BASQ_NS_APPLY_XCD=$v timeout -k 10 120 python tools/bench_reduction.py $sh --reps 200 2>&1 | grep -E "nullspace|car_eliminate|LAPACK"; done; done ) > "$out/ab_apply_xcd.txt" 2>&1; rc=$?; cat "$out/ab_apply_xcd.txt"; return $rc; }
 job_ab_apply_pairs() { ( for sh in "100 200" "50 100" "200 400"; do for v in 0 1 0 1; do echo "== $sh BASQ_NS_APPLY_PAIRS=$v"; BASQ_NS_APPLY_PAIRS=$v timeout -k 10 120 python tools/bench_reduction.py $sh --reps 200 2>&1 | grep -E "nullspace|LAPACK"; done; done ) > "$out/ab_apply_pairs.txt" 2>&1; rc=$?; cat "$out/ab_apply_pairs.txt"; return $rc; }
+job_ab_bs_dims()  { for i in 1 2; do for lib in ${AB_LIBS:-libbasq_hip.so}; do for cfg in "rbf 10 100" "rbf 24 100" "matern52 24 100" "matern52 6 100" "rbf 34 100"; do set -- $cfg; echo "== $lib $cfg" >> "$out/ab_bs_dims.txt"; BASQ_HIP_LIB=$PWD/basq_amd/csrc/$lib timeout -k 10 120 python tools/bench_blocksum.py --family $1 --d $2 --n $3 --reps 3 2>&1 | grep -v amdgpu.ids >> "$out/ab_bs_dims.txt" || return 1; done; done; done; cat "$out/ab_bs_dims.txt"; }
 job_attribute()   { timeout -k 10 900 python tools/attribute_mismatch.py > "$out/attribute_mismatch.txt" 2>&1; rc=$?; grep -v "amdgpu.ids\|^\[{" "$out/attribute_mismatch.txt" | cut -c1-220; return $rc; }
 job_pmc()         { pmc fetch "FETCH_SIZE" && pmc write "WRITE_SIZE" && pmc pipe "SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" && python tools/pmc_summary.py "$out" > "$out/pmc_summary.json"; rc=$?; cut -c1-400 "$out/pmc_summary.json"; return $rc; }
 
