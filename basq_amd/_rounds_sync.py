@@ -141,7 +141,10 @@ class SyncRounds:
                 trace.rounds.append(rec)
             if final:
                 gids, _ = self._gather_survivors(S)
-                kept_t = torch.tensor(kept_list, dtype=torch.int64, device=gids.device)
+                # (the kept sets are on the device already: no host-to-device copy of the list the host has just read back --
+                #  a synchronous 30-us copy at the very end of every batch, with the GPU idle)
+                kept_t = kept[:n_keep].to(torch.int64) if kept.device == gids.device else \
+                    torch.tensor(kept_list, dtype=torch.int64, device=gids.device)
                 return gids[kept_t], w_star[:n_keep].clone()     # :69-73
             t0 = time.perf_counter()
             if Mc is not None and C_cur >= 2 and 2 * n_keep == S_r and status == 0:
