@@ -51,6 +51,7 @@ PEAK_HBM_GBS = 8000.0
 POOL_SEEDS = (0, 1, 2, 3, 4)        # seeds 0-4, median
 CONFIG_STEPS = 3                    # timed batches per entry of `configs` (after two warm-up batches)
 WATCHDOG_EXIT_CODE = 3              # the runs with batches in flight did not finish on several ranks (the line is printed first)
+TOTAL_LIMIT_EXIT_CODE = 5           # several ranks: the whole run exceeded BASQ_BENCH_TOTAL_LIMIT_S (no line)
 
 WORKLOAD = dict(N=1_000_000, d=10, n=100, nys_ratio=1e-2, family="rbf", lengthscale=2.0, outputscale=1.0, pool_seed=0)
 
@@ -183,6 +184,21 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
         if rank == 0:
             print(f"[bench] RCCL group of {world} up in {time.perf_counter() - t_init:.1f} s", file=sys.stderr)
+
+    if dist is not None and world > 1:
+        # several ranks: a bound on the WHOLE run -- a rank that is stuck in a collective (first contact of the sharded path with a real
+        # multi-GPU node) must not hold the node until the driver's own limit; no line is printed (there is nothing measured to report),
+        # the exit code is a distinct non-zero one, and every rank runs the same timer
+        import threading
+
+        def total_limit():
+            print(f"[bench] rank {rank}: the run did not finish within BASQ_BENCH_TOTAL_LIMIT_S; leaving with code {TOTAL_LIMIT_EXIT_CODE}",
+                  file=sys.stderr, flush=True)
+            os._exit(TOTAL_LIMIT_EXIT_CODE)
+
+        whole = threading.Timer(float(os.environ.get("BASQ_BENCH_TOTAL_LIMIT_S", "1500")), total_limit)
+        whole.daemon = True
+        whole.start()
 
     import basq_amd
     from basq_amd._partition import initial_shards
